@@ -1,0 +1,125 @@
+// Shared internals of libzg_halo2: context object, workspace arena, error plumbing.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <array>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/zg_halo2.h"
+#include "curve.h"
+
+namespace zg {
+
+void set_error(const char* fmt, ...);
+
+#define ZG_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (call);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::zg::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, \
+                            __LINE__);                                                       \
+            return ZG_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+#define ZG_TRY(expr)              \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != ZG_OK) return _s; \
+    } while (0)
+
+#define ZG_REQUIRE(cond, status, ...)   \
+    do {                                \
+        if (!(cond)) {                  \
+            ::zg::set_error(__VA_ARGS__); \
+            return (status);            \
+        }                               \
+    } while (0)
+
+static_assert(sizeof(Fe) == 32 && sizeof(zg_fr) == 32, "field element layout");
+static_assert(sizeof(Affine) == 64 && sizeof(zg_g1_affine) == 64, "affine layout");
+static_assert(sizeof(Jac) == 96 && sizeof(zg_g1) == 96, "jacobian layout");
+static_assert(sizeof(XYZZ) == 128, "xyzz layout");
+
+// Cached HBM blocks.  Every user runs on the context stream, so a block released by one call can
+// be handed to the next without further synchronisation; hipMalloc happens only the first time a
+// size is seen (288 GB of HBM: blocks are kept, never trimmed).
+struct WsBlock {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool used = false;
+};
+
+struct TwiddleKey {
+    uint32_t log_n;
+    std::array<uint64_t, 4> omega;
+    bool operator<(const TwiddleKey& o) const {
+        if (log_n != o.log_n) return log_n < o.log_n;
+        return omega < o.omega;
+    }
+};
+
+}  // namespace zg
+
+struct zg_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+    std::vector<zg::WsBlock> pool;
+    // omega^i, i < 2^log_n, per (log_n, omega): NTT twiddles live in HBM for the context lifetime
+    std::map<zg::TwiddleKey, zg::Fe*> twiddles;
+    // pinned host staging for small D2H results
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    std::mutex mu;
+};
+
+struct zg_bases {
+    zg_ctx* ctx = nullptr;
+    size_t n = 0;
+    uint32_t c = 0;        // window bits
+    uint32_t windows = 0;  // ceil(255 / c)
+    zg::Affine* table = nullptr;  // [windows][n]: 2^(c*w) * P_i, affine
+};
+
+namespace zg {
+
+void* ws_alloc(zg_ctx* ctx, size_t bytes);  // nullptr on failure (error set)
+void ws_release(zg_ctx* ctx, void* p);
+
+// RAII: all blocks taken through a scope go back to the pool when the call returns.
+struct WsScope {
+    zg_ctx* ctx;
+    std::vector<void*> held;
+    bool failed = false;
+    explicit WsScope(zg_ctx* c) : ctx(c) {}
+    ~WsScope() {
+        for (void* p : held) ws_release(ctx, p);
+    }
+    template <class T>
+    T* get(size_t count) {
+        void* p = ws_alloc(ctx, count * sizeof(T) + 256);
+        if (!p) {
+            failed = true;
+            return nullptr;
+        }
+        held.push_back(p);
+        return reinterpret_cast<T*>(p);
+    }
+};
+int pinned_reserve(zg_ctx* ctx, size_t bytes);
+
+// twiddle table for (log_n, omega), created on first use
+int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out);
+
+// host-side constants
+Fe host_domain_omega(uint32_t log_n);
+
+}  // namespace zg

@@ -1,0 +1,133 @@
+// Context, workspace pool and error plumbing of libzg_halo2.
+#include "common.h"
+
+namespace zg {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+void* ws_alloc(zg_ctx* ctx, size_t bytes) {
+    bytes = (bytes + 4095) & ~size_t(4095);
+    WsBlock* best = nullptr;
+    for (auto& b : ctx->pool)
+        if (!b.used && b.cap >= bytes && (!best || b.cap < best->cap)) best = &b;
+    // do not hand a huge block to a tiny request when that would starve a later large one
+    if (best && best->cap <= 4 * bytes + (1u << 20)) {
+        best->used = true;
+        return best->p;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    ctx->pool.push_back(WsBlock{p, bytes, true});
+    return p;
+}
+
+void ws_release(zg_ctx* ctx, void* p) {
+    for (auto& b : ctx->pool)
+        if (b.p == p) {
+            b.used = false;
+            return;
+        }
+}
+
+int pinned_reserve(zg_ctx* ctx, size_t bytes) {
+    if (ctx->pinned_cap >= bytes) return ZG_OK;
+    if (ctx->pinned) {
+        ZG_HIP(hipStreamSynchronize(ctx->stream));
+        ZG_HIP(hipHostFree(ctx->pinned));
+        ctx->pinned = nullptr;
+        ctx->pinned_cap = 0;
+    }
+    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+    ZG_HIP(hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+    ctx->pinned_cap = cap;
+    return ZG_OK;
+}
+
+Fe host_domain_omega(uint32_t log_n) {
+    Fe w = fr_root_of_unity();
+    for (uint32_t i = log_n; i < FR_S; i++) w = Fr::sqr(w);
+    return w;
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+const char* zg_last_error(void) { return g_last_error.c_str(); }
+
+const char* zg_version(void) { return "zg_halo2 0.1 (gfx950)"; }
+
+int zg_ctx_create(int device_id, zg_ctx** out) {
+    ZG_REQUIRE(out != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("zg_ctx_create: no HIP device visible (%s); this library has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return ZG_ERR_NO_DEVICE;
+    }
+    ZG_REQUIRE(device_id >= 0 && device_id < count, ZG_ERR_INVALID_ARG,
+               "zg_ctx_create: device %d out of range (%d devices)", device_id, count);
+    ZG_HIP(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    ZG_HIP(hipGetDeviceProperties(&prop, device_id));
+    zg_ctx* ctx = new zg_ctx();
+    ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return ZG_ERR_HIP;
+    }
+    *out = ctx;
+    return ZG_OK;
+}
+
+void zg_ctx_destroy(zg_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
+    for (auto& b : ctx->pool) (void)hipFree(b.p);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int zg_ctx_sync(zg_ctx* ctx) {
+    ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_sync: ctx is null");
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+void* zg_ctx_stream(zg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int zg_domain_omega(uint32_t log_n, zg_fr* omega, zg_fr* omega_inv) {
+    ZG_REQUIRE(log_n <= FR_S, ZG_ERR_INVALID_ARG, "zg_domain_omega: log_n %u > 28", log_n);
+    Fe w = host_domain_omega(log_n);
+    if (omega) memcpy(omega, &w, 32);
+    if (omega_inv) {
+        Fe wi = Fr::inv(w);
+        memcpy(omega_inv, &wi, 32);
+    }
+    return ZG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+// BN254 prime-field arithmetic for gfx950 (and the host side of the same library).
+//
+// Replaces halo2curves 0.3.3 `bn256::{Fr, Fq}` (reference import: /root/reference/src/wnn.rs:18)
+// on the device.  Memory format is the reference's: 4 x u64 little-endian limbs in Montgomery form
+// (R = 2^256); in registers an element is 8 x u32 limbs, because the CDNA4 VALU multiplies
+// 32 x 32 -> 64 (v_mad_u64_u32) and has no 64-bit vector multiplier.  No MFMA: this is modular
+// integer arithmetic, not a dense contraction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZG_HD __host__ __device__ __forceinline__
+
+namespace zg {
+
+struct alignas(16) Fe {
+    uint32_t l[8];
+};
+
+// ---- per-field constants --------------------------------------------------------------------
+struct FrParams {
+    static ZG_HD uint32_t p(int i) {
+        constexpr uint32_t P[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
+                                   0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return P[i];
+    }
+    static constexpr uint32_t INV = 0xefffffffu;  // -p^-1 mod 2^32
+    static ZG_HD Fe one() {  // R mod p
+        return Fe{{0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu,
+                   0x9a07df2fu, 0x0e0a77c1u}};
+    }
+    static ZG_HD Fe r2() {  // R^2 mod p
+        return Fe{{0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du,
+                   0x7f4e44a5u, 0x0216d0b1u}};
+    }
+};
+
+struct FqParams {
+    static ZG_HD uint32_t p(int i) {
+        constexpr uint32_t P[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
+                                   0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return P[i];
+    }
+    static constexpr uint32_t INV = 0xe4866389u;
+    static ZG_HD Fe one() {
+        return Fe{{0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u, 0x7879462cu, 0x666ea36fu,
+                   0x9a07df2fu, 0x0e0a77c1u}};
+    }
+    static ZG_HD Fe r2() {
+        return Fe{{0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u, 0x0a417ff6u, 0x47ab1effu,
+                   0xcab8351fu, 0x06d89f71u}};
+    }
+};
+
+// ---- generic helpers ------------------------------------------------------------------------
+ZG_HD Fe fe_zero() { return Fe{{0, 0, 0, 0, 0, 0, 0, 0}}; }
+
+ZG_HD bool fe_is_zero(const Fe& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i];
+    return o == 0;
+}
+
+ZG_HD bool fe_eq(const Fe& a, const Fe& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
+    return o == 0;
+}
+
+// a + b with carry out
+ZG_HD uint32_t add8(uint32_t* o, const uint32_t* a, const uint32_t* b) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)a[i] + b[i];
+        o[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    return (uint32_t)c;
+}
+
+// a - b with borrow out (1 = borrowed)
+ZG_HD uint32_t sub8(uint32_t* o, const uint32_t* a, const uint32_t* b) {
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (int64_t)a[i] - (int64_t)b[i];
+        o[i] = (uint32_t)c;
+        c >>= 32;  // arithmetic shift: 0 or -1
+    }
+    return (uint32_t)(c & 1);
+}
+
+template <class P>
+struct Field {
+    static ZG_HD Fe zero() { return fe_zero(); }
+    static ZG_HD Fe one() { return P::one(); }
+
+    // conditional subtract: a in [0, 2p) -> [0, p)
+    static ZG_HD void reduce_once(Fe& a) {
+        uint32_t pm[8], t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pm[i] = P::p(i);
+        uint32_t borrow = sub8(t, a.l, pm);
+        if (!borrow) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) a.l[i] = t[i];
+        }
+    }
+
+    static ZG_HD Fe add(const Fe& a, const Fe& b) {
+        Fe o;
+        add8(o.l, a.l, b.l);  // p < 2^254: no carry out
+        reduce_once(o);
+        return o;
+    }
+
+    static ZG_HD Fe sub(const Fe& a, const Fe& b) {
+        Fe o;
+        uint32_t borrow = sub8(o.l, a.l, b.l);
+        if (borrow) {
+            uint32_t pm[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) pm[i] = P::p(i);
+            add8(o.l, o.l, pm);
+        }
+        return o;
+    }
+
+    static ZG_HD Fe neg(const Fe& a) {
+        if (fe_is_zero(a)) return a;
+        Fe o;
+        uint32_t pm[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pm[i] = P::p(i);
+        sub8(o.l, pm, a.l);
+        return o;
+    }
+
+    static ZG_HD Fe dbl(const Fe& a) { return add(a, a); }
+
+    // Montgomery product a*b*R^-1 mod p.  CIOS, fused multiply/reduce rows; the modulus leaves
+    // two spare top bits so the running value never needs a 10th word.
+    static ZG_HD Fe mul(const Fe& a, const Fe& b) {
+        uint32_t t[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) t[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t A = (uint64_t)a.l[0] * b.l[i] + t[0];
+            uint32_t m = (uint32_t)A * P::INV;
+            uint64_t C = (uint64_t)m * P::p(0) + (uint32_t)A;
+            A >>= 32;
+            C >>= 32;
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                A += (uint64_t)a.l[j] * b.l[i] + t[j];
+                C += (uint64_t)m * P::p(j) + (uint32_t)A;
+                t[j - 1] = (uint32_t)C;
+                A >>= 32;
+                C >>= 32;
+            }
+            t[7] = (uint32_t)(A + C);
+        }
+        Fe o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = t[i];
+        reduce_once(o);
+        return o;
+    }
+
+    static ZG_HD Fe sqr(const Fe& a) { return mul(a, a); }
+
+    static ZG_HD Fe from_raw(const Fe& a) { return mul(a, P::r2()); }  // canonical -> Montgomery
+
+    static ZG_HD Fe to_raw(const Fe& a) {  // Montgomery -> canonical integer
+        Fe one_raw = fe_zero();
+        one_raw.l[0] = 1;
+        return mul(a, one_raw);
+    }
+
+    static ZG_HD Fe from_u64(uint64_t v) {
+        Fe t = fe_zero();
+        t.l[0] = (uint32_t)v;
+        t.l[1] = (uint32_t)(v >> 32);
+        return from_raw(t);
+    }
+
+    // a^e for a 256-bit exponent given as 8 LE u32 limbs (left-to-right square and multiply)
+    static ZG_HD Fe pow(const Fe& a, const uint32_t e[8]) {
+        Fe res = one();
+        for (int i = 7; i >= 0; i--)
+            for (int b = 31; b >= 0; b--) {
+                res = sqr(res);
+                if ((e[i] >> b) & 1) res = mul(res, a);
+            }
+        return res;
+    }
+
+    static ZG_HD Fe pow_u64(const Fe& a, uint64_t e) {
+        Fe res = one();
+        bool started = false;
+        for (int b = 63; b >= 0; b--) {
+            if (started) res = sqr(res);
+            if ((e >> b) & 1) {
+                res = mul(res, a);
+                started = true;
+            }
+        }
+        return res;
+    }
+
+    // Fermat inversion a^(p-2); 0 -> 0
+    static ZG_HD Fe inv(const Fe& a) {
+        uint32_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) e[i] = P::p(i);
+        e[0] -= 2;
+        return pow(a, e);
+    }
+};
+
+using Fr = Field<FrParams>;
+using Fq = Field<FqParams>;
+
+// halo2curves bn256::Fr constants, Montgomery form (tests re-derive them with Python integers)
+ZG_HD Fe fr_root_of_unity() {  // 7^((r-1)/2^28)
+    return Fe{{0xb639feb8u, 0x9632c7c5u, 0x0d0ff299u, 0x985ce340u, 0x01b0ecd8u, 0xb2dd8800u,
+               0x6d98ce29u, 0x1d69070du}};
+}
+ZG_HD Fe fr_delta() {  // 7^(2^28)
+    return Fe{{0xefd78855u, 0x9a0c322bu, 0x249b563cu, 0x46e82d14u, 0xe0b0b7a7u, 0x5983a663u,
+               0xaaa111adu, 0x22ab452bu}};
+}
+ZG_HD Fe fr_zeta() {  // 7^((r-1)/3): the coset generator of EvaluationDomain
+    return Fe{{0x4a0329b3u, 0x93e7cedeu, 0x7a96c167u, 0x7d4fdca7u, 0xb19a750au, 0x8be4ba08u,
+               0xa5661c25u, 0x1cbd5653u}};
+}
+constexpr uint32_t FR_S = 28;  // two-adicity
+
+}  // namespace zg

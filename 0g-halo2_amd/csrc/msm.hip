@@ -1,0 +1,505 @@
+// Pippenger multi-scalar multiplication on BN254 G1 for gfx950 -- replaces
+// halo2_proofs::arithmetic::best_multiexp as reached through ParamsKZG::{commit, commit_lagrange}
+// (halo2_proofs v2023_04_20 src/arithmetic.rs, src/poly/kzg/commitment.rs), i.e. every commitment
+// made by create_proof (reference call site /root/reference/src/wnn.rs:242-259; 30 per WNN proof).
+//
+// MI355X-first structure (not halo2's per-thread windows + doubling ladder):
+//   * The base sets are fixed (ParamsKZG::g, ::g_lagrange), HBM is 288 GB: at registration every
+//     base gets W = ceil(255/c) precomputed affine copies 2^(c*w) * P_i.  All windows then share
+//     ONE bucket set per scalar vector, and the 254-doubling window combine -- a serial chain that
+//     a 64-lane SIMT machine cannot hide -- disappears.
+//   * signed c-bit digits halve the bucket count (buckets 1 .. 2^(c-1)).
+//   * digits are counted with integer atomics, scanned, scattered into bucket order, then split
+//     into tasks of at most K points so that hot buckets (advice columns are mostly 0/1/bytes)
+//     cannot serialise a wavefront; each lane accumulates one task in XYZZ coordinates.
+//   * sum_k k*B_k is taken bit-wise: G_j = sum of task partials whose bucket index has bit j,
+//     result = sum_j 2^j G_j -- strip sums, an LDS tree per (vector, bit), and one wavefront per
+//     vector for the final 2^j ladder.
+//   * batches of scalar vectors sharing one base set (6+8+7+5+4 per proof) run as one launch
+//     sequence: grid.y = vector index.
+// Integer-ALU bound (a mixed add is 10 field products of ~130 v_mad_u64_u32 each); no MFMA.
+#include "common.h"
+
+namespace zg {
+
+constexpr uint32_t MSM_K = 16;       // max points per accumulate task
+constexpr uint32_t MSM_STRIP = 16;   // task partials per level-1 reduce strip
+constexpr uint32_t MSM_MAX_C = 16;
+
+__device__ __forceinline__ Fe ld_fe_g(const Fe* p) {
+    Fe r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void st_fe_g(Fe* p, const Fe& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+__device__ __forceinline__ XYZZ ld_xyzz(const XYZZ* p) {
+    XYZZ r;
+    r.x = ld_fe_g(&p->x); r.y = ld_fe_g(&p->y); r.zz = ld_fe_g(&p->zz); r.zzz = ld_fe_g(&p->zzz);
+    return r;
+}
+__device__ __forceinline__ void st_xyzz(XYZZ* p, const XYZZ& v) {
+    st_fe_g(&p->x, v.x); st_fe_g(&p->y, v.y); st_fe_g(&p->zz, v.zz); st_fe_g(&p->zzz, v.zzz);
+}
+
+// ---------------------------------------------------------------- base table
+// table[w][i] = 2^(c*w) * P_i in affine form.  One thread per base point, windows in sequence.
+__global__ void msm_table_kernel(const Affine* __restrict__ bases, Affine* __restrict__ table,
+                                 uint32_t n, uint32_t c, uint32_t windows) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Affine p;
+    p.x = ld_fe_g(&bases[i].x);
+    p.y = ld_fe_g(&bases[i].y);
+    st_fe_g(&table[i].x, p.x);
+    st_fe_g(&table[i].y, p.y);
+    for (uint32_t w = 1; w < windows; w++) {
+        XYZZ acc = xyzz_dbl_affine(p);
+        for (uint32_t d = 1; d < c; d++) acc = xyzz_dbl(acc);
+        p = xyzz_to_affine(acc);
+        st_fe_g(&table[(size_t)w * n + i].x, p.x);
+        st_fe_g(&table[(size_t)w * n + i].y, p.y);
+    }
+}
+
+// ---------------------------------------------------------------- digits
+struct Digits {
+    uint32_t raw[8];
+};
+
+// bits [lo, lo+c) of the canonical scalar (zero beyond bit 255)
+__device__ __forceinline__ uint32_t window_bits(const uint32_t raw[8], uint32_t lo, uint32_t c) {
+    uint32_t limb = lo >> 5, sh = lo & 31;
+    if (limb >= 8) return 0;
+    uint64_t v = raw[limb];
+    if (limb + 1 < 8) v |= (uint64_t)raw[limb + 1] << 32;
+    return (uint32_t)(v >> sh) & ((1u << c) - 1);
+}
+
+// Pass 1 over the scalars: signed digits, bucket histogram; the slot each entry takes inside its
+// bucket is the value its atomic returned.
+__global__ void msm_count_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n, uint32_t c,
+                                 uint32_t windows, uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t b = blockIdx.y;
+    if (i >= n) return;
+    const uint32_t nb = 1u << (c - 1);
+    Fe s = Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i));
+    uint32_t* cb = cnt + (size_t)b * (nb + 1);
+    uint32_t* sb = slot + (size_t)b * windows * n;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < windows; w++) {
+        uint32_t d = window_bits(s.l, w * c, c) + carry;
+        carry = 0;
+        uint32_t k = d;
+        if (d > nb) {
+            k = (1u << c) - d;
+            carry = 1;
+        }
+        uint32_t sl = 0xffffffffu;
+        if (k != 0) sl = atomicAdd(&cb[k], 1u);
+        sb[(size_t)w * n + i] = sl;
+    }
+}
+
+// Exclusive scans of the bucket histogram (entry offsets) and of ceil(count / K) (task offsets).
+// One 1024-thread workgroup per scalar vector.
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t c,
+                                                        uint32_t* __restrict__ boff,
+                                                        uint32_t* __restrict__ toff,
+                                                        uint32_t* __restrict__ ttotal) {
+    __shared__ uint32_t se[1024], st[1024];
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const uint32_t* cb = cnt + (size_t)b * (nb + 1);
+    uint32_t* bo = boff + (size_t)b * (nb + 2);
+    uint32_t* to = toff + (size_t)b * (nb + 2);
+    const uint32_t per = (nb + 1 + 1023) / 1024;
+    uint32_t lo = tid * per, hi = lo + per;
+    if (hi > nb + 1) hi = nb + 1;
+    uint32_t es = 0, ts = 0;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t v = cb[k];
+        es += v;
+        ts += (v + MSM_K - 1) / MSM_K;
+    }
+    se[tid] = es;
+    st[tid] = ts;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        uint32_t ve = 0, vt = 0;
+        if (tid >= off) {
+            ve = se[tid - off];
+            vt = st[tid - off];
+        }
+        __syncthreads();
+        se[tid] += ve;
+        st[tid] += vt;
+        __syncthreads();
+    }
+    uint32_t eb = se[tid] - es, tb = st[tid] - ts;
+    for (uint32_t k = lo; k < hi; k++) {
+        uint32_t v = cb[k];
+        bo[k] = eb;
+        to[k] = tb;
+        eb += v;
+        tb += (v + MSM_K - 1) / MSM_K;
+    }
+    if (tid == 1023) {
+        bo[nb + 1] = se[1023];
+        to[nb + 1] = st[1023];
+        ttotal[b] = st[1023];
+    }
+}
+
+// Pass 2 over the scalars: write (point, window, sign) into bucket order.
+__global__ void msm_scatter_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n, uint32_t c,
+                                   uint32_t windows, const uint32_t* __restrict__ boff,
+                                   const uint32_t* __restrict__ slot, uint32_t* __restrict__ sorted) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t b = blockIdx.y;
+    if (i >= n) return;
+    const uint32_t nb = 1u << (c - 1);
+    Fe s = Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i));
+    const uint32_t* bo = boff + (size_t)b * (nb + 2);
+    const uint32_t* sb = slot + (size_t)b * windows * n;
+    uint32_t* so = sorted + (size_t)b * windows * n;
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < windows; w++) {
+        uint32_t d = window_bits(s.l, w * c, c) + carry;
+        carry = 0;
+        uint32_t k = d, neg = 0;
+        if (d > nb) {
+            k = (1u << c) - d;
+            carry = 1;
+            neg = 1;
+        }
+        if (k != 0) {
+            uint32_t sl = sb[(size_t)w * n + i];
+            so[bo[k] + sl] = i | (w << 24) | (neg << 31);
+        }
+    }
+}
+
+// One lane per task: at most K points of one bucket, mixed adds in XYZZ.
+__global__ __launch_bounds__(256) void msm_accumulate_kernel(
+    const Affine* __restrict__ table, uint32_t n_table, uint32_t c, uint32_t windows, uint32_t n,
+    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ toff,
+    const uint32_t* __restrict__ ttotal, const uint32_t* __restrict__ sorted, uint32_t max_tasks,
+    XYZZ* __restrict__ partial, uint32_t* __restrict__ pkey) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t b = blockIdx.y;
+    if (t >= ttotal[b]) return;
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t* to = toff + (size_t)b * (nb + 2);
+    // largest k with to[k] <= t  (to is non-decreasing, to[nb+1] = total > t)
+    uint32_t lo = 0, hi = nb + 1;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (to[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    const uint32_t k = lo;
+    const uint32_t j = t - to[k];
+    const uint32_t count = cnt[(size_t)b * (nb + 1) + k];
+    const uint32_t start = boff[(size_t)b * (nb + 2) + k] + j * MSM_K;
+    uint32_t len = count - j * MSM_K;
+    if (len > MSM_K) len = MSM_K;
+    const uint32_t* so = sorted + (size_t)b * windows * n + start;
+    XYZZ acc = xyzz_identity();
+    for (uint32_t e = 0; e < len; e++) {
+        uint32_t ent = so[e];
+        uint32_t i = ent & 0xffffffu, w = (ent >> 24) & 0x7fu;
+        const Affine* src = table + (size_t)w * n_table + i;
+        Affine p;
+        p.x = ld_fe_g(&src->x);
+        p.y = ld_fe_g(&src->y);
+        if (ent >> 31) p.y = Fq::neg(p.y);
+        acc = xyzz_madd(acc, p);
+    }
+    st_xyzz(partial + (size_t)b * max_tasks + t, acc);
+    pkey[(size_t)b * max_tasks + t] = k;
+}
+
+// Level 1 of sum_k k*B_k: lane (strip, bit j, vector b) adds the partials of its strip whose
+// bucket index has bit j set.
+__global__ __launch_bounds__(256) void msm_reduce1_kernel(const XYZZ* __restrict__ partial,
+                                                          const uint32_t* __restrict__ pkey,
+                                                          const uint32_t* __restrict__ ttotal,
+                                                          uint32_t max_tasks, uint32_t max_strips,
+                                                          uint32_t c, XYZZ* __restrict__ l1) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t j = blockIdx.y, b = blockIdx.z;
+    uint32_t total = ttotal[b];
+    uint32_t nstrips = (total + MSM_STRIP - 1) / MSM_STRIP;
+    if (s >= nstrips) return;
+    uint32_t t0 = s * MSM_STRIP, t1 = t0 + MSM_STRIP;
+    if (t1 > total) t1 = total;
+    const XYZZ* pp = partial + (size_t)b * max_tasks;
+    const uint32_t* pk = pkey + (size_t)b * max_tasks;
+    XYZZ acc = xyzz_identity();
+    for (uint32_t t = t0; t < t1; t++)
+        if ((pk[t] >> j) & 1u) acc = xyzz_add(acc, ld_xyzz(pp + t));
+    st_xyzz(l1 + ((size_t)b * c + j) * max_strips + s, acc);
+}
+
+// Level 2: one 256-thread workgroup per (vector, bit): strided serial sums, then an LDS tree.
+__global__ __launch_bounds__(256) void msm_reduce2_kernel(const XYZZ* __restrict__ l1,
+                                                          const uint32_t* __restrict__ ttotal,
+                                                          uint32_t max_strips, uint32_t c,
+                                                          XYZZ* __restrict__ g) {
+    __shared__ XYZZ sh[256];
+    uint32_t j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    uint32_t nstrips = (ttotal[b] + MSM_STRIP - 1) / MSM_STRIP;
+    const XYZZ* src = l1 + ((size_t)b * c + j) * max_strips;
+    XYZZ acc = xyzz_identity();
+    for (uint32_t s = tid; s < nstrips; s += 256) acc = xyzz_add(acc, ld_xyzz(src + s));
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t off = 128; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) st_xyzz(g + (size_t)b * c + j, sh[0]);
+}
+
+// Final ladder: lane j doubles G_j j times, then the c lanes are added pairwise through LDS.
+__global__ __launch_bounds__(64) void msm_final_kernel(const XYZZ* __restrict__ g, uint32_t c,
+                                                       XYZZ* __restrict__ out) {
+    __shared__ XYZZ sh[64];
+    uint32_t b = blockIdx.x, tid = threadIdx.x;
+    XYZZ acc = xyzz_identity();
+    if (tid < c) {
+        acc = ld_xyzz(g + (size_t)b * c + tid);
+        for (uint32_t d = 0; d < tid; d++) acc = xyzz_dbl(acc);
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t off = 32; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) st_xyzz(out + b, sh[0]);
+}
+
+static uint32_t default_window_bits(size_t n) {
+    uint32_t lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) lg++;
+    int c = (int)lg - 1;
+    if (c < 4) c = 4;
+    if (c > (int)MSM_MAX_C) c = MSM_MAX_C;
+    return (uint32_t)c;
+}
+
+int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t window_bits, zg_bases** out) {
+    ZG_REQUIRE(n > 0 && n < (1u << 24), ZG_ERR_UNSUPPORTED, "zg_bases_register: n=%zu out of range", n);
+    uint32_t c = window_bits ? window_bits : default_window_bits(n);
+    ZG_REQUIRE(c >= 2 && c <= MSM_MAX_C, ZG_ERR_INVALID_ARG, "zg_bases_register: window_bits %u not in [2,16]", c);
+    uint32_t windows = (255 + c - 1) / c;
+    zg_bases* b = new zg_bases();
+    b->ctx = ctx;
+    b->n = n;
+    b->c = c;
+    b->windows = windows;
+    hipError_t e = hipMalloc(&b->table, (size_t)windows * n * sizeof(Affine));
+    if (e != hipSuccess) {
+        set_error("zg_bases_register: hipMalloc(%zu) failed: %s", (size_t)windows * n * sizeof(Affine),
+                  hipGetErrorString(e));
+        delete b;
+        return ZG_ERR_OOM;
+    }
+    hipLaunchKernelGGL(msm_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_bases,
+                       b->table, (uint32_t)n, c, windows);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        set_error("zg_bases_register: table kernel failed: %s", hipGetErrorString(e));
+        (void)hipFree(b->table);
+        delete b;
+        return ZG_ERR_HIP;
+    }
+    *out = b;
+    return ZG_OK;
+}
+
+int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch,
+                  size_t n, XYZZ* d_out) {
+    ZG_REQUIRE(n <= bases->n, ZG_ERR_INVALID_ARG, "zg_msm: %zu scalars for %zu bases", n, bases->n);
+    ZG_REQUIRE(batch <= 65535, ZG_ERR_UNSUPPORTED, "zg_msm: batch %zu > 65535", batch);
+    if (batch == 0) return ZG_OK;
+    const uint32_t c = bases->c, W = bases->windows, nb = 1u << (c - 1);
+    const uint32_t B = (uint32_t)batch, N = (uint32_t)n;
+    if (n == 0) {
+        std::vector<XYZZ> ids(batch, xyzz_identity());
+        ZG_HIP(hipMemcpyAsync(d_out, ids.data(), batch * sizeof(XYZZ), hipMemcpyHostToDevice, ctx->stream));
+        ZG_HIP(hipStreamSynchronize(ctx->stream));
+        return ZG_OK;
+    }
+    const uint64_t entries = (uint64_t)N * W;
+    ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
+    uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
+    const uint32_t max_tasks = (uint32_t)mt;
+    const uint32_t max_strips = (max_tasks + MSM_STRIP - 1) / MSM_STRIP;
+
+    WsScope ws(ctx);
+    uint32_t* cnt = ws.get<uint32_t>((size_t)B * (nb + 1));
+    uint32_t* slot = ws.get<uint32_t>((size_t)B * entries);
+    uint32_t* boff = ws.get<uint32_t>((size_t)B * (nb + 2));
+    uint32_t* toff = ws.get<uint32_t>((size_t)B * (nb + 2));
+    uint32_t* ttotal = ws.get<uint32_t>(B);
+    uint32_t* sorted = ws.get<uint32_t>((size_t)B * entries);
+    XYZZ* partial = ws.get<XYZZ>((size_t)B * max_tasks);
+    uint32_t* pkey = ws.get<uint32_t>((size_t)B * max_tasks);
+    XYZZ* l1 = ws.get<XYZZ>((size_t)B * c * max_strips);
+    XYZZ* g = ws.get<XYZZ>((size_t)B * c);
+    if (ws.failed) return ZG_ERR_OOM;
+
+    hipStream_t st = ctx->stream;
+    ZG_HIP(hipMemsetAsync(cnt, 0, (size_t)B * (nb + 1) * sizeof(uint32_t), st));
+    dim3 gs((N + 255) / 256, B);
+    hipLaunchKernelGGL(msm_count_kernel, gs, dim3(256), 0, st, d_scalars, stride, N, c, W, cnt, slot);
+    hipLaunchKernelGGL(msm_scan_kernel, dim3(B), dim3(1024), 0, st, cnt, c, boff, toff, ttotal);
+    hipLaunchKernelGGL(msm_scatter_kernel, gs, dim3(256), 0, st, d_scalars, stride, N, c, W, boff, slot, sorted);
+    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0, st,
+                       bases->table, (uint32_t)bases->n, c, W, N, cnt, boff, toff, ttotal, sorted, max_tasks,
+                       partial, pkey);
+    hipLaunchKernelGGL(msm_reduce1_kernel, dim3((max_strips + 255) / 256, c, B), dim3(256), 0, st, partial,
+                       pkey, ttotal, max_tasks, max_strips, c, l1);
+    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(c, B), dim3(256), 0, st, l1, ttotal, max_strips, c, g);
+    hipLaunchKernelGGL(msm_final_kernel, dim3(B), dim3(64), 0, st, g, c, d_out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+// host: XYZZ -> normalised Jacobian (z = 1; identity = (0, 1, 0)), one shared inversion
+void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out) {
+    std::vector<Fe> pre(count);
+    Fe acc = Fq::one();
+    for (size_t i = 0; i < count; i++) {
+        pre[i] = acc;
+        if (!xyzz_is_identity(in[i])) acc = Fq::mul(acc, Fq::mul(in[i].zz, in[i].zzz));
+    }
+    acc = Fq::inv(acc);
+    for (size_t i = count; i-- > 0;) {
+        Jac j;
+        if (xyzz_is_identity(in[i])) {
+            j.x = fe_zero();
+            j.y = Fq::one();
+            j.z = fe_zero();
+        } else {
+            Fe zz_zzz = Fq::mul(in[i].zz, in[i].zzz);
+            Fe inv = Fq::mul(acc, pre[i]);  // 1 / (zz*zzz)
+            acc = Fq::mul(acc, zz_zzz);
+            j.x = Fq::mul(in[i].x, Fq::mul(inv, in[i].zzz));
+            j.y = Fq::mul(in[i].y, Fq::mul(inv, in[i].zz));
+            j.z = Fq::one();
+        }
+        memcpy(&out[i], &j, sizeof(Jac));
+    }
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+extern "C" {
+
+int zg_bases_register_dev(zg_ctx* ctx, const void* d_bases, size_t n, uint32_t window_bits, zg_bases** out) {
+    ZG_REQUIRE(ctx && d_bases && out, ZG_ERR_INVALID_ARG, "zg_bases_register_dev: null argument");
+    ZG_HIP(hipSetDevice(ctx->device));
+    return bases_register_dev(ctx, (const Affine*)d_bases, n, window_bits, out);
+}
+
+int zg_bases_register(zg_ctx* ctx, const zg_g1_affine* bases, size_t n, uint32_t window_bits, zg_bases** out) {
+    ZG_REQUIRE(ctx && bases && out, ZG_ERR_INVALID_ARG, "zg_bases_register: null argument");
+    ZG_HIP(hipSetDevice(ctx->device));
+    WsScope ws(ctx);
+    Affine* d = ws.get<Affine>(n ? n : 1);
+    if (!d) return ZG_ERR_OOM;
+    ZG_HIP(hipMemcpyAsync(d, bases, n * sizeof(Affine), hipMemcpyHostToDevice, ctx->stream));
+    return bases_register_dev(ctx, d, n, window_bits, out);
+}
+
+void zg_bases_free(zg_bases* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->table);
+    delete b;
+}
+
+size_t zg_bases_len(const zg_bases* b) { return b ? b->n : 0; }
+uint32_t zg_bases_window_bits(const zg_bases* b) { return b ? b->c : 0; }
+
+int zg_msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const void* d_scalars, size_t stride_elems,
+                     size_t batch, size_t n, void* d_out_xyzz) {
+    ZG_REQUIRE(ctx && bases && d_scalars && d_out_xyzz, ZG_ERR_INVALID_ARG, "zg_msm_batch_dev: null argument");
+    ZG_REQUIRE(bases->ctx == ctx, ZG_ERR_INVALID_ARG, "zg_msm_batch_dev: bases belong to another context");
+    ZG_HIP(hipSetDevice(ctx->device));
+    return msm_batch_dev(ctx, bases, (const Fe*)d_scalars, stride_elems, batch, n, (XYZZ*)d_out_xyzz);
+}
+
+int zg_msm_finish(zg_ctx* ctx, const void* d_xyzz, size_t batch, zg_g1* out) {
+    ZG_REQUIRE(ctx && d_xyzz && out, ZG_ERR_INVALID_ARG, "zg_msm_finish: null argument");
+    if (batch == 0) return ZG_OK;
+    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_TRY(pinned_reserve(ctx, batch * sizeof(XYZZ)));
+    ZG_HIP(hipMemcpyAsync(ctx->pinned, d_xyzz, batch * sizeof(XYZZ), hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    xyzz_batch_normalise((const XYZZ*)ctx->pinned, batch, out);
+    return ZG_OK;
+}
+
+int zg_msm_batch(zg_ctx* ctx, const zg_bases* bases, const zg_fr* const* scalars, size_t batch, size_t n,
+                 zg_g1* out) {
+    ZG_REQUIRE(ctx && bases && out && (scalars || batch == 0), ZG_ERR_INVALID_ARG, "zg_msm_batch: null argument");
+    ZG_REQUIRE(bases->ctx == ctx, ZG_ERR_INVALID_ARG, "zg_msm_batch: bases belong to another context");
+    ZG_REQUIRE(n <= bases->n, ZG_ERR_INVALID_ARG, "zg_msm_batch: %zu scalars for %zu bases", n, bases->n);
+    if (batch == 0) return ZG_OK;
+    ZG_HIP(hipSetDevice(ctx->device));
+    WsScope ws(ctx);
+    Fe* d = ws.get<Fe>(batch * (n ? n : 1));
+    XYZZ* r = ws.get<XYZZ>(batch);
+    if (ws.failed) return ZG_ERR_OOM;
+    for (size_t b = 0; b < batch; b++) {
+        ZG_REQUIRE(scalars[b] != nullptr || n == 0, ZG_ERR_INVALID_ARG, "zg_msm_batch: scalars[%zu] is null", b);
+        if (n) ZG_HIP(hipMemcpyAsync(d + b * n, scalars[b], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ZG_TRY(msm_batch_dev(ctx, bases, d, n, batch, n, r));
+    return zg_msm_finish(ctx, r, batch, out);
+}
+
+int zg_msm(zg_ctx* ctx, const zg_bases* bases, const zg_fr* scalars, size_t n, zg_g1* out) {
+    const zg_fr* arr[1] = {scalars};
+    return zg_msm_batch(ctx, bases, arr, 1, n, out);
+}
+
+int zg_g1_sum(const zg_g1* parts, size_t count, zg_g1* out) {
+    ZG_REQUIRE(out && (parts || count == 0), ZG_ERR_INVALID_ARG, "zg_g1_sum: null argument");
+    XYZZ acc = xyzz_identity();
+    for (size_t i = 0; i < count; i++) {
+        Jac j;
+        memcpy(&j, &parts[i], sizeof(Jac));
+        XYZZ p;
+        if (jac_is_identity(j)) {
+            p = xyzz_identity();
+        } else {
+            p.x = j.x;
+            p.y = j.y;
+            p.zz = Fq::sqr(j.z);
+            p.zzz = Fq::mul(p.zz, j.z);
+        }
+        acc = xyzz_add(acc, p);
+    }
+    xyzz_batch_normalise(&acc, 1, out);
+    return ZG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,508 @@
+// Radix-2 NTT / iNTT over BN254 Fr for gfx950 -- replaces halo2_proofs::arithmetic::best_fft and the
+// EvaluationDomain wrappers lagrange_to_coeff / coeff_to_extended / extended_to_coeff
+// (halo2_proofs v2023_04_20 src/arithmetic.rs, src/poly/domain.rs; reached from create_proof,
+// reference call site /root/reference/src/wnn.rs:242-259).
+//
+// Structure (MI355X-first, not halo2's recursive butterfly):
+//   N = N1 * N2.  Pass 1 ("cols"): each workgroup stages an [N1][C] tile of C adjacent columns in
+//   LDS, runs the size-N1 DIF butterflies there, multiplies by the inter-pass twiddle
+//   omega^(j2*k1) and writes rows of C contiguous elements.  Pass 2 ("rows"): each workgroup stages
+//   R contiguous rows of N2, runs the size-N2 butterflies in LDS and writes X[k1 + N1*k2] so that R
+//   neighbouring k1 form one contiguous segment.  Natural order in, natural order out, the
+//   bit-reversal is absorbed into the LDS read index of the store loop.  Twiddles omega^i come
+//   from one HBM table per (log_n, omega) (coalesced 32-B loads, L2 resident), the per-tile
+//   sub-transform twiddles are staged in LDS.  Zero padding, the zeta^(i mod 3) coset scaling, the
+//   ifft divisor and the truncation of extended_to_coeff are fused into the first load / last
+//   store so a polynomial crosses HBM exactly twice per transform.
+// The kernel is integer-ALU bound (one 254-bit Montgomery product per butterfly), not MFMA work.
+#include "common.h"
+
+namespace zg {
+
+struct NttArgs {
+    const Fe* in;
+    Fe* out;
+    const Fe* tw;       // omega^i, i < N
+    size_t in_stride;   // elements between consecutive batch arrays
+    size_t out_stride;
+    uint32_t log_n, log_n1, log_n2;
+    uint32_t in_len;    // FIRST pass: input entries beyond in_len read as zero
+    uint32_t out_len;   // LAST pass: entries >= out_len are not written
+    uint32_t coset_in;  // FIRST pass: multiply entry j by zin[j % 3]
+    uint32_t coset_out; // LAST pass: multiply entry k by zout[k % 3]
+    uint32_t scale_out; // LAST pass: multiply by `scale`
+    Fe zin1, zin2, zout1, zout2, scale;
+};
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) {
+    return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
+}
+
+__device__ __forceinline__ Fe ld_fe(const Fe* p) {
+    Fe r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
+    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
+    return r;
+}
+
+__device__ __forceinline__ void st_fe(Fe* p, const Fe& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+// One pass over LDS tiles of T = 2^LOG_T elements with T/4 threads.
+//   COLS : tile = [M = N1][cnt = T/N1 columns], sub-transform along the column (stride cnt)
+//   !COLS: tile = [cnt = min(T/N2, N1) rows][M = N2], sub-transform along the row
+//   FIRST: this pass reads the caller's input (zero padding / coset scaling apply)
+// The rows pass is always the last one (output scaling / truncation apply there).
+template <int LOG_T, bool COLS, bool FIRST>
+__global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
+    constexpr uint32_t T = 1u << LOG_T;
+    constexpr uint32_t NT = T / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    Fe* X = reinterpret_cast<Fe*>(smem);
+    Fe* TW = X + T;
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t log_m = COLS ? a.log_n1 : a.log_n2;
+    const uint32_t M = 1u << log_m;
+    const uint32_t N1 = 1u << a.log_n1, N2 = 1u << a.log_n2;
+    uint32_t log_cnt = LOG_T - log_m;
+    if (!COLS && log_cnt > a.log_n1) log_cnt = a.log_n1;
+    const uint32_t cnt = 1u << log_cnt;
+    const uint32_t tile = M << log_cnt;  // elements actually used (<= T)
+
+    // XCD-aware remap: consecutive tiles (which share 128-B lines when cnt*32 B < 128 B) go to
+    // the same XCD, i.e. the same L2, under the round-robin workgroup dispatch.
+    uint32_t nblk = gridDim.x, bid = blockIdx.x;
+    if ((nblk & 7u) == 0) bid = (bid & 7u) * (nblk >> 3) + (bid >> 3);
+    const uint32_t base = bid << log_cnt;  // first column (COLS) or first row (!COLS)
+
+    const Fe* in = a.in + (size_t)blockIdx.y * a.in_stride;
+    Fe* out = a.out + (size_t)blockIdx.y * a.out_stride;
+
+    // stage the sub-transform twiddles omega_M^t = omega^(t * N/M)
+    {
+        const uint32_t tw_shift = a.log_n - log_m;
+        for (uint32_t t = tid; t < M / 2; t += NT) TW[t] = ld_fe(a.tw + ((size_t)t << tw_shift));
+    }
+
+    // load the tile
+    for (uint32_t e = tid; e < tile; e += NT) {
+        uint32_t g, li;
+        if (COLS) {
+            uint32_t c = e & (cnt - 1), j1 = e >> log_cnt;
+            g = j1 * N2 + base + c;
+            li = e;  // [j1][c]
+        } else {
+            uint32_t j2 = e & (M - 1), r = e >> log_m;
+            g = (base + r) * N2 + j2;
+            li = e;  // [r][j2]
+        }
+        Fe v;
+        if (FIRST) {
+            if (g < a.in_len) {
+                v = ld_fe(in + g);
+                if (a.coset_in) {
+                    uint32_t m3 = g % 3u;
+                    if (m3 == 1) v = Fr::mul(v, a.zin1);
+                    else if (m3 == 2) v = Fr::mul(v, a.zin2);
+                }
+            } else {
+                v = fe_zero();
+            }
+        } else {
+            v = ld_fe(in + g);
+        }
+        X[li] = v;
+    }
+    __syncthreads();
+
+    // DIF butterflies: natural order in, bit-reversed order out
+    const uint32_t nbf = tile / 2;
+    for (uint32_t st = 0; st < log_m; st++) {
+        const uint32_t log_half = log_m - st - 1;
+        const uint32_t half = 1u << log_half;
+        for (uint32_t bf = tid; bf < nbf; bf += NT) {
+            uint32_t s, b;
+            if (COLS) {
+                s = bf & (cnt - 1);
+                b = bf >> log_cnt;
+            } else {
+                b = bf & (M / 2 - 1);
+                s = bf >> (log_m - 1);
+            }
+            uint32_t blk = b >> log_half, i = b & (half - 1);
+            uint32_t lo = (blk << (log_half + 1)) + i, hi = lo + half;
+            uint32_t ilo = COLS ? (lo << log_cnt) + s : (s << log_m) + lo;
+            uint32_t ihi = COLS ? (hi << log_cnt) + s : (s << log_m) + hi;
+            Fe u = X[ilo], v = X[ihi];
+            X[ilo] = Fr::add(u, v);
+            Fe d = Fr::sub(u, v);
+            uint32_t twi = i << st;
+            if (twi != 0) d = Fr::mul(d, TW[twi]);
+            X[ihi] = d;
+        }
+        __syncthreads();
+    }
+
+    // store
+    if (COLS) {
+        for (uint32_t e = tid; e < tile; e += NT) {
+            uint32_t c = e & (cnt - 1), pos = e >> log_cnt;
+            uint32_t k1 = bitrev(pos, log_m);
+            uint32_t j2 = base + c;
+            Fe v = X[e];
+            uint32_t ti = j2 * k1;  // < N
+            if (ti != 0) v = Fr::mul(v, ld_fe(a.tw + ti));
+            st_fe(out + (size_t)k1 * N2 + j2, v);
+        }
+    } else {
+        for (uint32_t e = tid; e < tile; e += NT) {
+            uint32_t r = e & (cnt - 1), k2 = e >> log_cnt;
+            uint32_t pos = bitrev(k2, log_m);
+            uint32_t k = (base + r) + N1 * k2;
+            if (k >= a.out_len) continue;
+            Fe v = X[(r << log_m) + pos];
+            if (a.scale_out) v = Fr::mul(v, a.scale);
+            if (a.coset_out) {
+                uint32_t m3 = k % 3u;
+                if (m3 == 1) v = Fr::mul(v, a.zout1);
+                else if (m3 == 2) v = Fr::mul(v, a.zout2);
+            }
+            st_fe(out + k, v);
+        }
+    }
+}
+
+// tw[i] = omega^i, i < n
+__global__ void twiddle_kernel(Fe* tw, Fe omega, uint32_t n) {
+    constexpr uint32_t CH = 16;
+    uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * CH;
+    if (i0 >= n) return;
+    Fe cur = Fr::pow_u64(omega, i0);
+    for (uint32_t j = 0; j < CH && i0 + j < n; j++) {
+        st_fe(tw + i0 + j, cur);
+        cur = Fr::mul(cur, omega);
+    }
+}
+
+int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out) {
+    TwiddleKey key;
+    key.log_n = log_n;
+    memcpy(key.omega.data(), &omega, 32);
+    auto it = ctx->twiddles.find(key);
+    if (it != ctx->twiddles.end()) {
+        *out = it->second;
+        return ZG_OK;
+    }
+    uint32_t n = 1u << log_n;
+    Fe* tw = nullptr;
+    ZG_HIP(hipMalloc(&tw, (size_t)n * sizeof(Fe)));
+    uint32_t threads = 256, per = 16;
+    uint32_t blocks = (n + threads * per - 1) / (threads * per);
+    hipLaunchKernelGGL(twiddle_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, tw, omega, n);
+    ZG_HIP(hipGetLastError());
+    ctx->twiddles[key] = tw;
+    *out = tw;
+    return ZG_OK;
+}
+
+struct NttPlan {
+    const Fe* in;
+    size_t in_stride;
+    Fe* out;
+    size_t out_stride;
+    size_t batch;
+    uint32_t log_n;
+    Fe omega;
+    uint32_t in_len, out_len;
+    bool coset_in = false, coset_out = false, scale_out = false;
+    Fe zin1, zin2, zout1, zout2, scale;
+};
+
+template <int LOG_T>
+static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, size_t tmp_stride) {
+    constexpr uint32_t T = 1u << LOG_T;
+    NttArgs a;
+    memset(&a, 0, sizeof(a));
+    a.tw = tw;
+    a.log_n = p.log_n;
+    a.in_len = p.in_len;
+    a.out_len = p.out_len;
+    a.coset_in = p.coset_in;
+    a.coset_out = p.coset_out;
+    a.scale_out = p.scale_out;
+    a.zin1 = p.zin1; a.zin2 = p.zin2; a.zout1 = p.zout1; a.zout2 = p.zout2; a.scale = p.scale;
+    const uint32_t N = 1u << p.log_n;
+    dim3 block(T / 4);
+    if (p.log_n <= (uint32_t)LOG_T) {
+        // one workgroup holds the whole transform: single rows pass, in-place safe
+        a.log_n1 = 0;
+        a.log_n2 = p.log_n;
+        a.in = p.in; a.in_stride = p.in_stride;
+        a.out = p.out; a.out_stride = p.out_stride;
+        size_t lds = (size_t)(T + N / 2) * sizeof(Fe);
+        hipLaunchKernelGGL((ntt_pass_kernel<LOG_T, false, true>), dim3(1, (uint32_t)p.batch), block,
+                           lds, ctx->stream, a);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    a.log_n1 = p.log_n / 2;
+    a.log_n2 = p.log_n - a.log_n1;
+    const uint32_t N1 = 1u << a.log_n1, N2 = 1u << a.log_n2;
+    {   // pass 1: in -> tmp
+        a.in = p.in; a.in_stride = p.in_stride;
+        a.out = tmp; a.out_stride = tmp_stride;
+        uint32_t cnt = T / N1;
+        size_t lds = (size_t)(T + N1 / 2) * sizeof(Fe);
+        hipLaunchKernelGGL((ntt_pass_kernel<LOG_T, true, true>), dim3(N2 / cnt, (uint32_t)p.batch),
+                           block, lds, ctx->stream, a);
+        ZG_HIP(hipGetLastError());
+    }
+    {   // pass 2: tmp -> out
+        a.in = tmp; a.in_stride = tmp_stride;
+        a.out = p.out; a.out_stride = p.out_stride;
+        uint32_t cnt = T / N2;
+        if (cnt > N1) cnt = N1;
+        size_t lds = (size_t)(T + N2 / 2) * sizeof(Fe);
+        hipLaunchKernelGGL((ntt_pass_kernel<LOG_T, false, false>), dim3(N1 / cnt, (uint32_t)p.batch),
+                           block, lds, ctx->stream, a);
+        ZG_HIP(hipGetLastError());
+    }
+    return ZG_OK;
+}
+
+// Runs the plan on the context stream.  `tmp` must hold batch * 2^log_n elements when
+// log_n exceeds the single-workgroup size (see ntt_needs_tmp).
+static uint32_t ntt_log_t(uint32_t log_n) { return log_n <= 16 ? 10u : 11u; }
+bool ntt_needs_tmp(uint32_t log_n) { return log_n > ntt_log_t(log_n); }
+
+int ntt_run(zg_ctx* ctx, const NttPlan& p, Fe* tmp, size_t tmp_stride) {
+    ZG_REQUIRE(p.log_n <= 22, ZG_ERR_UNSUPPORTED, "ntt: log_n %u > 22 not built", p.log_n);
+    if (p.batch == 0) return ZG_OK;
+    Fe* tw = nullptr;
+    ZG_TRY(get_twiddles(ctx, p.log_n, p.omega, &tw));
+    if (ntt_log_t(p.log_n) == 10) return launch_passes<10>(ctx, p, tw, tmp, tmp_stride);
+    return launch_passes<11>(ctx, p, tw, tmp, tmp_stride);
+}
+
+static bool g_lds_attr_done = false;
+static int ensure_lds_attr() {
+    if (g_lds_attr_done) return ZG_OK;
+    // tiles above 64 KB need the opt-in dynamic LDS limit
+    const int big = 160 * 1024;
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<11, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<11, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<11, false, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<10, true, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<10, false, true>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<10, false, false>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    g_lds_attr_done = true;
+    return ZG_OK;
+}
+
+// Device-resident batched transform, in place on d_a (through a workspace copy when two passes
+// are needed).
+int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
+                  const Fe* divisor) {
+    ZG_TRY(ensure_lds_attr());
+    WsScope ws(ctx);
+    NttPlan p;
+    p.in = d_a; p.in_stride = stride;
+    p.out = d_a; p.out_stride = stride;
+    p.batch = batch;
+    p.log_n = log_n;
+    p.omega = omega;
+    p.in_len = p.out_len = 1u << log_n;
+    if (divisor) {
+        p.scale_out = true;
+        p.scale = *divisor;
+    }
+    Fe* tmp = nullptr;
+    size_t n = (size_t)1 << log_n;
+    if (ntt_needs_tmp(log_n)) {
+        tmp = ws.get<Fe>(batch * n);
+        if (!tmp) return ZG_ERR_OOM;
+    }
+    return ntt_run(ctx, p, tmp, n);
+}
+
+int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
+                          size_t batch, uint32_t k, uint32_t ext_k) {
+    ZG_TRY(ensure_lds_attr());
+    WsScope ws(ctx);
+    NttPlan p;
+    p.in = d_in; p.in_stride = in_stride;
+    p.out = d_out; p.out_stride = out_stride;
+    p.batch = batch;
+    p.log_n = ext_k;
+    p.omega = host_domain_omega(ext_k);
+    p.in_len = 1u << k;
+    p.out_len = 1u << ext_k;
+    p.coset_in = true;
+    p.zin1 = fr_zeta();
+    p.zin2 = Fr::sqr(fr_zeta());
+    size_t n = (size_t)1 << ext_k;
+    Fe* tmp = nullptr;
+    if (ntt_needs_tmp(ext_k)) {
+        tmp = ws.get<Fe>(batch * n);
+        if (!tmp) return ZG_ERR_OOM;
+    } else if (d_in == d_out) {
+        // single pass is in-place safe
+    }
+    return ntt_run(ctx, p, tmp, n);
+}
+
+int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len,
+                          Fe* d_out) {
+    (void)k;
+    ZG_TRY(ensure_lds_attr());
+    WsScope ws(ctx);
+    size_t n = (size_t)1 << ext_k;
+    ZG_REQUIRE(out_len <= n, ZG_ERR_INVALID_ARG, "extended_to_coeff: out_len %zu > 2^%u", out_len, ext_k);
+    NttPlan p;
+    p.in = d_evals; p.in_stride = n;
+    p.out = d_out; p.out_stride = out_len;
+    p.batch = 1;
+    p.log_n = ext_k;
+    p.omega = Fr::inv(host_domain_omega(ext_k));
+    p.in_len = (uint32_t)n;
+    p.out_len = (uint32_t)out_len;
+    p.scale_out = true;
+    p.scale = Fr::inv(Fr::from_u64((uint64_t)n));
+    p.coset_out = true;
+    p.zout1 = Fr::sqr(fr_zeta());  // zeta^-1
+    p.zout2 = fr_zeta();           // zeta^-2
+    Fe* tmp = nullptr;
+    if (ntt_needs_tmp(ext_k)) {
+        tmp = ws.get<Fe>(n);
+        if (!tmp) return ZG_ERR_OOM;
+    } else if (d_out != d_evals) {
+        // single pass reads everything before it writes: fine for distinct or equal buffers
+    }
+    return ntt_run(ctx, p, tmp, n);
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+static inline Fe to_fe(const zg_fr* p) {
+    Fe r;
+    memcpy(&r, p, 32);
+    return r;
+}
+
+extern "C" {
+
+int zg_ntt_batch_dev(zg_ctx* ctx, void* d_a, size_t stride_elems, size_t batch, uint32_t log_n,
+                     const zg_fr* omega, const zg_fr* divisor) {
+    ZG_REQUIRE(ctx && d_a && omega, ZG_ERR_INVALID_ARG, "zg_ntt_batch_dev: null argument");
+    ZG_REQUIRE(stride_elems >= ((size_t)1 << log_n) || batch <= 1, ZG_ERR_INVALID_ARG,
+               "zg_ntt_batch_dev: stride %zu < 2^%u", stride_elems, log_n);
+    ZG_HIP(hipSetDevice(ctx->device));
+    Fe om = to_fe(omega), dv;
+    if (divisor) dv = to_fe(divisor);
+    return ntt_batch_dev(ctx, (Fe*)d_a, stride_elems, batch, log_n, om, divisor ? &dv : nullptr);
+}
+
+int zg_intt_batch(zg_ctx* ctx, zg_fr* const* a, size_t batch, uint32_t log_n, const zg_fr* omega_inv,
+                  const zg_fr* divisor) {
+    ZG_REQUIRE(ctx && omega_inv && (a || batch == 0), ZG_ERR_INVALID_ARG, "zg_ntt: null argument");
+    ZG_REQUIRE(log_n <= 22, ZG_ERR_UNSUPPORTED, "zg_ntt: log_n %u > 22 not built", log_n);
+    if (batch == 0) return ZG_OK;
+    ZG_HIP(hipSetDevice(ctx->device));
+    WsScope ws(ctx);
+    size_t n = (size_t)1 << log_n;
+    Fe* d = ws.get<Fe>(batch * n);
+    if (!d) return ZG_ERR_OOM;
+    for (size_t b = 0; b < batch; b++) {
+        ZG_REQUIRE(a[b] != nullptr, ZG_ERR_INVALID_ARG, "zg_ntt: a[%zu] is null", b);
+        ZG_HIP(hipMemcpyAsync(d + b * n, a[b], n * 32, hipMemcpyHostToDevice, ctx->stream));
+    }
+    Fe om = to_fe(omega_inv), dv;
+    if (divisor) dv = to_fe(divisor);
+    ZG_TRY(ntt_batch_dev(ctx, d, n, batch, log_n, om, divisor ? &dv : nullptr));
+    for (size_t b = 0; b < batch; b++)
+        ZG_HIP(hipMemcpyAsync(a[b], d + b * n, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+int zg_ntt_batch(zg_ctx* ctx, zg_fr* const* a, size_t batch, uint32_t log_n, const zg_fr* omega) {
+    return zg_intt_batch(ctx, a, batch, log_n, omega, nullptr);
+}
+
+int zg_ntt(zg_ctx* ctx, zg_fr* a, uint32_t log_n, const zg_fr* omega) {
+    zg_fr* arr[1] = {a};
+    return zg_intt_batch(ctx, arr, 1, log_n, omega, nullptr);
+}
+
+int zg_intt(zg_ctx* ctx, zg_fr* a, uint32_t log_n, const zg_fr* omega_inv, const zg_fr* divisor) {
+    zg_fr* arr[1] = {a};
+    return zg_intt_batch(ctx, arr, 1, log_n, omega_inv, divisor);
+}
+
+int zg_coeff_to_extended_batch_dev(zg_ctx* ctx, const void* d_coeffs, size_t in_stride_elems,
+                                   void* d_out, size_t out_stride_elems, size_t batch, uint32_t k,
+                                   uint32_t ext_k) {
+    ZG_REQUIRE(ctx && d_coeffs && d_out, ZG_ERR_INVALID_ARG, "zg_coeff_to_extended: null argument");
+    ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_coeff_to_extended: k=%u ext_k=%u", k, ext_k);
+    ZG_HIP(hipSetDevice(ctx->device));
+    return coeff_to_extended_dev(ctx, (const Fe*)d_coeffs, in_stride_elems, (Fe*)d_out,
+                                 out_stride_elems, batch, k, ext_k);
+}
+
+int zg_coeff_to_extended(zg_ctx* ctx, const zg_fr* coeffs, uint32_t k, uint32_t ext_k, zg_fr* out) {
+    ZG_REQUIRE(ctx && coeffs && out, ZG_ERR_INVALID_ARG, "zg_coeff_to_extended: null argument");
+    ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_coeff_to_extended: k=%u ext_k=%u", k, ext_k);
+    ZG_HIP(hipSetDevice(ctx->device));
+    WsScope ws(ctx);
+    size_t n = (size_t)1 << k, en = (size_t)1 << ext_k;
+    Fe* din = ws.get<Fe>(n);
+    Fe* dout = ws.get<Fe>(en);
+    if (!din || !dout) return ZG_ERR_OOM;
+    ZG_HIP(hipMemcpyAsync(din, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_TRY(coeff_to_extended_dev(ctx, din, n, dout, en, 1, k, ext_k));
+    ZG_HIP(hipMemcpyAsync(out, dout, en * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+int zg_extended_to_coeff_dev(zg_ctx* ctx, void* d_evals, uint32_t k, uint32_t ext_k, size_t out_len,
+                             void* d_out) {
+    ZG_REQUIRE(ctx && d_evals && d_out, ZG_ERR_INVALID_ARG, "zg_extended_to_coeff: null argument");
+    ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_extended_to_coeff: k=%u ext_k=%u", k, ext_k);
+    ZG_HIP(hipSetDevice(ctx->device));
+    return extended_to_coeff_dev(ctx, (Fe*)d_evals, k, ext_k, out_len, (Fe*)d_out);
+}
+
+int zg_extended_to_coeff(zg_ctx* ctx, zg_fr* evals, uint32_t k, uint32_t ext_k, size_t out_len,
+                         zg_fr* out) {
+    ZG_REQUIRE(ctx && evals && out, ZG_ERR_INVALID_ARG, "zg_extended_to_coeff: null argument");
+    ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_extended_to_coeff: k=%u ext_k=%u", k, ext_k);
+    ZG_HIP(hipSetDevice(ctx->device));
+    WsScope ws(ctx);
+    size_t en = (size_t)1 << ext_k;
+    ZG_REQUIRE(out_len <= en, ZG_ERR_INVALID_ARG, "zg_extended_to_coeff: out_len too large");
+    Fe* din = ws.get<Fe>(en);
+    Fe* dout = ws.get<Fe>(out_len ? out_len : 1);
+    if (!din || !dout) return ZG_ERR_OOM;
+    ZG_HIP(hipMemcpyAsync(din, evals, en * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_TRY(extended_to_coeff_dev(ctx, din, k, ext_k, out_len, dout));
+    ZG_HIP(hipMemcpyAsync(out, dout, out_len * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+}  // extern "C"

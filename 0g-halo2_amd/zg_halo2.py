@@ -1,0 +1,268 @@
+"""ctypes binding of libzg_halo2.so (include/zg_halo2.h) for the Python test/bench harness.
+
+Field elements travel as numpy ``uint64`` arrays of shape ``(..., 4)`` (little-endian limbs,
+Montgomery form: the memory format of halo2curves ``bn256::Fr`` / ``Fq``), affine points as
+``(..., 8)`` and Jacobian points as ``(..., 12)``.
+
+There is no CPU fallback: ``load()`` raises if the shared library is missing and ``Ctx()`` raises
+if no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_int, c_size_t, c_uint32, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzg_halo2.so")
+
+FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+FQ_MODULUS = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+_lib = None
+
+
+class ZgError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"zg_halo2 status {status}: {msg}")
+        self.status = status
+
+
+def load() -> ctypes.CDLL:
+    """Loads libzg_halo2.so; raises loudly when the HIP extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C 0g-halo2_amd` "
+            "(or __graft_entry__.build()). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.zg_last_error.restype = c_char_p
+    lib.zg_version.restype = c_char_p
+    lib.zg_ctx_stream.restype = c_void_p
+    lib.zg_ctx_stream.argtypes = [c_void_p]
+    lib.zg_bases_len.restype = c_size_t
+    lib.zg_bases_len.argtypes = [c_void_p]
+    lib.zg_bases_window_bits.restype = c_uint32
+    lib.zg_bases_window_bits.argtypes = [c_void_p]
+    lib.zg_ctx_destroy.argtypes = [c_void_p]
+    lib.zg_ctx_destroy.restype = None
+    lib.zg_bases_free.argtypes = [c_void_p]
+    lib.zg_bases_free.restype = None
+    _lib = lib
+    return lib
+
+
+# Every symbol include/zg_halo2.h declares (tests check the shared object exports all of them).
+ABI_SYMBOLS = [
+    "zg_last_error", "zg_version", "zg_ctx_create", "zg_ctx_destroy", "zg_ctx_sync", "zg_ctx_stream",
+    "zg_bases_register", "zg_bases_register_dev", "zg_bases_free", "zg_bases_len",
+    "zg_bases_window_bits", "zg_msm", "zg_msm_batch", "zg_msm_batch_dev", "zg_msm_finish", "zg_g1_sum",
+    "zg_ntt", "zg_intt", "zg_ntt_batch", "zg_intt_batch", "zg_ntt_batch_dev", "zg_coeff_to_extended",
+    "zg_coeff_to_extended_batch_dev", "zg_extended_to_coeff", "zg_extended_to_coeff_dev",
+    "zg_domain_omega",
+]
+
+
+def _check(status: int) -> None:
+    if status != 0:
+        raise ZgError(status, load().zg_last_error().decode())
+
+
+def _fr(a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == 4, a.shape
+    return a
+
+
+def _ptr(a: np.ndarray) -> c_void_p:
+    return c_void_p(a.ctypes.data)
+
+
+def int_to_limbs(x: int) -> np.ndarray:
+    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+
+def limbs_to_int(a) -> int:
+    return sum(int(a[i]) << (64 * i) for i in range(4))
+
+
+def fr_from_int(x: int) -> np.ndarray:
+    """Canonical integer -> Montgomery limbs (host helper for tests)."""
+    return int_to_limbs((x % FR_MODULUS) * (1 << 256) % FR_MODULUS)
+
+
+def fr_to_int(a) -> int:
+    return limbs_to_int(a) * pow(1 << 256, -1, FR_MODULUS) % FR_MODULUS
+
+
+def fq_from_int(x: int) -> np.ndarray:
+    return int_to_limbs((x % FQ_MODULUS) * (1 << 256) % FQ_MODULUS)
+
+
+def fq_to_int(a) -> int:
+    return limbs_to_int(a) * pow(1 << 256, -1, FQ_MODULUS) % FQ_MODULUS
+
+
+def domain_omega(log_n: int):
+    om = np.zeros(4, np.uint64)
+    omi = np.zeros(4, np.uint64)
+    _check(load().zg_domain_omega(c_uint32(log_n), _ptr(om), _ptr(omi)))
+    return om, omi
+
+
+def g1_sum(parts: np.ndarray) -> np.ndarray:
+    parts = np.ascontiguousarray(parts, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, np.uint64)
+    _check(load().zg_g1_sum(_ptr(parts), c_size_t(parts.shape[0]), _ptr(out)))
+    return out
+
+
+class Ctx:
+    """One GPU (zg_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        h = c_void_p()
+        _check(self.lib.zg_ctx_create(c_int(device), ctypes.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.zg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _check(self.lib.zg_ctx_sync(self.h))
+
+    @property
+    def stream(self) -> int:
+        return self.lib.zg_ctx_stream(self.h)
+
+    # ---- MSM ----
+    def register_bases(self, bases: np.ndarray, window_bits: int = 0) -> "Bases":
+        bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+        h = c_void_p()
+        _check(self.lib.zg_bases_register(self.h, _ptr(bases), c_size_t(bases.shape[0]),
+                                          c_uint32(window_bits), ctypes.byref(h)))
+        return Bases(self, h)
+
+    def register_bases_dev(self, d_ptr: int, n: int, window_bits: int = 0) -> "Bases":
+        h = c_void_p()
+        _check(self.lib.zg_bases_register_dev(self.h, c_void_p(d_ptr), c_size_t(n), c_uint32(window_bits),
+                                              ctypes.byref(h)))
+        return Bases(self, h)
+
+    def msm(self, bases: "Bases", scalars: np.ndarray) -> np.ndarray:
+        scalars = _fr(scalars).reshape(-1, 4)
+        out = np.zeros(12, np.uint64)
+        _check(self.lib.zg_msm(self.h, bases.h, _ptr(scalars), c_size_t(scalars.shape[0]), _ptr(out)))
+        return out
+
+    def msm_batch(self, bases: "Bases", scalars: np.ndarray) -> np.ndarray:
+        scalars = _fr(scalars)
+        assert scalars.ndim == 3
+        batch, n = scalars.shape[0], scalars.shape[1]
+        ptrs = (c_void_p * batch)(*[scalars[b].ctypes.data for b in range(batch)])
+        out = np.zeros((batch, 12), np.uint64)
+        _check(self.lib.zg_msm_batch(self.h, bases.h, ptrs, c_size_t(batch), c_size_t(n), _ptr(out)))
+        return out
+
+    def msm_batch_dev(self, bases: "Bases", d_scalars: int, stride: int, batch: int, n: int, d_out: int):
+        _check(self.lib.zg_msm_batch_dev(self.h, bases.h, c_void_p(d_scalars), c_size_t(stride),
+                                         c_size_t(batch), c_size_t(n), c_void_p(d_out)))
+
+    def msm_finish(self, d_xyzz: int, batch: int) -> np.ndarray:
+        out = np.zeros((batch, 12), np.uint64)
+        _check(self.lib.zg_msm_finish(self.h, c_void_p(d_xyzz), c_size_t(batch), _ptr(out)))
+        return out
+
+    # ---- NTT ----
+    def ntt(self, a: np.ndarray, omega: np.ndarray, divisor: np.ndarray | None = None) -> np.ndarray:
+        """Returns best_fft(a, omega) (times divisor when given); a is not modified."""
+        a = _fr(a).reshape(-1, 4).copy()
+        n = a.shape[0]
+        log_n = n.bit_length() - 1
+        assert 1 << log_n == n
+        omega = _fr(omega)
+        if divisor is None:
+            _check(self.lib.zg_ntt(self.h, _ptr(a), c_uint32(log_n), _ptr(omega)))
+        else:
+            divisor = _fr(divisor)
+            _check(self.lib.zg_intt(self.h, _ptr(a), c_uint32(log_n), _ptr(omega), _ptr(divisor)))
+        return a
+
+    def ntt_batch(self, a: np.ndarray, omega: np.ndarray, divisor: np.ndarray | None = None) -> np.ndarray:
+        a = _fr(a).copy()
+        assert a.ndim == 3
+        batch, n = a.shape[0], a.shape[1]
+        log_n = n.bit_length() - 1
+        ptrs = (c_void_p * batch)(*[a[b].ctypes.data for b in range(batch)])
+        omega = _fr(omega)
+        if divisor is None:
+            _check(self.lib.zg_ntt_batch(self.h, ptrs, c_size_t(batch), c_uint32(log_n), _ptr(omega)))
+        else:
+            divisor = _fr(divisor)
+            _check(self.lib.zg_intt_batch(self.h, ptrs, c_size_t(batch), c_uint32(log_n), _ptr(omega),
+                                          _ptr(divisor)))
+        return a
+
+    def ntt_batch_dev(self, d_a: int, stride: int, batch: int, log_n: int, omega: np.ndarray,
+                      divisor: np.ndarray | None = None):
+        omega = _fr(omega)
+        dv = _ptr(_fr(divisor)) if divisor is not None else c_void_p(0)
+        _check(self.lib.zg_ntt_batch_dev(self.h, c_void_p(d_a), c_size_t(stride), c_size_t(batch),
+                                         c_uint32(log_n), _ptr(omega), dv))
+
+    def coeff_to_extended(self, coeffs: np.ndarray, k: int, ext_k: int) -> np.ndarray:
+        coeffs = _fr(coeffs).reshape(-1, 4)
+        assert coeffs.shape[0] == 1 << k
+        out = np.zeros((1 << ext_k, 4), np.uint64)
+        _check(self.lib.zg_coeff_to_extended(self.h, _ptr(coeffs), c_uint32(k), c_uint32(ext_k), _ptr(out)))
+        return out
+
+    def coeff_to_extended_batch_dev(self, d_in: int, in_stride: int, d_out: int, out_stride: int, batch: int,
+                                    k: int, ext_k: int):
+        _check(self.lib.zg_coeff_to_extended_batch_dev(self.h, c_void_p(d_in), c_size_t(in_stride),
+                                                       c_void_p(d_out), c_size_t(out_stride), c_size_t(batch),
+                                                       c_uint32(k), c_uint32(ext_k)))
+
+    def extended_to_coeff(self, evals: np.ndarray, k: int, ext_k: int, out_len: int) -> np.ndarray:
+        evals = _fr(evals).reshape(-1, 4).copy()
+        assert evals.shape[0] == 1 << ext_k
+        out = np.zeros((out_len, 4), np.uint64)
+        _check(self.lib.zg_extended_to_coeff(self.h, _ptr(evals), c_uint32(k), c_uint32(ext_k),
+                                             c_size_t(out_len), _ptr(out)))
+        return out
+
+    def extended_to_coeff_dev(self, d_evals: int, k: int, ext_k: int, out_len: int, d_out: int):
+        _check(self.lib.zg_extended_to_coeff_dev(self.h, c_void_p(d_evals), c_uint32(k), c_uint32(ext_k),
+                                                 c_size_t(out_len), c_void_p(d_out)))
+
+
+class Bases:
+    def __init__(self, ctx: Ctx, h: c_void_p):
+        self.ctx = ctx
+        self.h = h
+
+    def __len__(self):
+        return self.ctx.lib.zg_bases_len(self.h)
+
+    @property
+    def window_bits(self) -> int:
+        return self.ctx.lib.zg_bases_window_bits(self.h)
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.zg_bases_free(self.h)
+            self.h = None

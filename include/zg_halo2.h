@@ -1,0 +1,137 @@
+/*
+ * zg_halo2.h -- C ABI of the MI355X proving backend for zero_g's Halo2 WNN circuit.
+ *
+ * This is the drop-in boundary.  The reference has no FFI seam of its own:
+ * `Wnn::proof` (/root/reference/src/wnn.rs:232-262) calls `halo2_proofs::plonk::create_proof`
+ * (wnn.rs:242-259) with `KZGCommitmentScheme<Bn256>` / `ProverGWC` (wnn.rs:243-244), and the hot
+ * arithmetic sits behind halo2's `arithmetic::{best_multiexp, best_fft}`, `poly::EvaluationDomain`,
+ * `poly::commitment::{Params, ParamsProver}` and `plonk::{evaluation, lookup, permutation,
+ * vanishing}` (git dependency halo2_proofs v2023_04_20, reference Cargo.toml:21-25).  Each entry
+ * point below names the upstream function it replaces; INTEGRATION.md shows the Rust `extern "C"`
+ * binding a maintainer would add in a `[patch]`-ed halo2_proofs (the mechanism the reference
+ * already uses for halo2curves, Cargo.toml:14-18).
+ *
+ * Conventions
+ *   - zg_fr / zg_fq : 4 x u64 little-endian limbs, Montgomery form, R = 2^256 (halo2curves 0.3.3).
+ *   - zg_g1_affine  : {x, y}, 64 B, (0,0) = identity (bn256::G1Affine).
+ *   - zg_g1         : Jacobian {x, y, z}, 96 B, z = 0 = identity (bn256::G1).  MSM results are
+ *                     returned NORMALISED (z = 1, or (0,1,0) for the identity) so that the bytes are
+ *                     canonical: a Jacobian triple is otherwise only defined up to scaling.
+ *   - every function returns 0 on success or a negative zg_status; zg_last_error() describes the
+ *     most recent failure on the calling thread.  Nothing throws or aborts across the ABI.
+ *     Upstream MSM/FFT are infallible apart from length asserts; the Rust shim maps nonzero to panic!.
+ *   - pointers are borrowed for the duration of the call unless a handle is returned.
+ *   - one zg_ctx drives one GPU (one process per GPU; multi-GPU composition is in INTEGRATION.md).
+ *   - *_dev entry points take DEVICE pointers (HBM-resident data, e.g. torch tensors' data_ptr())
+ *     and are asynchronous on the context stream; call zg_ctx_sync() before reading results.
+ */
+#ifndef ZG_HALO2_H
+#define ZG_HALO2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { uint64_t l[4]; } zg_fr;
+typedef struct { uint64_t l[4]; } zg_fq;
+typedef struct { zg_fq x, y; } zg_g1_affine;
+typedef struct { zg_fq x, y, z; } zg_g1;
+
+typedef struct zg_ctx zg_ctx;       /* one GPU: stream, workspace, twiddle cache        */
+typedef struct zg_bases zg_bases;   /* HBM-resident base set (ParamsKZG::g / g_lagrange) */
+
+typedef enum {
+    ZG_OK = 0,
+    ZG_ERR_INVALID_ARG = -1,   /* null pointer, length mismatch (upstream: assert_eq! panic) */
+    ZG_ERR_NO_DEVICE = -2,     /* no usable HIP device: the library never falls back to a CPU path */
+    ZG_ERR_HIP = -3,           /* a HIP runtime call failed                                  */
+    ZG_ERR_UNSUPPORTED = -4,   /* size outside what the kernels are built for                */
+    ZG_ERR_CONSTRAINT = -5,    /* plonk::Error::ConstraintSystemFailure (lookup input not in table) */
+    ZG_ERR_OOM = -6
+} zg_status;
+
+const char *zg_last_error(void);
+/* Library version string and the gfx target it was compiled for ("gfx950"). */
+const char *zg_version(void);
+
+/* ------------------------------------------------------------------ context */
+/* Creates a context on HIP device `device_id`.  Fails with ZG_ERR_NO_DEVICE when no GPU is
+ * visible: there is deliberately no CPU fallback. */
+int zg_ctx_create(int device_id, zg_ctx **out);
+void zg_ctx_destroy(zg_ctx *ctx);
+int zg_ctx_sync(zg_ctx *ctx);
+/* The hipStream_t every call of this context is ordered on (as void* to keep HIP out of the ABI). */
+void *zg_ctx_stream(zg_ctx *ctx);
+
+/* ------------------------------------------------------------------ MSM
+ * Replaces halo2_proofs::arithmetic::best_multiexp as reached through
+ * ParamsKZG::commit / commit_lagrange (halo2_proofs/src/poly/kzg/commitment.rs upstream),
+ * i.e. every commitment create_proof makes (30 per WNN proof).        */
+
+/* Uploads a fixed base set once (ParamsKZG::g or ::g_lagrange) and precomputes the
+ * window-shifted copies 2^(c*w) * P_i that let all Pippenger windows share one bucket set.
+ * window_bits = 0 picks c from n.  Host pointer. */
+int zg_bases_register(zg_ctx *ctx, const zg_g1_affine *bases, size_t n, uint32_t window_bits,
+                      zg_bases **out);
+/* Same, from a device pointer (n * 64 B, HBM resident). */
+int zg_bases_register_dev(zg_ctx *ctx, const void *d_bases, size_t n, uint32_t window_bits,
+                          zg_bases **out);
+void zg_bases_free(zg_bases *b);
+size_t zg_bases_len(const zg_bases *b);
+uint32_t zg_bases_window_bits(const zg_bases *b);
+
+/* out = sum_i scalars[i] * bases[i], i < n <= zg_bases_len; == best_multiexp(scalars, &bases[..n]) */
+int zg_msm(zg_ctx *ctx, const zg_bases *bases, const zg_fr *scalars, size_t n, zg_g1 *out);
+/* `batch` scalar vectors against the same bases in one launch sequence; out[batch]. */
+int zg_msm_batch(zg_ctx *ctx, const zg_bases *bases, const zg_fr *const *scalars, size_t batch,
+                 size_t n, zg_g1 *out);
+/* Device-resident scalars: vector b starts at d_scalars + b*stride_elems*32 B.  The un-normalised
+ * results (extended Jacobian X,Y,ZZ,ZZZ; 128 B each) are left in d_out_xyzz[batch]; use
+ * zg_msm_finish to bring them to the host as normalised zg_g1. */
+int zg_msm_batch_dev(zg_ctx *ctx, const zg_bases *bases, const void *d_scalars, size_t stride_elems,
+                     size_t batch, size_t n, void *d_out_xyzz);
+int zg_msm_finish(zg_ctx *ctx, const void *d_xyzz, size_t batch, zg_g1 *out);
+/* Host helper for point-range sharding across GPUs: out = normalised sum of `count` Jacobian
+ * partials (the EC add that follows the RCCL all-gather; EC add is not an ncclRedOp). */
+int zg_g1_sum(const zg_g1 *parts, size_t count, zg_g1 *out);
+
+/* ------------------------------------------------------------------ NTT
+ * Replaces halo2_proofs::arithmetic::best_fft and the EvaluationDomain wrappers
+ * (halo2_proofs/src/poly/domain.rs upstream: lagrange_to_coeff, coeff_to_extended,
+ * extended_to_coeff, divide_by_vanishing_poly).                                             */
+
+/* In place, natural order in and out: a[k] <- sum_j a[j] * omega^(j*k); a has 2^log_n entries. */
+int zg_ntt(zg_ctx *ctx, zg_fr *a, uint32_t log_n, const zg_fr *omega);
+/* EvaluationDomain::ifft: best_fft with omega_inv followed by the multiplication by `divisor`. */
+int zg_intt(zg_ctx *ctx, zg_fr *a, uint32_t log_n, const zg_fr *omega_inv, const zg_fr *divisor);
+int zg_ntt_batch(zg_ctx *ctx, zg_fr *const *a, size_t batch, uint32_t log_n, const zg_fr *omega);
+int zg_intt_batch(zg_ctx *ctx, zg_fr *const *a, size_t batch, uint32_t log_n,
+                  const zg_fr *omega_inv, const zg_fr *divisor);
+/* Device-resident, in place; array b at d_a + b*stride_elems*32 B.  divisor may be NULL. */
+int zg_ntt_batch_dev(zg_ctx *ctx, void *d_a, size_t stride_elems, size_t batch, uint32_t log_n,
+                     const zg_fr *omega, const zg_fr *divisor);
+
+/* EvaluationDomain::coeff_to_extended: coefficient i is multiplied by zeta^(i mod 3)
+ * (g_coset = Fr::ZETA), zero-padded from 2^k to 2^ext_k and transformed with extended_omega. */
+int zg_coeff_to_extended(zg_ctx *ctx, const zg_fr *coeffs, uint32_t k, uint32_t ext_k, zg_fr *out);
+int zg_coeff_to_extended_batch_dev(zg_ctx *ctx, const void *d_coeffs, size_t in_stride_elems,
+                                   void *d_out, size_t out_stride_elems, size_t batch, uint32_t k,
+                                   uint32_t ext_k);
+/* EvaluationDomain::extended_to_coeff: inverse transform on the extended domain, multiplication by
+ * 2^-ext_k and by zeta^-(i mod 3), truncated to out_len (= n * quotient_poly_degree). evals is
+ * clobbered. */
+int zg_extended_to_coeff(zg_ctx *ctx, zg_fr *evals, uint32_t k, uint32_t ext_k, size_t out_len,
+                         zg_fr *out);
+int zg_extended_to_coeff_dev(zg_ctx *ctx, void *d_evals, uint32_t k, uint32_t ext_k, size_t out_len,
+                             void *d_out);
+
+/* The standard domain roots: omega = ROOT_OF_UNITY^(2^(28-log_n)) and its inverse. */
+int zg_domain_omega(uint32_t log_n, zg_fr *omega, zg_fr *omega_inv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZG_HALO2_H */

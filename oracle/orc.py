@@ -1,0 +1,198 @@
+"""ctypes binding of oracle/libzg_oracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+Arrays use the same numpy conventions as the product binding: Fr/Fq = uint64[..., 4] Montgomery
+limbs, affine = uint64[..., 8], Jacobian = uint64[..., 12].
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_int, c_int32, c_size_t, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libzg_oracle.so")
+_lib = None
+
+
+def build() -> None:
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(LIB_PATH)
+    return _lib
+
+
+def _p(a: np.ndarray) -> c_void_p:
+    return c_void_p(a.ctypes.data)
+
+
+def _c(a, last) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    assert a.shape[-1] == last, a.shape
+    return a
+
+
+class Domain(ctypes.Structure):
+    _fields_ = (
+        [("k", c_uint32), ("extended_k", c_uint32), ("n", c_uint64), ("extended_n", c_uint64),
+         ("quotient_poly_degree", c_uint32)]
+        + [(name, c_uint64 * 4) for name in (
+            "omega", "omega_inv", "extended_omega", "extended_omega_inv", "g_coset", "g_coset_inv",
+            "ifft_divisor", "extended_ifft_divisor", "barycentric_weight")]
+        + [("t_evaluations", c_void_p), ("t_len", c_size_t)]
+    )
+
+    def fe(self, name: str) -> np.ndarray:
+        return np.array(list(getattr(self, name)), dtype=np.uint64)
+
+
+def domain(j: int, k: int) -> Domain:
+    d = Domain()
+    load().orc_domain_new(ctypes.byref(d), c_uint32(j), c_uint32(k))
+    return d
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("k", c_uint32), ("n", c_uint64), ("g", c_void_p), ("g_lagrange", c_void_p),
+                ("s", c_uint64 * 4)]
+
+    def g_np(self) -> np.ndarray:
+        n = int(self.n)
+        return np.ctypeslib.as_array(ctypes.cast(self.g, ctypes.POINTER(c_uint64)), shape=(n, 8)).copy()
+
+    def g_lagrange_np(self) -> np.ndarray:
+        n = int(self.n)
+        return np.ctypeslib.as_array(ctypes.cast(self.g_lagrange, ctypes.POINTER(c_uint64)),
+                                     shape=(n, 8)).copy()
+
+
+def params_new(k: int, seed: int = 0x5EED) -> Params:
+    """ParamsKZG::new(k) with the toxic scalar drawn from SplitMix64(seed)."""
+    s = fill_fr(seed, 1)[0]
+    p = Params()
+    load().orc_params_new(ctypes.byref(p), c_uint32(k), _p(s))
+    return p
+
+
+def fill_fr(seed: int, n: int) -> np.ndarray:
+    out = np.zeros((n, 4), np.uint64)
+    load().orc_fill_fr(c_uint64(seed), _p(out), c_size_t(n))
+    return out
+
+
+def fill_fr_sparse(seed: int, n: int) -> np.ndarray:
+    out = np.zeros((n, 4), np.uint64)
+    load().orc_fill_fr_sparse(c_uint64(seed), _p(out), c_size_t(n))
+    return out
+
+
+def fr_from_int(x: int) -> np.ndarray:
+    raw = np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    out = np.zeros(4, np.uint64)
+    load().orc_fr_from_raw(_p(out), _p(raw))
+    return out
+
+
+def fr_to_int(a) -> int:
+    a = _c(a, 4)
+    raw = np.zeros(4, np.uint64)
+    load().orc_fr_to_raw(_p(raw), _p(a))
+    return sum(int(raw[i]) << (64 * i) for i in range(4))
+
+
+def fq_to_int(a) -> int:
+    a = _c(a, 4)
+    raw = np.zeros(4, np.uint64)
+    load().orc_fq_to_raw(_p(raw), _p(a))
+    return sum(int(raw[i]) << (64 * i) for i in range(4))
+
+
+def fr_inv(a) -> np.ndarray:
+    out = np.zeros(4, np.uint64)
+    load().orc_fr_inv(_p(out), _p(_c(a, 4)))
+    return out
+
+
+def msm(scalars: np.ndarray, bases: np.ndarray, threads: int = 1) -> np.ndarray:
+    """halo2 best_multiexp restated; returns the NORMALISED Jacobian point (z = 1 / identity)."""
+    scalars = _c(scalars, 4).reshape(-1, 4)
+    bases = _c(bases, 8).reshape(-1, 8)
+    n = scalars.shape[0]
+    assert bases.shape[0] >= n
+    r = np.zeros(12, np.uint64)
+    if threads <= 1:
+        load().orc_msm(_p(r), _p(scalars), _p(bases), c_size_t(n))
+    else:
+        load().orc_msm_mt(_p(r), _p(scalars), _p(bases), c_size_t(n), c_int(threads))
+    return normalise(r)
+
+
+def msm_naive(scalars: np.ndarray, bases: np.ndarray) -> np.ndarray:
+    scalars = _c(scalars, 4).reshape(-1, 4)
+    bases = _c(bases, 8).reshape(-1, 8)
+    r = np.zeros(12, np.uint64)
+    load().orc_msm_naive(_p(r), _p(scalars), _p(bases), c_size_t(scalars.shape[0]))
+    return normalise(r)
+
+
+def normalise(jac: np.ndarray) -> np.ndarray:
+    """Jacobian -> (x, y, 1) or (0, 1, 0): the canonical form the product ABI returns."""
+    jac = _c(jac, 12)
+    L = load()
+    aff = np.zeros(8, np.uint64)
+    L.orc_g1_to_affine(_p(aff), _p(jac))
+    out = np.zeros(12, np.uint64)
+    L.orc_g1_from_affine(_p(out), _p(aff))
+    return out
+
+
+def g1_add(p: np.ndarray, q: np.ndarray) -> np.ndarray:
+    out = np.zeros(12, np.uint64)
+    load().orc_g1_add(_p(out), _p(_c(p, 12)), _p(_c(q, 12)))
+    return out
+
+
+def fft(a: np.ndarray, omega: np.ndarray) -> np.ndarray:
+    a = _c(a, 4).reshape(-1, 4).copy()
+    n = a.shape[0]
+    log_n = n.bit_length() - 1
+    assert 1 << log_n == n
+    load().orc_fft(_p(a), _p(_c(omega, 4)), c_uint32(log_n))
+    return a
+
+
+def dft_naive(a: np.ndarray, omega: np.ndarray) -> np.ndarray:
+    a = _c(a, 4).reshape(-1, 4)
+    n = a.shape[0]
+    out = np.zeros_like(a)
+    load().orc_dft_naive(_p(out), _p(a), _p(_c(omega, 4)), c_uint32(n.bit_length() - 1))
+    return out
+
+
+def lagrange_to_coeff(d: Domain, a: np.ndarray) -> np.ndarray:
+    a = _c(a, 4).reshape(-1, 4).copy()
+    load().orc_lagrange_to_coeff(ctypes.byref(d), _p(a))
+    return a
+
+
+def coeff_to_extended(d: Domain, coeffs: np.ndarray) -> np.ndarray:
+    coeffs = _c(coeffs, 4).reshape(-1, 4)
+    out = np.zeros((int(d.extended_n), 4), np.uint64)
+    load().orc_coeff_to_extended(ctypes.byref(d), _p(out), _p(coeffs))
+    return out
+
+
+def extended_to_coeff(d: Domain, evals: np.ndarray) -> np.ndarray:
+    evals = _c(evals, 4).reshape(-1, 4).copy()
+    out = np.zeros((int(d.n) * int(d.quotient_poly_degree), 4), np.uint64)
+    load().orc_extended_to_coeff(ctypes.byref(d), _p(out), _p(evals))
+    return out

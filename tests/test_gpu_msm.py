@@ -1,0 +1,103 @@
+"""GPU parity: HIP Pippenger MSM (through the C ABI) == oracle restatement of halo2's best_multiexp,
+compared as normalised points (bit-exact), on uniform and on advice-like sparse scalars."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def srs(orc):
+    prm = orc.params_new(12)
+    return prm.g_np(), prm.g_lagrange_np()
+
+
+@pytest.mark.parametrize("c", [0, 4, 8, 11, 13, 16])
+def test_msm_matches_oracle_uniform(ctx, zg, orc, srs, c):
+    g, _ = srs
+    n = g.shape[0]
+    bases = ctx.register_bases(g, c)
+    s = orc.fill_fr(21, n)
+    assert np.array_equal(ctx.msm(bases, s), orc.msm(s, g, threads=8))
+    bases.free()
+
+
+def test_msm_sparse_and_edge_scalars(ctx, zg, orc, srs):
+    _, gl = srs
+    n = gl.shape[0]
+    bases = ctx.register_bases(gl)
+    sp = orc.fill_fr_sparse(5, n)
+    assert np.array_equal(ctx.msm(bases, sp), orc.msm(sp, gl, threads=8))
+    # all zeros -> identity (0, 1, 0)
+    z = np.zeros((n, 4), np.uint64)
+    r = ctx.msm(bases, z)
+    assert not r[:4].any() and not r[8:].any() and zg.fq_to_int(r[4:8]) == 1
+    # unit vector -> that base; r-1 (= -1) on one point -> its negation
+    for idx in (0, 1, n - 1):
+        e = np.zeros((n, 4), np.uint64)
+        e[idx] = orc.fr_from_int(1)
+        r = ctx.msm(bases, e)
+        assert np.array_equal(r[:8], gl[idx]) and zg.fq_to_int(r[8:]) == 1
+    e = np.zeros((n, 4), np.uint64)
+    e[7] = orc.fr_from_int(zg.FR_MODULUS - 1)
+    r = ctx.msm(bases, e)
+    assert np.array_equal(r[:4], gl[7][:4])
+    assert zg.fq_to_int(r[4:8]) == zg.FQ_MODULUS - zg.fq_to_int(gl[7][4:])
+    # all ones: one hot bucket holding every point
+    ones = np.tile(orc.fr_from_int(1), (n, 1))
+    assert np.array_equal(ctx.msm(bases, ones), orc.msm(ones, gl, threads=8))
+    # maximal scalars r-1 everywhere (top window + carry path)
+    mx = np.tile(orc.fr_from_int(zg.FR_MODULUS - 1), (n, 1))
+    assert np.array_equal(ctx.msm(bases, mx), orc.msm(mx, gl, threads=8))
+    # ragged: fewer scalars than bases, and n = 1
+    for m in (1, 2, 3, 100, n - 1):
+        s = orc.fill_fr(900 + m, m)
+        assert np.array_equal(ctx.msm(bases, s), orc.msm(s, gl[:m], threads=4))
+    # empty
+    r = ctx.msm(bases, np.zeros((0, 4), np.uint64))
+    assert not r[:4].any() and not r[8:].any()
+    bases.free()
+
+
+def test_msm_batch_matches_single(ctx, zg, orc, srs):
+    g, _ = srs
+    n = g.shape[0]
+    bases = ctx.register_bases(g)
+    batch = 6
+    s = np.stack([orc.fill_fr(31 + b, n) if b % 2 == 0 else orc.fill_fr_sparse(31 + b, n) for b in range(batch)])
+    got = ctx.msm_batch(bases, s)
+    for b in range(batch):
+        assert np.array_equal(got[b], orc.msm(s[b], g, threads=8)), b
+    bases.free()
+
+
+def test_msm_linearity_full_size(ctx, zg, orc):
+    """k = 14 (BASELINE configs[1]): MSM(a) + MSM(b) == MSM(a + b), and parity with the oracle."""
+    prm = orc.params_new(14)
+    g = prm.g_np()
+    n = g.shape[0]
+    bases = ctx.register_bases(g)
+    a, b = orc.fill_fr(1, n), orc.fill_fr_sparse(2, n)
+    L = orc.load()
+    import ctypes
+
+    ab = np.zeros_like(a)
+    for i in range(n):
+        L.orc_fr_add(ctypes.c_void_p(ab[i].ctypes.data), ctypes.c_void_p(a[i].ctypes.data),
+                     ctypes.c_void_p(b[i].ctypes.data))
+    ra, rb, rab = ctx.msm(bases, a), ctx.msm(bases, b), ctx.msm(bases, ab)
+    assert np.array_equal(zg.g1_sum(np.stack([ra, rb])), rab)
+    assert np.array_equal(ra, orc.msm(a, g, threads=8))
+    assert np.array_equal(rb, orc.msm(b, g, threads=8))
+    bases.free()
+
+
+def test_msm_argument_errors(ctx, zg, orc, srs):
+    g, _ = srs
+    bases = ctx.register_bases(g[:16])
+    with pytest.raises(zg.ZgError) as e:
+        ctx.msm(bases, orc.fill_fr(1, 17))
+    assert e.value.status == -1
+    with pytest.raises(zg.ZgError):
+        ctx.register_bases(g[:16], 17)
+    bases.free()
