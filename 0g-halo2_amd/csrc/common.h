@@ -79,6 +79,14 @@ struct zg_ctx {
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     std::mutex mu;
+    // optional per-kernel HIP-event timing (zg_ctx_profile_*): events bracket every launch
+    bool profiling = false;
+    struct ProfRec {
+        const char* name;
+        hipEvent_t e0, e1;
+        double bytes;
+    };
+    std::vector<ProfRec> prof;
 };
 
 struct zg_bases {
@@ -115,6 +123,17 @@ struct WsScope {
     }
 };
 int pinned_reserve(zg_ctx* ctx, size_t bytes);
+
+// Launch wrapper: when profiling is on, two hipEvents bracket the kernel on the context stream and
+// `algo_bytes` (the ALGORITHMIC bytes this launch is charged with) is recorded beside it.
+void prof_begin(zg_ctx* ctx, const char* name, double algo_bytes);
+void prof_end(zg_ctx* ctx);
+#define ZG_LAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                 \
+    do {                                                                           \
+        if ((ctx)->profiling) ::zg::prof_begin((ctx), (name), (double)(bytes));    \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);  \
+        if ((ctx)->profiling) ::zg::prof_end((ctx));                               \
+    } while (0)
 
 // twiddle table for (log_n, omega), created on first use
 int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out);

@@ -56,6 +56,18 @@ int pinned_reserve(zg_ctx* ctx, size_t bytes) {
     return ZG_OK;
 }
 
+void prof_begin(zg_ctx* ctx, const char* name, double algo_bytes) {
+    zg_ctx::ProfRec r;
+    r.name = name;
+    r.bytes = algo_bytes;
+    (void)hipEventCreate(&r.e0);
+    (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, ctx->stream);
+    ctx->prof.push_back(r);
+}
+
+void prof_end(zg_ctx* ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->stream); }
+
 Fe host_domain_omega(uint32_t log_n) {
     Fe w = fr_root_of_unity();
     for (uint32_t i = log_n; i < FR_S; i++) w = Fr::sqr(w);
@@ -118,6 +130,43 @@ int zg_ctx_sync(zg_ctx* ctx) {
 }
 
 void* zg_ctx_stream(zg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int zg_ctx_profile_enable(zg_ctx* ctx, int on) {
+    ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_profile_enable: ctx is null");
+    ctx->profiling = on != 0;
+    return ZG_OK;
+}
+
+// Synchronises, folds the recorded launches into per-kernel totals and clears the log.
+int zg_ctx_profile_collect(zg_ctx* ctx, zg_kernel_stat* out, size_t cap, size_t* count) {
+    ZG_REQUIRE(ctx && count, ZG_ERR_INVALID_ARG, "zg_ctx_profile_collect: null argument");
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<zg_kernel_stat> acc;
+    for (auto& r : ctx->prof) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+        zg_kernel_stat* s = nullptr;
+        for (auto& a : acc)
+            if (strcmp(a.name, r.name) == 0) s = &a;
+        if (!s) {
+            zg_kernel_stat n;
+            memset(&n, 0, sizeof(n));
+            strncpy(n.name, r.name, sizeof(n.name) - 1);
+            acc.push_back(n);
+            s = &acc.back();
+        }
+        s->launches += 1;
+        s->total_ms += ms;
+        s->algo_bytes += r.bytes;
+    }
+    ctx->prof.clear();
+    *count = acc.size();
+    if (out)
+        for (size_t i = 0; i < acc.size() && i < cap; i++) out[i] = acc[i];
+    return ZG_OK;
+}
 
 int zg_domain_omega(uint32_t log_n, zg_fr* omega, zg_fr* omega_inv) {
     ZG_REQUIRE(log_n <= FR_S, ZG_ERR_INVALID_ARG, "zg_domain_omega: log_n %u > 28", log_n);

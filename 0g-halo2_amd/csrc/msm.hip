@@ -361,19 +361,22 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
     XYZZ* g = ws.get<XYZZ>((size_t)B * c);
     if (ws.failed) return ZG_ERR_OOM;
 
-    hipStream_t st = ctx->stream;
-    ZG_HIP(hipMemsetAsync(cnt, 0, (size_t)B * (nb + 1) * sizeof(uint32_t), st));
+    ZG_HIP(hipMemsetAsync(cnt, 0, (size_t)B * (nb + 1) * sizeof(uint32_t), ctx->stream));
     dim3 gs((N + 255) / 256, B);
-    hipLaunchKernelGGL(msm_count_kernel, gs, dim3(256), 0, st, d_scalars, stride, N, c, W, cnt, slot);
-    hipLaunchKernelGGL(msm_scan_kernel, dim3(B), dim3(1024), 0, st, cnt, c, boff, toff, ttotal);
-    hipLaunchKernelGGL(msm_scatter_kernel, gs, dim3(256), 0, st, d_scalars, stride, N, c, W, boff, slot, sorted);
-    hipLaunchKernelGGL(msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0, st,
-                       bases->table, (uint32_t)bases->n, c, W, N, cnt, boff, toff, ttotal, sorted, max_tasks,
-                       partial, pkey);
-    hipLaunchKernelGGL(msm_reduce1_kernel, dim3((max_strips + 255) / 256, c, B), dim3(256), 0, st, partial,
-                       pkey, ttotal, max_tasks, max_strips, c, l1);
-    hipLaunchKernelGGL(msm_reduce2_kernel, dim3(c, B), dim3(256), 0, st, l1, ttotal, max_strips, c, g);
-    hipLaunchKernelGGL(msm_final_kernel, dim3(B), dim3(64), 0, st, g, c, d_out);
+    // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out;
+    // charged once, to the accumulate kernel that does the group work.
+    const double msm_bytes = (double)B * ((double)N * 96.0 + 96.0);
+    ZG_LAUNCH(ctx, "msm_count", 0, msm_count_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, cnt, slot);
+    ZG_LAUNCH(ctx, "msm_scan", 0, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, boff, toff, ttotal);
+    ZG_LAUNCH(ctx, "msm_scatter", 0, msm_scatter_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, boff,
+              slot, sorted);
+    ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B),
+              dim3(256), 0, bases->table, (uint32_t)bases->n, c, W, N, cnt, boff, toff, ttotal, sorted,
+              max_tasks, partial, pkey);
+    ZG_LAUNCH(ctx, "msm_reduce1", 0, msm_reduce1_kernel, dim3((max_strips + 255) / 256, c, B), dim3(256), 0,
+              partial, pkey, ttotal, max_tasks, max_strips, c, l1);
+    ZG_LAUNCH(ctx, "msm_reduce2", 0, msm_reduce2_kernel, dim3(c, B), dim3(256), 0, l1, ttotal, max_strips, c, g);
+    ZG_LAUNCH(ctx, "msm_final", 0, msm_final_kernel, dim3(B), dim3(64), 0, g, c, d_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -238,6 +238,8 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
     a.scale_out = p.scale_out;
     a.zin1 = p.zin1; a.zin2 = p.zin2; a.zout1 = p.zout1; a.zout2 = p.zout2; a.scale = p.scale;
     const uint32_t N = 1u << p.log_n;
+    // algorithmic bytes of a transform: input entries read + output entries written
+    const double pass_bytes = (double)p.batch * ((double)p.in_len + (double)p.out_len) * 32.0;
     dim3 block(T / 4);
     if (p.log_n <= (uint32_t)LOG_T) {
         // one workgroup holds the whole transform: single rows pass, in-place safe
@@ -246,8 +248,8 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.in = p.in; a.in_stride = p.in_stride;
         a.out = p.out; a.out_stride = p.out_stride;
         size_t lds = (size_t)(T + N / 2) * sizeof(Fe);
-        hipLaunchKernelGGL((ntt_pass_kernel<LOG_T, false, true>), dim3(1, (uint32_t)p.batch), block,
-                           lds, ctx->stream, a);
+        ZG_LAUNCH(ctx, "ntt_single", pass_bytes, (ntt_pass_kernel<LOG_T, false, true>),
+                  dim3(1, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
@@ -259,8 +261,8 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.out = tmp; a.out_stride = tmp_stride;
         uint32_t cnt = T / N1;
         size_t lds = (size_t)(T + N1 / 2) * sizeof(Fe);
-        hipLaunchKernelGGL((ntt_pass_kernel<LOG_T, true, true>), dim3(N2 / cnt, (uint32_t)p.batch),
-                           block, lds, ctx->stream, a);
+        ZG_LAUNCH(ctx, "ntt_cols", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, true, true>),
+                  dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }
     {   // pass 2: tmp -> out
@@ -269,8 +271,8 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         uint32_t cnt = T / N2;
         if (cnt > N1) cnt = N1;
         size_t lds = (size_t)(T + N2 / 2) * sizeof(Fe);
-        hipLaunchKernelGGL((ntt_pass_kernel<LOG_T, false, false>), dim3(N1 / cnt, (uint32_t)p.batch),
-                           block, lds, ctx->stream, a);
+        ZG_LAUNCH(ctx, "ntt_rows", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, false, false>),
+                  dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }
     return ZG_OK;

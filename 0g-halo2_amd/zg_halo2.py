@@ -64,8 +64,14 @@ ABI_SYMBOLS = [
     "zg_bases_window_bits", "zg_msm", "zg_msm_batch", "zg_msm_batch_dev", "zg_msm_finish", "zg_g1_sum",
     "zg_ntt", "zg_intt", "zg_ntt_batch", "zg_intt_batch", "zg_ntt_batch_dev", "zg_coeff_to_extended",
     "zg_coeff_to_extended_batch_dev", "zg_extended_to_coeff", "zg_extended_to_coeff_dev",
-    "zg_domain_omega",
+    "zg_domain_omega", "zg_ctx_profile_enable", "zg_ctx_profile_collect", "zg_params_new",
+    "zg_params_new_dev",
 ]
+
+
+class KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_uint64), ("total_ms", ctypes.c_double),
+                ("algo_bytes", ctypes.c_double)]
 
 
 def _check(status: int) -> None:
@@ -148,6 +154,30 @@ class Ctx:
     @property
     def stream(self) -> int:
         return self.lib.zg_ctx_stream(self.h)
+
+    def profile(self, on: bool):
+        _check(self.lib.zg_ctx_profile_enable(self.h, c_int(1 if on else 0)))
+
+    def profile_collect(self) -> dict:
+        """{kernel: (launches, total_ms, algo_bytes)} since the last collect; synchronises."""
+        cap = 64
+        arr = (KernelStat * cap)()
+        cnt = c_size_t(0)
+        _check(self.lib.zg_ctx_profile_collect(self.h, arr, c_size_t(cap), ctypes.byref(cnt)))
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms), float(arr[i].algo_bytes))
+                for i in range(min(cap, cnt.value))}
+
+    # ---- SRS ----
+    def params_new(self, k: int, s: np.ndarray):
+        """ParamsKZG::new(k) with toxic scalar s -> (g, g_lagrange) as uint64[n, 8] host arrays."""
+        n = 1 << k
+        g = np.zeros((n, 8), np.uint64)
+        gl = np.zeros((n, 8), np.uint64)
+        _check(self.lib.zg_params_new(self.h, c_uint32(k), _ptr(_fr(s)), _ptr(g), _ptr(gl)))
+        return g, gl
+
+    def params_new_dev(self, k: int, s: np.ndarray, d_g: int, d_gl: int):
+        _check(self.lib.zg_params_new_dev(self.h, c_uint32(k), _ptr(_fr(s)), c_void_p(d_g), c_void_p(d_gl)))
 
     # ---- MSM ----
     def register_bases(self, bases: np.ndarray, window_bits: int = 0) -> "Bases":

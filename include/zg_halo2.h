@@ -66,6 +66,18 @@ int zg_ctx_sync(zg_ctx *ctx);
 /* The hipStream_t every call of this context is ordered on (as void* to keep HIP out of the ABI). */
 void *zg_ctx_stream(zg_ctx *ctx);
 
+/* Per-kernel timing with HIP events recorded on the context stream around every launch (used by
+ * bench.py for the roofline line; off by default).  algo_bytes is the ALGORITHMIC byte count the
+ * launches were charged with (DESIGN.md lists the per-unit figures), not measured HBM traffic. */
+typedef struct {
+    char name[48];
+    uint64_t launches;
+    double total_ms;
+    double algo_bytes;
+} zg_kernel_stat;
+int zg_ctx_profile_enable(zg_ctx *ctx, int on);
+int zg_ctx_profile_collect(zg_ctx *ctx, zg_kernel_stat *out, size_t cap, size_t *count);
+
 /* ------------------------------------------------------------------ MSM
  * Replaces halo2_proofs::arithmetic::best_multiexp as reached through
  * ParamsKZG::commit / commit_lagrange (halo2_proofs/src/poly/kzg/commitment.rs upstream),
@@ -97,6 +109,13 @@ int zg_msm_finish(zg_ctx *ctx, const void *d_xyzz, size_t batch, zg_g1 *out);
 /* Host helper for point-range sharding across GPUs: out = normalised sum of `count` Jacobian
  * partials (the EC add that follows the RCCL all-gather; EC add is not an ncclRedOp). */
 int zg_g1_sum(const zg_g1 *parts, size_t count, zg_g1 *out);
+
+/* ------------------------------------------------------------------ SRS
+ * Replaces ParamsKZG::<Bn256>::new(k) (reference call sites benches/bench.rs:19, src/main.rs:232):
+ * g[i] = s^i * G and g_lagrange[i] = L_i(s) * G, 2^k affine points each.  Upstream draws s from
+ * OsRng; here the caller supplies it so that runs are reproducible. */
+int zg_params_new(zg_ctx *ctx, uint32_t k, const zg_fr *s, zg_g1_affine *g, zg_g1_affine *g_lagrange);
+int zg_params_new_dev(zg_ctx *ctx, uint32_t k, const zg_fr *s, void *d_g, void *d_g_lagrange);
 
 /* ------------------------------------------------------------------ NTT
  * Replaces halo2_proofs::arithmetic::best_fft and the EvaluationDomain wrappers

@@ -124,14 +124,16 @@ void orc_fft(orc_fr *a, const orc_fr *omega, uint32_t log_n) {
     }
     size_t chunk = 2, twiddle_chunk = n / 2;
     for (uint32_t s = 0; s < log_n; s++) {
-        for (size_t base = 0; base < n; base += chunk) {
-            orc_fr *left = a + base, *right = a + base + chunk / 2;
-            for (size_t i = 0; i < chunk / 2; i++) {
-                orc_fr t = right[i];
-                if (i != 0) orc_fr_mul(&t, &t, &tw[i * twiddle_chunk]);
-                orc_fr_sub(&right[i], &left[i], &t);
-                orc_fr_add(&left[i], &left[i], &t);
-            }
+        /* n/2 independent butterflies per stage (halo2 spreads them over rayon threads) */
+        const size_t half = chunk / 2;
+#pragma omp parallel for schedule(static) if (n >= 4096)
+        for (long bf = 0; bf < (long)(n / 2); bf++) {
+            size_t blk = (size_t)bf / half, i = (size_t)bf % half;
+            orc_fr *left = a + blk * chunk, *right = left + half;
+            orc_fr t = right[i];
+            if (i != 0) orc_fr_mul(&t, &t, &tw[i * twiddle_chunk]);
+            orc_fr_sub(&right[i], &left[i], &t);
+            orc_fr_add(&left[i], &left[i], &t);
         }
         chunk *= 2;
         twiddle_chunk /= 2;

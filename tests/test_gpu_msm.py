@@ -101,3 +101,13 @@ def test_msm_argument_errors(ctx, zg, orc, srs):
     with pytest.raises(zg.ZgError):
         ctx.register_bases(g[:16], 17)
     bases.free()
+
+
+def test_params_new_matches_oracle(ctx, zg, orc):
+    """ParamsKZG::new(k) on the GPU == the oracle's setup for the same toxic scalar."""
+    k = 7
+    s = orc.fill_fr(0x5EED, 1)[0]
+    g, gl = ctx.params_new(k, s)
+    prm = orc.params_new(k, 0x5EED)
+    assert np.array_equal(g, prm.g_np())
+    assert np.array_equal(gl, prm.g_lagrange_np())
