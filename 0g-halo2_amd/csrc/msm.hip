@@ -363,20 +363,20 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
 
     ZG_HIP(hipMemsetAsync(cnt, 0, (size_t)B * (nb + 1) * sizeof(uint32_t), ctx->stream));
     dim3 gs((N + 255) / 256, B);
-    // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out;
-    // charged once, to the accumulate kernel that does the group work.
+    // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out.  Every
+    // stage kernel processes the same B MSMs per launch, so each is charged the same figure.
     const double msm_bytes = (double)B * ((double)N * 96.0 + 96.0);
-    ZG_LAUNCH(ctx, "msm_count", 0, msm_count_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, cnt, slot);
-    ZG_LAUNCH(ctx, "msm_scan", 0, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, boff, toff, ttotal);
-    ZG_LAUNCH(ctx, "msm_scatter", 0, msm_scatter_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, boff,
+    ZG_LAUNCH(ctx, "msm_count", msm_bytes, msm_count_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, cnt, slot);
+    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, boff, toff, ttotal);
+    ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, boff,
               slot, sorted);
     ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B),
               dim3(256), 0, bases->table, (uint32_t)bases->n, c, W, N, cnt, boff, toff, ttotal, sorted,
               max_tasks, partial, pkey);
-    ZG_LAUNCH(ctx, "msm_reduce1", 0, msm_reduce1_kernel, dim3((max_strips + 255) / 256, c, B), dim3(256), 0,
+    ZG_LAUNCH(ctx, "msm_reduce1", msm_bytes, msm_reduce1_kernel, dim3((max_strips + 255) / 256, c, B), dim3(256), 0,
               partial, pkey, ttotal, max_tasks, max_strips, c, l1);
-    ZG_LAUNCH(ctx, "msm_reduce2", 0, msm_reduce2_kernel, dim3(c, B), dim3(256), 0, l1, ttotal, max_strips, c, g);
-    ZG_LAUNCH(ctx, "msm_final", 0, msm_final_kernel, dim3(B), dim3(64), 0, g, c, d_out);
+    ZG_LAUNCH(ctx, "msm_reduce2", msm_bytes, msm_reduce2_kernel, dim3(c, B), dim3(256), 0, l1, ttotal, max_strips, c, g);
+    ZG_LAUNCH(ctx, "msm_final", msm_bytes, msm_final_kernel, dim3(B), dim3(64), 0, g, c, d_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

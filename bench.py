@@ -154,7 +154,7 @@ def cpu_baseline(k: int, threads: int):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
 
-    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    orc.load().orc_set_threads(threads)
     n = 1 << k
     prm = orc.params_new(k)
     g, gl = prm.g_np(), prm.g_lagrange_np()
@@ -179,6 +179,15 @@ def cpu_baseline(k: int, threads: int):
         "sample": f"1 full MSM+NTT schedule of one k={k} proof (30 MSM, 21 iNTT, 21 coset NTT, 1 ext iNTT) "
                   f"in {dt:.2f} s with the oracle's OpenMP restatement of halo2 best_multiexp/best_fft",
     }
+
+
+def host_cores() -> int:
+    """Cores this process may actually use (the GPU box gives one GPU a 16-core share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
 
 
 def main():
@@ -259,7 +268,7 @@ def main():
             "kernels_ms_per_step": {k_: v[1] / args.steps for k_, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.k, os.cpu_count() or 1)
+            out["cpu_baseline"] = cpu_baseline(args.k, host_cores())
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

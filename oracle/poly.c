@@ -10,6 +10,14 @@
 #include <omp.h>
 #endif
 
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
+#endif
+}
+
 /* ------------------------------------------------------------------ MSM */
 void orc_msm_naive(orc_g1 *out, const orc_fr *scalars, const orc_g1a *bases, size_t n) {
     orc_g1 acc;

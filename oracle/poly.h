@@ -20,6 +20,9 @@
 extern "C" {
 #endif
 
+/* OpenMP thread count used by the parallel loops below (CPU-baseline timing). */
+void orc_set_threads(int n);
+
 /* ---- arithmetic.rs ---- */
 /* Naive sum_i s_i * P_i by double-and-add: the definition MSM implementations are checked against. */
 void orc_msm_naive(orc_g1 *out, const orc_fr *scalars, const orc_g1a *bases, size_t n);
