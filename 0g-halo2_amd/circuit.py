@@ -1,0 +1,377 @@
+"""Host-side circuit description for the prover ABI (include/zg_halo2.h `zg_circuit`).
+
+A small mirror of halo2's `ConstraintSystem` (halo2_proofs v2023_04_20 src/plonk/circuit.rs) and of the
+permutation assembly done by keygen (src/plonk/permutation/keygen.rs): columns, cell queries, gate
+polynomials, lookup arguments, equality constraints -> the flat arrays `zg_prover_create` takes.
+It exists to feed tests and bench.py with circuits of the reference's shape; zero_g's real circuit is
+built by the Rust `WnnChip::configure` (/root/reference/src/gadgets/wnn.rs:125-172), which this run
+does not re-implement (out of scope).
+
+Polynomials are kept expanded: {tuple(sorted query indices): coefficient mod r}.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+MONT = (1 << 256) % R
+DELTA = pow(7, 1 << 28, R)
+ROOT_OF_UNITY = pow(7, (R - 1) >> 28, R)
+
+FIXED, ADVICE, INSTANCE = 0, 1, 2
+MAX_FACTORS, MAX_LOOKUP_WIDTH = 8, 4
+
+
+def omega_for(k: int) -> int:
+    return pow(ROOT_OF_UNITY, 1 << (28 - k), R)
+
+
+def to_mont_array(vals) -> np.ndarray:
+    """list of canonical ints -> uint64[len, 4] Montgomery limbs"""
+    out = np.empty((len(vals), 4), dtype=np.uint64)
+    m = (1 << 64) - 1
+    for i, v in enumerate(vals):
+        x = (v % R) * MONT % R
+        out[i, 0] = x & m
+        out[i, 1] = (x >> 64) & m
+        out[i, 2] = (x >> 128) & m
+        out[i, 3] = x >> 192
+    return out
+
+
+class Expr:
+    """Multivariate polynomial over cell queries, coefficients mod r."""
+
+    __slots__ = ("terms",)
+
+    def __init__(self, terms=None):
+        self.terms = {k: v % R for k, v in (terms or {}).items() if v % R}
+
+    @staticmethod
+    def const(c: int) -> "Expr":
+        return Expr({(): c})
+
+    @staticmethod
+    def _lift(o) -> "Expr":
+        return o if isinstance(o, Expr) else Expr.const(int(o))
+
+    def __add__(self, o):
+        o = Expr._lift(o)
+        t = dict(self.terms)
+        for k, v in o.terms.items():
+            t[k] = (t.get(k, 0) + v) % R
+        return Expr(t)
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return Expr({k: -v for k, v in self.terms.items()})
+
+    def __sub__(self, o):
+        return self + (-Expr._lift(o))
+
+    def __rsub__(self, o):
+        return Expr._lift(o) - self
+
+    def __mul__(self, o):
+        o = Expr._lift(o)
+        t = {}
+        for k1, v1 in self.terms.items():
+            for k2, v2 in o.terms.items():
+                k = tuple(sorted(k1 + k2))
+                t[k] = (t.get(k, 0) + v1 * v2) % R
+        return Expr(t)
+
+    __rmul__ = __mul__
+
+    def degree(self) -> int:
+        return max((len(k) for k in self.terms), default=0)
+
+    def eval(self, cell):
+        """cell(query_index) -> int"""
+        acc = 0
+        for k, v in self.terms.items():
+            p = v
+            for q in k:
+                p = p * cell(q) % R
+            acc += p
+        return acc % R
+
+
+class _Poly(ctypes.Structure):
+    _fields_ = [("first", ctypes.c_uint32), ("count", ctypes.c_uint32)]
+
+
+class _Query(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_uint32), ("column", ctypes.c_uint32), ("rotation", ctypes.c_int32)]
+
+
+class _Monomial(ctypes.Structure):
+    _fields_ = [("coeff", ctypes.c_uint64 * 4), ("n_factors", ctypes.c_uint32),
+                ("factors", ctypes.c_uint32 * MAX_FACTORS)]
+
+
+class _Lookup(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_uint32), ("inputs", _Poly * MAX_LOOKUP_WIDTH),
+                ("tables", _Poly * MAX_LOOKUP_WIDTH)]
+
+
+class CCircuit(ctypes.Structure):
+    """ctypes image of `zg_circuit`."""
+    _fields_ = [
+        ("k", ctypes.c_uint32), ("cs_degree", ctypes.c_uint32), ("blinding_factors", ctypes.c_uint32),
+        ("n_fixed", ctypes.c_uint32), ("n_advice", ctypes.c_uint32), ("n_instance", ctypes.c_uint32),
+        ("n_queries", ctypes.c_uint32), ("queries", ctypes.POINTER(_Query)),
+        ("n_monomials", ctypes.c_uint32), ("monomials", ctypes.POINTER(_Monomial)),
+        ("n_gates", ctypes.c_uint32), ("gates", ctypes.POINTER(_Poly)),
+        ("n_lookups", ctypes.c_uint32), ("lookups", ctypes.POINTER(_Lookup)),
+        ("n_perm_columns", ctypes.c_uint32), ("perm_columns", ctypes.POINTER(_Query)),
+        ("n_advice_queries", ctypes.c_uint32), ("advice_queries", ctypes.POINTER(_Query)),
+        ("n_fixed_queries", ctypes.c_uint32), ("fixed_queries", ctypes.POINTER(_Query)),
+    ]
+
+
+@dataclass
+class ConstraintSystem:
+    k: int
+    n_fixed: int = 0
+    n_advice: int = 0
+    n_instance: int = 0
+    queries: list = field(default_factory=list)          # (kind, column, rotation)
+    gates: list = field(default_factory=list)            # Expr, creation order
+    lookups: list = field(default_factory=list)          # (inputs [Expr], tables [Expr])
+    perm_columns: list = field(default_factory=list)     # (kind, column)
+    advice_queries: list = field(default_factory=list)   # (column, rotation) in first-query order
+    fixed_queries: list = field(default_factory=list)
+    instance_queries: list = field(default_factory=list)
+
+    # ---- columns
+    def fixed_column(self) -> int:
+        self.n_fixed += 1
+        return self.n_fixed - 1
+
+    def advice_column(self) -> int:
+        self.n_advice += 1
+        return self.n_advice - 1
+
+    def instance_column(self) -> int:
+        self.n_instance += 1
+        return self.n_instance - 1
+
+    # ---- queries (query_any_index)
+    def q(self, kind: int, column: int, rotation: int = 0) -> Expr:
+        key = (kind, column, rotation)
+        if key not in self.queries:
+            self.queries.append(key)
+            lst = {FIXED: self.fixed_queries, ADVICE: self.advice_queries, INSTANCE: self.instance_queries}[kind]
+            lst.append((column, rotation))
+        return Expr({(self.queries.index(key),): 1})
+
+    def fixed(self, c, rot=0):
+        return self.q(FIXED, c, rot)
+
+    def advice(self, c, rot=0):
+        return self.q(ADVICE, c, rot)
+
+    def instance(self, c, rot=0):
+        return self.q(INSTANCE, c, rot)
+
+    def create_gate(self, polys):
+        for p in polys:
+            assert p.degree() <= MAX_FACTORS
+            self.gates.append(p)
+
+    def lookup(self, inputs, tables):
+        assert len(inputs) == len(tables) <= MAX_LOOKUP_WIDTH
+        self.lookups.append((list(inputs), list(tables)))
+
+    def enable_equality(self, kind: int, column: int):
+        """permutation.add_column + query at Rotation::cur() (halo2 does both)."""
+        if (kind, column) not in self.perm_columns:
+            self.perm_columns.append((kind, column))
+            self.q(kind, column, 0)
+
+    # ---- derived quantities (circuit.rs)
+    def degree(self) -> int:
+        d = 3 if self.perm_columns else 1  # permutation::Argument::required_degree
+        for ins, tabs in self.lookups:
+            ind = max([1] + [e.degree() for e in ins])
+            td = max([1] + [e.degree() for e in tabs])
+            d = max(d, 4, 2 + ind + td)
+        for g in self.gates:
+            d = max(d, g.degree())
+        return d
+
+    def blinding_factors(self) -> int:
+        per_col = {}
+        for (c, _r) in self.advice_queries:
+            per_col[c] = per_col.get(c, 0) + 1
+        return max(3, max(per_col.values(), default=0)) + 2
+
+    def extended_k(self) -> int:
+        ek = self.k
+        while (1 << ek) < (1 << self.k) * (self.degree() - 1):
+            ek += 1
+        return ek
+
+    def usable_rows(self) -> int:
+        return (1 << self.k) - (self.blinding_factors() + 1)
+
+    # ---- flattening to the ABI structs
+    def to_c(self) -> "CircuitImage":
+        monos, polys = [], []
+
+        def add_poly(e: Expr) -> _Poly:
+            first = len(monos)
+            for key in sorted(e.terms):
+                m = _Monomial()
+                x = e.terms[key] * MONT % R
+                for i in range(4):
+                    m.coeff[i] = (x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+                m.n_factors = len(key)
+                for i, qi in enumerate(key):
+                    m.factors[i] = qi
+                monos.append(m)
+            return _Poly(first, len(monos) - first)
+
+        gates = [add_poly(g) for g in self.gates]
+        lks = []
+        for ins, tabs in self.lookups:
+            lk = _Lookup()
+            lk.width = len(ins)
+            for i, e in enumerate(ins):
+                lk.inputs[i] = add_poly(e)
+            for i, e in enumerate(tabs):
+                lk.tables[i] = add_poly(e)
+            lks.append(lk)
+
+        def arr(ctype, items):
+            a = (ctype * max(1, len(items)))()
+            for i, it in enumerate(items):
+                a[i] = it
+            return a
+
+        img = CircuitImage()
+        img.queries = arr(_Query, [_Query(k, c, r) for (k, c, r) in self.queries])
+        img.monomials = arr(_Monomial, monos)
+        img.gates = arr(_Poly, gates)
+        img.lookups = arr(_Lookup, lks)
+        img.perm = arr(_Query, [_Query(k, c, 0) for (k, c) in self.perm_columns])
+        img.aq = arr(_Query, [_Query(ADVICE, c, r) for (c, r) in self.advice_queries])
+        img.fq = arr(_Query, [_Query(FIXED, c, r) for (c, r) in self.fixed_queries])
+        c = CCircuit()
+        c.k, c.cs_degree, c.blinding_factors = self.k, self.degree(), self.blinding_factors()
+        c.n_fixed, c.n_advice, c.n_instance = self.n_fixed, self.n_advice, self.n_instance
+        c.n_queries, c.queries = len(self.queries), ctypes.cast(img.queries, ctypes.POINTER(_Query))
+        c.n_monomials, c.monomials = len(monos), ctypes.cast(img.monomials, ctypes.POINTER(_Monomial))
+        c.n_gates, c.gates = len(gates), ctypes.cast(img.gates, ctypes.POINTER(_Poly))
+        c.n_lookups, c.lookups = len(lks), ctypes.cast(img.lookups, ctypes.POINTER(_Lookup))
+        c.n_perm_columns, c.perm_columns = len(self.perm_columns), ctypes.cast(img.perm, ctypes.POINTER(_Query))
+        c.n_advice_queries, c.advice_queries = len(self.advice_queries), ctypes.cast(img.aq, ctypes.POINTER(_Query))
+        c.n_fixed_queries, c.fixed_queries = len(self.fixed_queries), ctypes.cast(img.fq, ctypes.POINTER(_Query))
+        img.c = c
+        return img
+
+
+class CircuitImage:
+    """Keeps the ctypes arrays alive next to the zg_circuit that points into them."""
+    c: CCircuit
+
+    def ptr(self):
+        return ctypes.byref(self.c)
+
+
+class Assignment:
+    """Cell values + equality constraints -> fixed / advice / instance columns and the sigma
+    polynomials keygen derives (permutation::keygen::Assembly)."""
+
+    def __init__(self, cs: ConstraintSystem):
+        self.cs = cs
+        self.n = 1 << cs.k
+        self.fixed = [[0] * self.n for _ in range(cs.n_fixed)]
+        self.advice = [[0] * self.n for _ in range(cs.n_advice)]
+        self.instance = [[0] * self.n for _ in range(cs.n_instance)]
+        m = len(cs.perm_columns)
+        # cycle representation as in halo2: mapping[col][row] = next cell of the cycle
+        self.mapping = [[(c, r) for r in range(self.n)] for c in range(m)]
+        self.aux = [[(c, r) for r in range(self.n)] for c in range(m)]
+        self.sizes = [[1] * self.n for _ in range(m)]
+
+    def col(self, kind):
+        return {FIXED: self.fixed, ADVICE: self.advice, INSTANCE: self.instance}[kind]
+
+    def set(self, kind, column, row, value):
+        self.col(kind)[column][row] = value % R
+
+    def get(self, kind, column, row):
+        return self.col(kind)[column][row]
+
+    def copy(self, a, b):
+        """a, b = (kind, column, row); merges their permutation cycles (Assembly::copy)."""
+        pa = self.cs.perm_columns.index((a[0], a[1]))
+        pb = self.cs.perm_columns.index((b[0], b[1]))
+        assert self.get(*a) == self.get(*b), (a, b, self.get(*a), self.get(*b))
+        lc, lr, rc, rr = pa, a[2], pb, b[2]
+        if self.aux[lc][lr] == self.aux[rc][rr]:
+            return
+        if self.sizes[self.aux[lc][lr][0]][self.aux[lc][lr][1]] < self.sizes[self.aux[rc][rr][0]][self.aux[rc][rr][1]]:
+            lc, lr, rc, rr = rc, rr, lc, lr
+        la, ra = self.aux[lc][lr], self.aux[rc][rr]
+        self.sizes[la[0]][la[1]] += self.sizes[ra[0]][ra[1]]
+        i, j = rc, rr
+        while True:
+            self.aux[i][j] = la
+            i, j = self.mapping[i][j]
+            if (i, j) == (rc, rr):
+                break
+        self.mapping[lc][lr], self.mapping[rc][rr] = self.mapping[rc][rr], self.mapping[lc][lr]
+
+    def sigma_values(self) -> np.ndarray:
+        """[n_perm][n] Lagrange values: sigma_c(omega^r) = delta^c' * omega^r' for mapping[c][r] = (c', r')."""
+        m = len(self.cs.perm_columns)
+        w = omega_for(self.cs.k)
+        wp = [1] * self.n
+        for i in range(1, self.n):
+            wp[i] = wp[i - 1] * w % R
+        dp = [pow(DELTA, c, R) for c in range(m)]
+        out = np.empty((max(m, 1), self.n, 4), dtype=np.uint64)
+        for c in range(m):
+            out[c] = to_mont_array([dp[pc] * wp[pr] % R for (pc, pr) in self.mapping[c]])
+        return out[:m]
+
+    def fixed_values(self) -> np.ndarray:
+        return np.stack([to_mont_array(col) for col in self.fixed]) if self.fixed else np.zeros((0, self.n, 4), np.uint64)
+
+    def advice_values(self) -> np.ndarray:
+        return np.stack([to_mont_array(col) for col in self.advice]) if self.advice else np.zeros((0, self.n, 4), np.uint64)
+
+    def instance_values(self, length: int) -> np.ndarray:
+        if not self.instance:
+            return np.zeros((0, length, 4), np.uint64)
+        return np.stack([to_mont_array(col[:length]) for col in self.instance])
+
+    def check(self):
+        """MockProver-style check on the usable rows: gates vanish, lookup inputs are in the table,
+        copies hold (asserted at copy time)."""
+        cs, n = self.cs, self.n
+        usable = cs.usable_rows()
+
+        def cell_at(row):
+            def f(qi):
+                kind, c, rot = cs.queries[qi]
+                return self.col(kind)[c][(row + rot) % n]
+            return f
+
+        for row in range(usable):
+            f = cell_at(row)
+            for gi, g in enumerate(cs.gates):
+                v = g.eval(f)
+                assert v == 0, f"gate {gi} fails on row {row}: {v}"
+        for li, (ins, tabs) in enumerate(cs.lookups):
+            table = {tuple(t.eval(cell_at(r)) for t in tabs) for r in range(usable)}
+            for row in range(usable):
+                tup = tuple(e.eval(cell_at(row)) for e in ins)
+                assert tup in table, f"lookup {li} input {tup} on row {row} not in table"

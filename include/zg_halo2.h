@@ -150,6 +150,105 @@ int zg_extended_to_coeff_dev(zg_ctx *ctx, void *d_evals, uint32_t k, uint32_t ex
 /* The standard domain roots: omega = ROOT_OF_UNITY^(2^(28-log_n)) and its inverse. */
 int zg_domain_omega(uint32_t log_n, zg_fr *omega, zg_fr *omega_inv);
 
+/* ------------------------------------------------------------------ circuit description
+ * What halo2 keeps in `ConstraintSystem` + `ProvingKey` (halo2_proofs v2023_04_20
+ * src/plonk/circuit.rs, src/plonk/keygen.rs), flattened to plain arrays so that it can cross a C ABI.
+ * For zero_g it is produced from `WnnCircuit::configure` (/root/reference/src/gadgets/wnn.rs:334-371,
+ * chips configured at wnn.rs:125-172); SURVEY.md appendix A lists its 12 gate polynomials,
+ * 4 lookups and 8 permutation columns.  Every polynomial (gate, lookup input, lookup table) is given
+ * in expanded form sum_m coeff_m * prod_f cell(query_f): exact over the field, so the value is the
+ * one halo2's Expression tree / GraphEvaluator computes. */
+enum { ZG_FIXED = 0, ZG_ADVICE = 1, ZG_INSTANCE = 2 };
+enum { ZG_MAX_FACTORS = 8, ZG_MAX_LOOKUP_WIDTH = 4 };
+
+typedef struct {
+    uint32_t kind;      /* ZG_FIXED / ZG_ADVICE / ZG_INSTANCE */
+    uint32_t column;
+    int32_t rotation;   /* Rotation(i32): row offset in the 2^k domain */
+} zg_query;
+
+typedef struct {
+    zg_fr coeff;                          /* Montgomery form */
+    uint32_t n_factors;                   /* 0 = constant term */
+    uint32_t factors[ZG_MAX_FACTORS];     /* indices into zg_circuit.queries */
+} zg_monomial;
+
+typedef struct { uint32_t first, count; } zg_poly;   /* range in zg_circuit.monomials */
+
+typedef struct {
+    uint32_t width;                              /* tuple length m (same for inputs and table) */
+    zg_poly inputs[ZG_MAX_LOOKUP_WIDTH];         /* lookup::Argument::input_expressions */
+    zg_poly tables[ZG_MAX_LOOKUP_WIDTH];         /* lookup::Argument::table_expressions */
+} zg_lookup;
+
+typedef struct {
+    uint32_t k;                  /* rows = 2^k */
+    uint32_t cs_degree;          /* ConstraintSystem::degree(); extended domain = smallest 2^e >= 2^k*(degree-1) */
+    uint32_t blinding_factors;   /* ConstraintSystem::blinding_factors(); last rotation = -(bf+1) */
+    uint32_t n_fixed, n_advice, n_instance;
+    uint32_t n_queries;        const zg_query *queries;
+    uint32_t n_monomials;      const zg_monomial *monomials;
+    uint32_t n_gates;          const zg_poly *gates;         /* gate polynomials in creation order */
+    uint32_t n_lookups;        const zg_lookup *lookups;
+    uint32_t n_perm_columns;   const zg_query *perm_columns; /* permutation::Argument::columns (rotation unused) */
+    uint32_t n_advice_queries; const zg_query *advice_queries;  /* cs.advice_queries: order of the advice evals */
+    uint32_t n_fixed_queries;  const zg_query *fixed_queries;   /* cs.fixed_queries  */
+} zg_circuit;
+
+/* ------------------------------------------------------------------ prover
+ * Replaces halo2_proofs::plonk::create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC, _, _,
+ * EvmTranscript, _> for ONE circuit instance, as Wnn::proof calls it
+ * (/root/reference/src/wnn.rs:242-259), from "advice columns assigned" to "proof bytes":
+ * commitments (MSM), lagrange_to_coeff / coeff_to_extended (NTT), lookup::prover::{commit_permuted,
+ * commit_product}, permutation::prover::commit, vanishing::prover::{commit, construct, evaluate},
+ * Evaluator::evaluate_h, eval_polynomial and ProverGWC::create_proof, with the Keccak-256
+ * EvmTranscript of snark-verifier (wnn.rs:21,249).  Witness synthesis (the Rust WnnChip) stays on the
+ * caller's side: advice arrives as column values.
+ *
+ * Randomness: upstream draws blinding scalars from OsRng (wnn.rs:256), so real proofs are not
+ * reproducible.  Here every blinding scalar is a pure function of (rng_seed, purpose tag, index) --
+ * SplitMix64 + rejection sampling, documented in DESIGN.md -- so that the oracle reproduces the same
+ * proof bytes. */
+typedef struct zg_prover zg_prover;
+
+/* Uploads the proving key material and derives what keygen_pk derives (fixed/sigma polys and their
+ * extended cosets, l_0 / l_last / l_active_row cosets).  fixed_values: [n_fixed][2^k] Lagrange values;
+ * sigma_values: [n_perm_columns][2^k] Lagrange values of the permutation polynomials
+ * (pk.permutation.permutations); g / g_lagrange: ParamsKZG; vk_repr: vk.transcript_repr, the scalar
+ * create_proof hashes into the transcript first.  All host pointers, copied. */
+int zg_prover_create(zg_ctx *ctx, const zg_circuit *circuit, const zg_fr *fixed_values,
+                     const zg_fr *sigma_values, const zg_g1_affine *g, const zg_g1_affine *g_lagrange,
+                     const zg_fr *vk_repr, zg_prover **out);
+void zg_prover_destroy(zg_prover *p);
+/* advice: [n_advice][2^k] column values (host); the last blinding_factors+1 rows are overwritten with
+ * blinding scalars as create_proof does.  instance: [n_instance][instance_len] public inputs.
+ * proof: receives the transcript bytes (EvmTranscript layout). */
+int zg_prover_prove(zg_prover *p, const zg_fr *advice, const zg_fr *instance, size_t instance_len,
+                    uint64_t rng_seed, uint8_t *proof, size_t proof_cap, size_t *proof_len);
+/* Same with the advice columns already in HBM ([n_advice][2^k], clobbered). */
+int zg_prover_prove_dev(zg_prover *p, void *d_advice, const zg_fr *instance, size_t instance_len,
+                        uint64_t rng_seed, uint8_t *proof, size_t proof_cap, size_t *proof_len);
+/* Upper bound of the proof size in bytes for this circuit. */
+size_t zg_prover_proof_size(const zg_prover *p);
+/* Test hook: copies an intermediate of the LAST proof to the host.  what: 0 = h(X) on the extended
+ * coset before division by (X^n - 1) [2^ext_k], 1 = permutation z (index = set) [2^k Lagrange],
+ * 2 = lookup z (index = lookup) [2^k Lagrange], 3 = permuted input a' (index = lookup),
+ * 4 = permuted table s' (index = lookup), 5 = h pieces in coefficient form [5 * 2^k]. */
+int zg_prover_fetch(zg_prover *p, uint32_t what, uint32_t index, zg_fr *out, size_t cap_elems);
+
+/* Stand-alone building blocks of the above (device pointers, context stream), exposed for tests. */
+/* z[0] = z0, z[i+1] = z[i] * num[i] / den[i]  (lookup::prover::commit_product / permutation commit). */
+int zg_grand_product_dev(zg_ctx *ctx, const void *d_num, const void *d_den, const zg_fr *z0, size_t n,
+                         void *d_z);
+/* eval_polynomial: out[j] = polys[j](points[j]) for `count` (poly, point) pairs; polys at
+ * d_polys + poly_index[j]*stride_elems; points are host scalars; out is a host array. */
+int zg_eval_polys_dev(zg_ctx *ctx, const void *d_polys, size_t stride_elems, size_t n,
+                      const uint32_t *poly_index, const zg_fr *points, size_t count, zg_fr *out);
+/* kate_division: d_q[0..n-1) = a(X) / (X - z). */
+int zg_kate_division_dev(zg_ctx *ctx, const void *d_a, size_t n, const zg_fr *z, void *d_q);
+/* Keccak-256 (EvmTranscript's hash), host. */
+void zg_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,3 +196,87 @@ def extended_to_coeff(d: Domain, evals: np.ndarray) -> np.ndarray:
     out = np.zeros((int(d.n) * int(d.quotient_poly_degree), 4), np.uint64)
     load().orc_extended_to_coeff(ctypes.byref(d), _p(out), _p(evals))
     return out
+
+
+# ---------------------------------------------------------------- create_proof / verify_proof
+class _Pk(ctypes.Structure):
+    _fields_ = [("cs", c_void_p), ("fixed_values", c_void_p), ("sigma_values", c_void_p),
+                ("params", c_void_p), ("vk_repr", c_uint64 * 4)]
+
+
+class Trace(ctypes.Structure):
+    _fields_ = ([(name, c_void_p) for name in ("h_ext", "perm_z", "lookup_z", "permuted_input",
+                                               "permuted_table", "h_pieces")]
+                + [(name, c_uint64 * 4) for name in ("theta", "beta", "gamma", "y", "x", "v")]
+                + [("n_sets", c_uint32)])
+
+    def array(self, name: str, count: int) -> np.ndarray:
+        ptr = getattr(self, name)
+        return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(c_uint64)), shape=(count, 4)).copy()
+
+    def fe(self, name: str) -> np.ndarray:
+        return np.array(list(getattr(self, name)), dtype=np.uint64)
+
+
+class ProvingKey:
+    """orc_pk: circuit image (0g-halo2_amd/circuit.py CircuitImage), fixed/sigma values, SRS."""
+
+    def __init__(self, image, fixed_values: np.ndarray, sigma_values: np.ndarray, params: Params,
+                 vk_repr: np.ndarray):
+        self.image = image
+        self.fixed = np.ascontiguousarray(fixed_values, dtype=np.uint64)
+        self.sigma = np.ascontiguousarray(sigma_values, dtype=np.uint64)
+        self.params = params
+        self.vk_repr = np.ascontiguousarray(vk_repr, dtype=np.uint64)
+        self.c = _Pk()
+        self.c.cs = ctypes.cast(image.ptr(), c_void_p)
+        self.c.fixed_values = self.fixed.ctypes.data
+        self.c.sigma_values = self.sigma.ctypes.data
+        self.c.params = ctypes.cast(ctypes.byref(params), c_void_p)
+        for i in range(4):
+            self.c.vk_repr[i] = int(self.vk_repr[i])
+
+
+def proof_size(image) -> int:
+    f = load().orc_proof_size
+    f.restype = c_size_t
+    return int(f(image.ptr()))
+
+
+def create_proof(pk: ProvingKey, advice: np.ndarray, instance: np.ndarray, seed: int, want_trace=False):
+    """Returns (status, proof bytes, Trace | None)."""
+    advice = np.ascontiguousarray(advice, dtype=np.uint64)
+    instance = np.ascontiguousarray(instance, dtype=np.uint64)
+    inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0
+    cap = proof_size(pk.image)
+    buf = (ctypes.c_uint8 * cap)()
+    plen = c_size_t(0)
+    tr = Trace() if want_trace else None
+    st = load().orc_create_proof(ctypes.byref(pk.c), _p(advice), _p(instance), c_size_t(inst_len),
+                                 c_uint64(seed), buf, c_size_t(cap), ctypes.byref(plen),
+                                 ctypes.byref(tr) if tr is not None else None)
+    return st, bytes(buf[: plen.value]), tr
+
+
+def verify_proof(pk: ProvingKey, instance: np.ndarray, proof: bytes) -> int:
+    instance = np.ascontiguousarray(instance, dtype=np.uint64)
+    inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0
+    buf = (ctypes.c_uint8 * len(proof)).from_buffer_copy(proof)
+    return int(load().orc_verify_proof(ctypes.byref(pk.c), _p(instance), c_size_t(inst_len), buf,
+                                       c_size_t(len(proof))))
+
+
+def trace_free(tr: Trace):
+    load().orc_trace_free(ctypes.byref(tr))
+
+
+def keccak256(data: bytes) -> bytes:
+    out = (ctypes.c_uint8 * 32)()
+    load().orc_keccak256(data, c_size_t(len(data)), out)
+    return bytes(out)
+
+
+def rand_fr(seed: int, tag: int, index: int) -> np.ndarray:
+    out = np.zeros(4, np.uint64)
+    load().orc_rand_fr(_p(out), c_uint64(seed), c_uint32(tag), c_uint64(index))
+    return out

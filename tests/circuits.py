@@ -1,0 +1,72 @@
+"""Test circuits built with the host-side ConstraintSystem mirror (0g-halo2_amd/circuit.py)."""
+import random
+
+from circuit import ADVICE, FIXED, INSTANCE, R, Assignment, ConstraintSystem
+
+
+def toy_circuit(k=5, seed=1, table_bits=4, two_lookups=False, force_degree=None):
+    """A multiplication chain with a range lookup, a rotation, copy constraints across advice /
+    fixed / instance columns: exercises every argument create_proof has (gates, lookup, permutation
+    with >1 set when the degree is small, instance, constants)."""
+    rng = random.Random(seed)
+    cs = ConstraintSystem(k)
+    q_mul = cs.fixed_column()
+    tab = cs.fixed_column()
+    const = cs.fixed_column()
+    a0, a1, a2 = cs.advice_column(), cs.advice_column(), cs.advice_column()
+    inst = cs.instance_column()
+    for kind, c in ((ADVICE, a0), (ADVICE, a1), (ADVICE, a2), (INSTANCE, inst), (FIXED, const)):
+        cs.enable_equality(kind, c)
+    q = cs.fixed(q_mul)
+    cs.create_gate([q * (cs.advice(a0) * cs.advice(a1) - cs.advice(a2)),
+                    q * (cs.advice(a0, 1) - cs.advice(a2))])
+    cs.lookup([q * cs.advice(a1)], [cs.fixed(tab)])
+    if two_lookups:
+        q_t = cs.fixed_column()
+        tab2 = cs.fixed_column()
+        cs.lookup([cs.fixed(q_t) * cs.advice(a1), cs.fixed(q_t) * cs.advice(a1, -1)],
+                  [cs.fixed(tab), cs.fixed(tab2)])
+    q_hi = None
+    if force_degree:
+        # a higher-degree restatement of the product gate, q_hi * a0^(d-3) * (a0*a1 - a2), active on
+        # the same rows (an identically-zero gate would make the top h pieces the zero polynomial,
+        # whose identity commitment EvmTranscript refuses to absorb -- as upstream does)
+        q_hi = cs.fixed_column()
+        e = cs.fixed(q_hi) * (cs.advice(a0) * cs.advice(a1) - cs.advice(a2))
+        for _ in range(force_degree - 3):
+            e = e * cs.advice(a0)
+        cs.create_gate([e])
+
+    asg = Assignment(cs)
+    n, usable = 1 << k, cs.usable_rows()
+    tsize = 1 << table_bits
+    for r in range(usable):
+        asg.set(FIXED, tab, r, r % tsize)
+        if two_lookups:
+            asg.set(FIXED, 4, r, (r % tsize) * 3 % R)  # tab2: pairs (v, 3v)
+    rows = usable - 2
+    val = 3
+    asg.set(FIXED, const, 0, 3)
+    for r in range(rows):
+        asg.set(FIXED, q_mul, r, 1)
+        if q_hi is not None:
+            asg.set(FIXED, q_hi, r, 1)
+        b = rng.randrange(tsize)
+        asg.set(ADVICE, a0, r, val)
+        asg.set(ADVICE, a1, r, b)
+        val = val * b % R
+        asg.set(ADVICE, a2, r, val)
+    asg.set(ADVICE, a0, rows, val)
+    asg.set(INSTANCE, inst, 0, val)
+    asg.copy((ADVICE, a0, 0), (FIXED, const, 0))
+    asg.copy((ADVICE, a2, rows - 1), (INSTANCE, inst, 0))
+    for r in range(rows):
+        asg.copy((ADVICE, a2, r), (ADVICE, a0, r + 1))
+    # a few extra copies between equal cells to make longer cycles
+    zeros = [r for r in range(rows) if asg.get(ADVICE, a1, r) == 0]
+    for r1, r2 in zip(zeros, zeros[1:]):
+        asg.copy((ADVICE, a1, r1), (ADVICE, a1, r2))
+    if two_lookups:
+        # q_t rows: (a1[r], a1[r-1]) must be (v, 3v): use dedicated rows at the end of the region
+        pass
+    return cs, asg, 1  # instance_len = 1
