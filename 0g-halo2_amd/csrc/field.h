@@ -213,13 +213,85 @@ struct Field {
         return res;
     }
 
-    // Fermat inversion a^(p-2); 0 -> 0
-    static ZG_HD Fe inv(const Fe& a) {
+    // Fermat inversion a^(p-2); 0 -> 0.  ~380 dependent products: use inv() unless a constant-time
+    // chain is wanted.
+    static ZG_HD Fe inv_fermat(const Fe& a) {
         uint32_t e[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) e[i] = P::p(i);
         e[0] -= 2;
         return pow(a, e);
+    }
+
+    // Inversion by the binary extended Euclidean algorithm on the canonical integer (HAC 14.61):
+    // shifts, adds and subtracts only -- an order of magnitude shorter than the Fermat chain when a
+    // single lane has to do it (grand-product denominators, affine normalisation).  0 -> 0.
+    static ZG_HD Fe inv(const Fe& a) {
+        if (fe_is_zero(a)) return a;
+        uint32_t pm[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pm[i] = P::p(i);
+        // u = a*R (the Montgomery residue taken as an integer), v = p; invariants:
+        //   x1 * (aR) == u (mod p),  x2 * (aR) == v (mod p)
+        uint32_t u[8], v[8], x1[8], x2[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            u[i] = a.l[i];
+            v[i] = pm[i];
+            x1[i] = 0;
+            x2[i] = 0;
+        }
+        x1[0] = 1;
+        auto is_one = [](const uint32_t* w) {
+            uint32_t o = w[0] ^ 1u;
+#pragma unroll
+            for (int i = 1; i < 8; i++) o |= w[i];
+            return o == 0;
+        };
+        auto shr1 = [](uint32_t* w, uint32_t top) {
+#pragma unroll
+            for (int i = 0; i < 7; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 31);
+            w[7] = (w[7] >> 1) | (top << 31);
+        };
+        auto halve_mod = [&](uint32_t* w) {  // w <- w/2 mod p
+            uint32_t carry = 0;
+            if (w[0] & 1u) carry = add8(w, w, pm);
+            shr1(w, carry);
+        };
+        auto geq = [](const uint32_t* x, const uint32_t* y) {
+            for (int i = 7; i >= 0; i--) {
+                if (x[i] > y[i]) return true;
+                if (x[i] < y[i]) return false;
+            }
+            return true;
+        };
+        auto sub_mod = [&](uint32_t* x, const uint32_t* y) {  // x <- x - y mod p
+            uint32_t borrow = sub8(x, x, y);
+            if (borrow) add8(x, x, pm);
+        };
+        while (!is_one(u) && !is_one(v)) {
+            while ((u[0] & 1u) == 0) {
+                shr1(u, 0);
+                halve_mod(x1);
+            }
+            while ((v[0] & 1u) == 0) {
+                shr1(v, 0);
+                halve_mod(x2);
+            }
+            if (geq(u, v)) {
+                sub8(u, u, v);
+                sub_mod(x1, x2);
+            } else {
+                sub8(v, v, u);
+                sub_mod(x2, x1);
+            }
+        }
+        Fe r;
+        const uint32_t* res = is_one(u) ? x1 : x2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = res[i];
+        // r = (aR)^-1 = a^-1 R^-1 as an integer; two Montgomery products by R^2 give a^-1 R
+        return mul(mul(r, P::r2()), P::r2());
     }
 };
 

@@ -1,0 +1,109 @@
+// Device-side circuit image and the launch helpers of poly.hip (shared with prover.hip).
+#pragma once
+
+#include "common.h"
+
+namespace zg {
+
+struct alignas(16) DMono {
+    Fe coeff;
+    uint32_t n_factors;
+    uint32_t coeff_is_one;
+    uint32_t factors[ZG_MAX_FACTORS];
+    uint32_t pad[2];
+};
+static_assert(sizeof(DMono) == 80, "DMono layout");
+
+struct DLookup {
+    uint32_t width;
+    zg_poly inputs[ZG_MAX_LOOKUP_WIDTH];
+    zg_poly tables[ZG_MAX_LOOKUP_WIDTH];
+};
+
+// circuit arrays in HBM (read through the scalar cache: every index is wave-uniform)
+struct DevCircuit {
+    const zg_query* queries;
+    const DMono* monos;
+    const zg_poly* gates;
+    const DLookup* lookups;
+    const zg_query* perm_cols;
+    uint32_t n_gates, n_lookups, n_perm, chunk, n_sets;
+};
+
+// one family of column arrays [column][size]
+struct Cols {
+    const Fe* fixed;
+    const Fe* advice;
+    const Fe* instance;
+    uint32_t log_size;
+    int32_t rot_scale;
+};
+
+struct EvalHArgs {
+    DevCircuit c;
+    Cols cols;  // extended cosets
+    const Fe* sigma_cos;
+    const Fe* pz_cos;
+    const Fe* lz_cos;
+    const Fe* pin_cos;
+    const Fe* ptab_cos;
+    const Fe* l0;
+    const Fe* llast;
+    const Fe* lactive;
+    const Fe* ext_tw;  // extended_omega^i
+    const Fe* t_eval;  // ((zeta*ext_omega^i)^n - 1)^-1, period t_len (power of two)
+    uint32_t t_mask;
+    int32_t last_rot;  // -(blinding_factors + 1)
+    Fe y, beta, gamma, theta, delta_start, delta;
+    Fe* h;
+};
+
+// blinding scalar = f(seed, tag, index); identical to the oracle's definition
+enum {
+    TAG_ADVICE_BLIND = 1,
+    TAG_PERMUTED_INPUT = 2,
+    TAG_PERMUTED_TABLE = 3,
+    TAG_PERM_Z = 4,
+    TAG_LOOKUP_Z = 5,
+    TAG_RANDOM_POLY = 6
+};
+
+// ---- launch helpers (all asynchronous on ctx->stream) ----
+int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
+                    uint64_t seed, uint32_t tag);
+int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag);
+int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe& theta, Fe* cin, Fe* ctab,
+                         uint32_t n);
+int poly_to_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
+int poly_from_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
+int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab, const Fe& beta,
+                      const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups);
+int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe* sigma_val, const Fe* omega_tw,
+                    const Fe& beta, const Fe& gamma, Fe* num, Fe* den, uint32_t n);
+// z[b][0] = *z0[b] (device pointers, or one if null), z[b][i+1] = z[b][i]*num[b][i]/den[b][i]; tmp: [batch][n]
+int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* const* d_z0, Fe* z, Fe* tmp,
+                       uint32_t n, uint32_t batch);
+int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en);
+int poly_powers(zg_ctx* ctx, const Fe* points_host, uint32_t npoints, uint32_t n, Fe* d_pow);
+int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint32_t* d_poly_idx,
+             const uint32_t* d_point_idx, const Fe* d_pow, uint32_t count, Fe* d_out);
+// out[i] = sum_j horner in `v` over the polys listed (first listed = highest power), then out[0] -= sub
+int poly_horner_combine(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_list, uint32_t count,
+                        const Fe& v, const Fe& sub, Fe* out, uint32_t n);
+int poly_kate_division(zg_ctx* ctx, const Fe* a, uint32_t n, const Fe& z, Fe* q);
+int poly_l_cosets_init(zg_ctx* ctx, Fe* l0, Fe* llast, Fe* lblind, uint32_t n, uint32_t bf);
+int poly_lactive(zg_ctx* ctx, Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en);
+
+// from ntt.hip
+int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
+                  const Fe* divisor);
+int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
+                          size_t batch, uint32_t k, uint32_t ext_k);
+int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len, Fe* d_out);
+// from msm.hip
+int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch, size_t n,
+                  XYZZ* d_out);
+int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t window_bits, zg_bases** out);
+void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
+
+}  // namespace zg

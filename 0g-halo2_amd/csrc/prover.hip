@@ -1,0 +1,809 @@
+// create_proof for one circuit instance on one MI355X -- replaces
+// halo2_proofs::plonk::create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC, _, _, EvmTranscript, _>
+// as Wnn::proof calls it (/root/reference/src/wnn.rs:232-262; upstream v2023_04_20 src/plonk/prover.rs).
+//
+// Everything between "advice columns assigned" and "proof bytes" stays in HBM: columns, coefficient
+// forms, extended cosets, lookup/permutation products, h(X).  The host only sees what the Fiat-Shamir
+// transcript needs -- commitments (one 128-B XYZZ point each), evaluations (32 B each) -- plus, for
+// now, the compressed lookup columns that lookup::prover::permute_expression_pair sorts (a host
+// std::sort in this round; SURVEY.md 8f item 2 moves it to the device).  Work that does not depend
+// on the next challenge (iNTTs, coset NTTs) is queued behind the commitment MSM so that it runs while
+// the host hashes.
+#include <algorithm>
+#include <memory>
+#include <thread>
+
+#include "poly.h"
+#include "transcript.h"
+
+namespace zg {
+
+// ------------------------------------------------------------------ Keccak-256 (original padding)
+static inline uint64_t rol64(uint64_t x, unsigned s) { return s ? (x << s) | (x >> (64 - s)) : x; }
+
+static void keccak_f1600(uint64_t a[25]) {
+    static const uint64_t rc[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    // rho offsets indexed [x + 5y]
+    static const unsigned rho[25] = {0,  1,  62, 28, 27, 36, 44, 6,  55, 20, 3,  10, 43,
+                                     25, 39, 41, 45, 15, 21, 8,  18, 2,  61, 56, 14};
+    for (int round = 0; round < 24; round++) {
+        uint64_t c[5], d[5], b[25];
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol64(c[(x + 1) % 5], 1);
+        for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+        // rho + pi: b[y, 2x+3y] = rot(a[x, y])
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol64(a[x + 5 * y], rho[x + 5 * y]);
+        for (int y = 0; y < 5; y++)
+            for (int x = 0; x < 5; x++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= rc[round];
+    }
+}
+
+void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
+    constexpr size_t rate = 136;
+    uint64_t st[25] = {0};
+    auto absorb = [&](const uint8_t* blk) {
+        for (size_t i = 0; i < rate / 8; i++) {
+            uint64_t w = 0;
+            for (int j = 0; j < 8; j++) w |= (uint64_t)blk[8 * i + j] << (8 * j);
+            st[i] ^= w;
+        }
+        keccak_f1600(st);
+    };
+    while (len >= rate) {
+        absorb(data);
+        data += rate;
+        len -= rate;
+    }
+    uint8_t last[rate];
+    memset(last, 0, rate);
+    memcpy(last, data, len);
+    last[len] ^= 0x01;
+    last[rate - 1] ^= 0x80;
+    absorb(last);
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(st[i] >> (8 * j));
+}
+
+// ------------------------------------------------------------------ host sort of permute_expression_pair
+struct Raw {
+    uint64_t l[4];
+};
+static inline bool raw_less(const Raw& a, const Raw& b) {
+    for (int i = 3; i >= 0; i--) {
+        if (a.l[i] != b.l[i]) return a.l[i] < b.l[i];
+    }
+    return false;
+}
+static inline bool raw_eq(const Raw& a, const Raw& b) { return memcmp(a.l, b.l, 32) == 0; }
+
+// lookup::prover::permute_expression_pair on canonical values (without the blinding tail).
+// a: compressed input (usable entries, sorted in place -> a'), t: compressed table (sorted in place,
+// scratch), out: s'.  Returns false when an input value is missing from the table.
+static bool permute_pair_host(Raw* a, Raw* t, Raw* out, size_t usable) {
+    std::sort(a, a + usable, raw_less);
+    std::sort(t, t + usable, raw_less);
+    // unique table values with multiplicities: the BTreeMap<value, count>
+    std::vector<uint32_t> cnt;
+    size_t nu = 0;
+    for (size_t i = 0; i < usable; i++) {
+        if (i == 0 || !raw_eq(t[i], t[nu - 1])) {
+            t[nu++] = t[i];
+            cnt.push_back(1);
+        } else {
+            cnt.back()++;
+        }
+    }
+    std::vector<uint32_t> repeated;
+    repeated.reserve(usable);
+    size_t cur = 0;  // both sequences ascend: a merge pointer replaces the map lookup
+    for (size_t row = 0; row < usable; row++) {
+        if (row == 0 || !raw_eq(a[row], a[row - 1])) {
+            out[row] = a[row];
+            while (cur < nu && raw_less(t[cur], a[row])) cur++;
+            if (cur == nu || !raw_eq(t[cur], a[row]) || cnt[cur] == 0) return false;
+            cnt[cur]--;
+        } else {
+            repeated.push_back((uint32_t)row);
+        }
+    }
+    for (size_t u = 0; u < nu; u++)
+        for (uint32_t c = 0; c < cnt[u]; c++) {
+            if (repeated.empty()) return false;
+            out[repeated.back()] = t[u];
+            repeated.pop_back();
+        }
+    return repeated.empty();
+}
+
+}  // namespace zg
+
+using namespace zg;
+
+// ------------------------------------------------------------------ prover object
+struct zg_prover {
+    zg_ctx* ctx = nullptr;
+    uint32_t k = 0, ext_k = 0, cs_degree = 0, bf = 0, qpd = 0;
+    uint32_t n = 0, en = 0, usable = 0;
+    uint32_t F = 0, A = 0, I = 0, P = 0, NL = 0, sets = 0, chunk = 0;
+    std::vector<zg_query> advice_queries, fixed_queries;
+    DevCircuit dc{};
+    std::vector<void*> owned;  // device allocations freed at destroy
+    zg_bases *g = nullptr, *gl = nullptr;
+    Fe vk_repr{};
+    Fe omega{}, omega_inv{}, ifft_div{};
+    // pk-derived, resident
+    Fe *fixed_val = nullptr, *sigma_val = nullptr, *fixed_cos = nullptr, *sigma_cos = nullptr;
+    Fe *l0 = nullptr, *llast = nullptr, *lactive = nullptr, *t_eval = nullptr, *omega_tw = nullptr, *ext_tw = nullptr;
+    // coefficient-form slab [n_polys][n]
+    Fe* polys = nullptr;
+    uint32_t n_polys = 0;
+    uint32_t ix_fixed = 0, ix_sigma = 0, ix_adv = 0, ix_inst = 0, ix_pz = 0, ix_lz = 0, ix_perm = 0, ix_random = 0,
+             ix_hpiece = 0, ix_hpoly = 0;
+    // per-proof buffers
+    Fe *adv_val = nullptr, *inst_val = nullptr, *adv_cos = nullptr, *inst_cos = nullptr, *pz_cos = nullptr,
+       *lz_cos = nullptr, *perm_cos = nullptr;
+    Fe *cin = nullptr, *ctab = nullptr, *perm = nullptr /* [2NL][n]: a'_l, s'_l */, *zs = nullptr /* [sets+NL][n] */;
+    Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *h = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr,
+       *raw = nullptr;
+    Fe *pin_cos_c = nullptr, *ptab_cos_c = nullptr, *pin_c = nullptr, *ptab_c = nullptr;
+    XYZZ* xyzz = nullptr;
+    uint32_t* d_idx = nullptr;
+    const Fe** d_z0 = nullptr;
+    hipEvent_t ev = nullptr;
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+    bool have_last = false;
+};
+
+namespace {
+
+template <class T>
+int dalloc(zg_prover* p, T** out, size_t count) {
+    void* q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        set_error("zg_prover: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return ZG_ERR_OOM;
+    }
+    p->owned.push_back(q);
+    *out = reinterpret_cast<T*>(q);
+    return ZG_OK;
+}
+
+inline Fe to_fe(const zg_fr* s) {
+    Fe r;
+    memcpy(&r, s, 32);
+    return r;
+}
+
+Fe rotate_omega(const zg_prover* p, const Fe& x, int32_t rot) {
+    Fe w = rot >= 0 ? Fr::pow_u64(p->omega, (uint64_t)rot) : Fr::pow_u64(p->omega_inv, (uint64_t)(-(int64_t)rot));
+    return Fr::mul(x, w);
+}
+
+// D2H of `count` XYZZ results behind the work already queued; returns after ONLY that copy is done
+int fetch_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
+    zg_ctx* ctx = p->ctx;
+    ZG_HIP(hipMemcpyAsync(p->pinned, p->xyzz, count * sizeof(XYZZ), hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(hipEventRecord(p->ev, ctx->stream));
+    return ZG_OK;
+}
+int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
+    ZG_HIP(hipEventSynchronize(p->ev));
+    out.resize(count);
+    xyzz_batch_normalise((const XYZZ*)p->pinned, count, reinterpret_cast<zg_g1*>(out.data()));
+    return ZG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void zg_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) { keccak256(data, len, out); }
+
+size_t zg_prover_proof_size(const zg_prover* p) {
+    if (!p) return 0;
+    size_t points = p->A + 2 * p->NL + p->sets + p->NL + 1 + p->qpd;
+    size_t scalars = p->advice_queries.size() + p->fixed_queries.size() + 1 + p->P + (p->sets ? 3 * p->sets - 1 : 0) +
+                     5 * p->NL;
+    size_t max_open = 2 + p->advice_queries.size() + p->fixed_queries.size();
+    return 64 * (points + max_open) + 32 * scalars;
+}
+
+void zg_prover_destroy(zg_prover* p) {
+    if (!p) return;
+    (void)hipSetDevice(p->ctx->device);
+    (void)hipStreamSynchronize(p->ctx->stream);
+    for (void* q : p->owned) (void)hipFree(q);
+    if (p->g) zg_bases_free(p->g);
+    if (p->gl) zg_bases_free(p->gl);
+    if (p->ev) (void)hipEventDestroy(p->ev);
+    if (p->pinned) (void)hipHostFree(p->pinned);
+    delete p;
+}
+
+int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_values, const zg_fr* sigma_values,
+                     const zg_g1_affine* g, const zg_g1_affine* g_lagrange, const zg_fr* vk_repr, zg_prover** out) {
+    ZG_REQUIRE(ctx && cs && g && g_lagrange && vk_repr && out, ZG_ERR_INVALID_ARG, "zg_prover_create: null argument");
+    ZG_REQUIRE(cs->n_fixed == 0 || fixed_values, ZG_ERR_INVALID_ARG, "zg_prover_create: fixed_values is null");
+    ZG_REQUIRE(cs->n_perm_columns == 0 || sigma_values, ZG_ERR_INVALID_ARG, "zg_prover_create: sigma_values is null");
+    ZG_REQUIRE(cs->cs_degree >= 3 && cs->cs_degree <= 9, ZG_ERR_UNSUPPORTED, "zg_prover_create: cs_degree %u", cs->cs_degree);
+    ZG_REQUIRE(cs->k >= 4, ZG_ERR_UNSUPPORTED, "zg_prover_create: k=%u < 4", cs->k);
+    ZG_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<zg_prover, void (*)(zg_prover*)> guard(new zg_prover(), zg_prover_destroy);
+    zg_prover* p = guard.get();
+    p->ctx = ctx;
+    p->k = cs->k;
+    p->n = 1u << cs->k;
+    p->cs_degree = cs->cs_degree;
+    p->bf = cs->blinding_factors;
+    p->qpd = cs->cs_degree - 1;
+    p->ext_k = cs->k;
+    while ((1ull << p->ext_k) < (uint64_t)p->n * p->qpd) p->ext_k++;
+    ZG_REQUIRE(p->ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_prover_create: extended domain 2^%u not built", p->ext_k);
+    p->en = 1u << p->ext_k;
+    ZG_REQUIRE(p->n > p->bf + 2, ZG_ERR_INVALID_ARG, "zg_prover_create: too few rows");
+    p->usable = p->n - (p->bf + 1);
+    p->F = cs->n_fixed; p->A = cs->n_advice; p->I = cs->n_instance; p->P = cs->n_perm_columns; p->NL = cs->n_lookups;
+    p->chunk = cs->cs_degree - 2;
+    p->sets = p->P ? (p->P + p->chunk - 1) / p->chunk : 0;
+    p->advice_queries.assign(cs->advice_queries, cs->advice_queries + cs->n_advice_queries);
+    p->fixed_queries.assign(cs->fixed_queries, cs->fixed_queries + cs->n_fixed_queries);
+    p->vk_repr = to_fe(vk_repr);
+    p->omega = host_domain_omega(p->k);
+    p->omega_inv = Fr::inv(p->omega);
+    p->ifft_div = Fr::inv(Fr::from_u64(p->n));
+    const uint32_t n = p->n, en = p->en;
+    hipStream_t st = ctx->stream;
+    ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
+
+    // ---- validate and upload the circuit tables
+    for (uint32_t q = 0; q < cs->n_queries; q++) {
+        const zg_query& qq = cs->queries[q];
+        uint32_t lim = qq.kind == ZG_FIXED ? p->F : qq.kind == ZG_ADVICE ? p->A : qq.kind == ZG_INSTANCE ? p->I : 0;
+        ZG_REQUIRE(qq.column < lim, ZG_ERR_INVALID_ARG, "zg_prover_create: query %u names column %u of kind %u", q,
+                   qq.column, qq.kind);
+    }
+    std::vector<DMono> monos(cs->n_monomials);
+    Fe one = Fr::one();
+    for (uint32_t m = 0; m < cs->n_monomials; m++) {
+        const zg_monomial& s = cs->monomials[m];
+        ZG_REQUIRE(s.n_factors <= ZG_MAX_FACTORS, ZG_ERR_INVALID_ARG, "zg_prover_create: monomial %u has %u factors", m, s.n_factors);
+        DMono d;
+        memset(&d, 0, sizeof(d));
+        memcpy(&d.coeff, &s.coeff, 32);
+        d.n_factors = s.n_factors;
+        d.coeff_is_one = fe_eq(d.coeff, one) ? 1 : 0;
+        for (uint32_t f = 0; f < s.n_factors; f++) {
+            ZG_REQUIRE(s.factors[f] < cs->n_queries, ZG_ERR_INVALID_ARG, "zg_prover_create: monomial %u factor out of range", m);
+            d.factors[f] = s.factors[f];
+        }
+        monos[m] = d;
+    }
+    auto poly_ok = [&](const zg_poly& q) { return (uint64_t)q.first + q.count <= cs->n_monomials; };
+    std::vector<DLookup> lks(cs->n_lookups);
+    for (uint32_t l = 0; l < cs->n_lookups; l++) {
+        const zg_lookup& s = cs->lookups[l];
+        ZG_REQUIRE(s.width >= 1 && s.width <= ZG_MAX_LOOKUP_WIDTH, ZG_ERR_INVALID_ARG, "zg_prover_create: lookup %u width %u", l, s.width);
+        lks[l].width = s.width;
+        for (uint32_t e = 0; e < s.width; e++) {
+            ZG_REQUIRE(poly_ok(s.inputs[e]) && poly_ok(s.tables[e]), ZG_ERR_INVALID_ARG, "zg_prover_create: lookup %u polynomial out of range", l);
+            lks[l].inputs[e] = s.inputs[e];
+            lks[l].tables[e] = s.tables[e];
+        }
+    }
+    for (uint32_t gi = 0; gi < cs->n_gates; gi++)
+        ZG_REQUIRE(poly_ok(cs->gates[gi]), ZG_ERR_INVALID_ARG, "zg_prover_create: gate %u out of range", gi);
+    for (uint32_t c = 0; c < cs->n_perm_columns; c++) {
+        const zg_query& qq = cs->perm_columns[c];
+        uint32_t lim = qq.kind == ZG_FIXED ? p->F : qq.kind == ZG_ADVICE ? p->A : qq.kind == ZG_INSTANCE ? p->I : 0;
+        ZG_REQUIRE(qq.column < lim, ZG_ERR_INVALID_ARG, "zg_prover_create: permutation column %u out of range", c);
+    }
+    zg_query* d_q; DMono* d_m; zg_poly* d_g; DLookup* d_l; zg_query* d_pc;
+    ZG_TRY(dalloc(p, &d_q, cs->n_queries));
+    ZG_TRY(dalloc(p, &d_m, cs->n_monomials));
+    ZG_TRY(dalloc(p, &d_g, cs->n_gates));
+    ZG_TRY(dalloc(p, &d_l, cs->n_lookups));
+    ZG_TRY(dalloc(p, &d_pc, cs->n_perm_columns));
+    if (cs->n_queries) ZG_HIP(hipMemcpyAsync(d_q, cs->queries, cs->n_queries * sizeof(zg_query), hipMemcpyHostToDevice, st));
+    if (cs->n_monomials) ZG_HIP(hipMemcpyAsync(d_m, monos.data(), monos.size() * sizeof(DMono), hipMemcpyHostToDevice, st));
+    if (cs->n_gates) ZG_HIP(hipMemcpyAsync(d_g, cs->gates, cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice, st));
+    if (cs->n_lookups) ZG_HIP(hipMemcpyAsync(d_l, lks.data(), lks.size() * sizeof(DLookup), hipMemcpyHostToDevice, st));
+    if (cs->n_perm_columns) ZG_HIP(hipMemcpyAsync(d_pc, cs->perm_columns, cs->n_perm_columns * sizeof(zg_query), hipMemcpyHostToDevice, st));
+    ZG_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope
+    p->dc.queries = d_q; p->dc.monos = d_m; p->dc.gates = d_g; p->dc.lookups = d_l; p->dc.perm_cols = d_pc;
+    p->dc.n_gates = cs->n_gates; p->dc.n_lookups = cs->n_lookups; p->dc.n_perm = p->P; p->dc.chunk = p->chunk;
+    p->dc.n_sets = p->sets;
+
+    // ---- SRS
+    {
+        WsScope ws(ctx);
+        Affine* d = ws.get<Affine>(n);
+        if (!d) return ZG_ERR_OOM;
+        ZG_HIP(hipMemcpyAsync(d, g, (size_t)n * sizeof(Affine), hipMemcpyHostToDevice, st));
+        ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->g));
+        ZG_HIP(hipMemcpyAsync(d, g_lagrange, (size_t)n * sizeof(Affine), hipMemcpyHostToDevice, st));
+        ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->gl));
+    }
+
+    // ---- slabs
+    const uint32_t F = p->F, A = p->A, I = p->I, P = p->P, NL = p->NL, S = p->sets, Q = p->qpd;
+    p->ix_fixed = 0; p->ix_sigma = F; p->ix_adv = F + P; p->ix_inst = p->ix_adv + A; p->ix_pz = p->ix_inst + I;
+    p->ix_lz = p->ix_pz + S; p->ix_perm = p->ix_lz + NL; p->ix_random = p->ix_perm + 2 * NL;
+    p->ix_hpiece = p->ix_random + 1; p->ix_hpoly = p->ix_hpiece + Q;
+    p->n_polys = p->ix_hpoly + 1;
+    ZG_TRY(dalloc(p, &p->polys, (size_t)p->n_polys * n));
+    ZG_TRY(dalloc(p, &p->fixed_val, (size_t)F * n));
+    ZG_TRY(dalloc(p, &p->sigma_val, (size_t)P * n));
+    ZG_TRY(dalloc(p, &p->fixed_cos, (size_t)F * en));
+    ZG_TRY(dalloc(p, &p->sigma_cos, (size_t)P * en));
+    ZG_TRY(dalloc(p, &p->l0, (size_t)en));
+    ZG_TRY(dalloc(p, &p->llast, (size_t)en));
+    ZG_TRY(dalloc(p, &p->lactive, (size_t)en));
+    ZG_TRY(dalloc(p, &p->adv_val, (size_t)A * n));
+    ZG_TRY(dalloc(p, &p->inst_val, (size_t)I * n));
+    ZG_TRY(dalloc(p, &p->adv_cos, (size_t)A * en));
+    ZG_TRY(dalloc(p, &p->inst_cos, (size_t)I * en));
+    ZG_TRY(dalloc(p, &p->pz_cos, (size_t)S * en));
+    ZG_TRY(dalloc(p, &p->lz_cos, (size_t)NL * en));
+    ZG_TRY(dalloc(p, &p->perm_cos, (size_t)2 * NL * en));
+    ZG_TRY(dalloc(p, &p->pin_cos_c, (size_t)NL * en));
+    ZG_TRY(dalloc(p, &p->ptab_cos_c, (size_t)NL * en));
+    ZG_TRY(dalloc(p, &p->pin_c, (size_t)NL * n));
+    ZG_TRY(dalloc(p, &p->ptab_c, (size_t)NL * n));
+    ZG_TRY(dalloc(p, &p->cin, (size_t)NL * n));
+    ZG_TRY(dalloc(p, &p->ctab, (size_t)NL * n));
+    ZG_TRY(dalloc(p, &p->perm, (size_t)2 * NL * n));
+    ZG_TRY(dalloc(p, &p->zs, (size_t)(S + NL) * n));
+    const uint32_t mb = std::max(S, NL);
+    ZG_TRY(dalloc(p, &p->num, (size_t)mb * n));
+    ZG_TRY(dalloc(p, &p->den, (size_t)mb * n));
+    ZG_TRY(dalloc(p, &p->tmp, (size_t)mb * n));
+    ZG_TRY(dalloc(p, &p->h, (size_t)en));
+    ZG_TRY(dalloc(p, &p->raw, (size_t)2 * NL * n));
+    const uint32_t max_points = 4 + (uint32_t)(p->advice_queries.size() + p->fixed_queries.size());
+    ZG_TRY(dalloc(p, &p->pw, (size_t)max_points * n + max_points));
+    const uint32_t max_evals = (uint32_t)(p->advice_queries.size() + p->fixed_queries.size()) + P + 3 * S + 5 * NL + 4;
+    ZG_TRY(dalloc(p, &p->evals, max_evals));
+    ZG_TRY(dalloc(p, &p->wpoly, (size_t)2 * max_points * n));
+    ZG_TRY(dalloc(p, &p->xyzz, std::max<size_t>(std::max<size_t>(A, 2 * NL), std::max<size_t>(S + NL + 1, std::max<size_t>(Q, max_points)))));
+    ZG_TRY(dalloc(p, &p->d_idx, (size_t)4 * max_evals + 64));
+    ZG_TRY(dalloc(p, &p->d_z0, mb + 1));
+    p->pinned_cap = std::max<size_t>((size_t)4 * NL * n * 32, 1u << 20);
+    ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocDefault));
+
+    // ---- keygen_pk's derived data: fixed / sigma polys + cosets, l_0 / l_last / l_active_row
+    if (F) {
+        ZG_HIP(hipMemcpyAsync(p->fixed_val, fixed_values, (size_t)F * n * 32, hipMemcpyHostToDevice, st));
+        Fe* fp = p->polys + (size_t)p->ix_fixed * n;
+        ZG_HIP(hipMemcpyAsync(fp, p->fixed_val, (size_t)F * n * 32, hipMemcpyDeviceToDevice, st));
+        ZG_TRY(ntt_batch_dev(ctx, fp, n, F, p->k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(ctx, fp, n, p->fixed_cos, en, F, p->k, p->ext_k));
+    }
+    if (P) {
+        ZG_HIP(hipMemcpyAsync(p->sigma_val, sigma_values, (size_t)P * n * 32, hipMemcpyHostToDevice, st));
+        Fe* sp = p->polys + (size_t)p->ix_sigma * n;
+        ZG_HIP(hipMemcpyAsync(sp, p->sigma_val, (size_t)P * n * 32, hipMemcpyDeviceToDevice, st));
+        ZG_TRY(ntt_batch_dev(ctx, sp, n, P, p->k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(ctx, sp, n, p->sigma_cos, en, P, p->k, p->ext_k));
+    }
+    {
+        WsScope ws(ctx);
+        Fe* t3 = ws.get<Fe>((size_t)3 * n);
+        Fe* lblind = ws.get<Fe>(en);
+        if (ws.failed) return ZG_ERR_OOM;
+        ZG_TRY(poly_l_cosets_init(ctx, t3, t3 + n, t3 + 2 * n, n, p->bf));
+        ZG_TRY(ntt_batch_dev(ctx, t3, n, 3, p->k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(ctx, t3, n, p->l0, en, 1, p->k, p->ext_k));
+        ZG_TRY(coeff_to_extended_dev(ctx, t3 + n, n, p->llast, en, 1, p->k, p->ext_k));
+        ZG_TRY(coeff_to_extended_dev(ctx, t3 + 2 * n, n, lblind, en, 1, p->k, p->ext_k));
+        ZG_TRY(poly_lactive(ctx, p->lactive, p->llast, lblind, en));
+        ZG_HIP(hipStreamSynchronize(st));
+    }
+    // t_evaluations of EvaluationDomain: ((zeta * ext_omega^i)^n - 1)^-1, one period
+    {
+        uint32_t t_len = 1u << (p->ext_k - p->k);
+        std::vector<Fe> te(t_len);
+        Fe ext_omega = host_domain_omega(p->ext_k);
+        Fe cur = Fr::pow_u64(fr_zeta(), n), step = Fr::pow_u64(ext_omega, n);
+        for (uint32_t i = 0; i < t_len; i++) {
+            te[i] = Fr::inv(Fr::sub(cur, Fr::one()));
+            cur = Fr::mul(cur, step);
+        }
+        ZG_TRY(dalloc(p, &p->t_eval, t_len));
+        ZG_HIP(hipMemcpy(p->t_eval, te.data(), t_len * sizeof(Fe), hipMemcpyHostToDevice));
+        ZG_TRY(get_twiddles(ctx, p->k, p->omega, &p->omega_tw));
+        ZG_TRY(get_twiddles(ctx, p->ext_k, ext_omega, &p->ext_tw));
+    }
+    ZG_HIP(hipStreamSynchronize(st));
+    *out = guard.release();
+    return ZG_OK;
+}
+
+int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, size_t instance_len, uint64_t seed,
+                        uint8_t* proof, size_t proof_cap, size_t* proof_len) {
+    ZG_REQUIRE(p && proof && proof_len && (d_advice || p->A == 0), ZG_ERR_INVALID_ARG, "zg_prover_prove: null argument");
+    ZG_REQUIRE(p->I == 0 || instance || instance_len == 0, ZG_ERR_INVALID_ARG, "zg_prover_prove: instance is null");
+    ZG_REQUIRE(instance_len <= p->usable, ZG_ERR_INVALID_ARG, "zg_prover_prove: instance too large (Error::InstanceTooLarge)");
+    zg_ctx* ctx = p->ctx;
+    ZG_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t n = p->n, en = p->en, k = p->k, ek = p->ext_k, bf = p->bf, usable = p->usable;
+    const uint32_t F = p->F, A = p->A, I = p->I, P = p->P, NL = p->NL, S = p->sets, Q = p->qpd;
+    (void)F;
+    Fe* polys = p->polys;
+    auto poly_at = [&](uint32_t ix) { return polys + (size_t)ix * n; };
+    EvmTranscript tr;
+    std::vector<Jac> pts;
+    p->have_last = false;
+
+    // ---- vk + instance values into the transcript; instance polynomial
+    tr.common_scalar(p->vk_repr);
+    if (I) {
+        ZG_HIP(hipMemsetAsync(p->inst_val, 0, (size_t)I * n * 32, st));
+        for (uint32_t c = 0; c < I; c++) {
+            for (size_t i = 0; i < instance_len; i++) tr.common_scalar(to_fe(&instance[c * instance_len + i]));
+            if (instance_len)
+                ZG_HIP(hipMemcpyAsync(p->inst_val + (size_t)c * n, instance + c * instance_len, instance_len * 32,
+                                      hipMemcpyHostToDevice, st));
+        }
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_inst), p->inst_val, (size_t)I * n * 32, hipMemcpyDeviceToDevice, st));
+        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_inst), n, p->inst_cos, en, I, k, ek));
+    }
+
+    // ---- advice: blind, commit (Lagrange basis); coefficient + coset forms queued behind the MSM
+    Fe* adv = reinterpret_cast<Fe*>(d_advice);
+    if (A) {
+        ZG_TRY(poly_blind_rows(ctx, adv, n, A, usable, bf + 1, seed, TAG_ADVICE_BLIND));
+        ZG_TRY(msm_batch_dev(ctx, p->gl, adv, n, A, n, p->xyzz));
+        ZG_TRY(fetch_points(p, A, pts));
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_adv), adv, (size_t)A * n * 32, hipMemcpyDeviceToDevice, st));
+        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_adv), n, p->adv_cos, en, A, k, ek));
+        ZG_TRY(wait_points(p, A, pts));
+        for (auto& q : pts) tr.write_point(q);
+    }
+    const Fe theta = tr.squeeze();
+
+    Cols base_cols;
+    base_cols.fixed = p->fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
+    base_cols.log_size = k; base_cols.rot_scale = 1;
+
+    // ---- lookups: commit_permuted
+    if (NL) {
+        ZG_TRY(poly_lookup_compress(ctx, p->dc, base_cols, theta, p->cin, p->ctab, n));
+        ZG_TRY(poly_to_raw(ctx, p->cin, p->raw, (size_t)NL * n));
+        ZG_TRY(poly_to_raw(ctx, p->ctab, p->raw + (size_t)NL * n, (size_t)NL * n));
+        Raw* host = reinterpret_cast<Raw*>(p->pinned);  // [a_0..a_NL-1][t_0..t_NL-1][out s'_0..]  (n each)
+        ZG_HIP(hipMemcpyAsync(host, p->raw, (size_t)2 * NL * n * 32, hipMemcpyDeviceToHost, st));
+        ZG_HIP(hipStreamSynchronize(st));
+        Raw* outbuf = host + (size_t)2 * NL * n;
+        std::vector<int> okv(NL, 1);
+        std::vector<std::thread> th;
+        for (uint32_t l = 0; l < NL; l++)
+            th.emplace_back([&, l]() {
+                okv[l] = permute_pair_host(host + (size_t)l * n, host + (size_t)(NL + l) * n, outbuf + (size_t)l * n, usable) ? 1 : 0;
+            });
+        for (auto& t : th) t.join();
+        for (uint32_t l = 0; l < NL; l++)
+            if (!okv[l]) {
+                set_error("zg_prover_prove: lookup %u has an input outside its table (ConstraintSystemFailure)", l);
+                return ZG_ERR_CONSTRAINT;
+            }
+        // back to the device: perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form), then the blinding tail
+        for (uint32_t l = 0; l < NL; l++) {
+            ZG_HIP(hipMemcpyAsync(p->raw + (size_t)(2 * l) * n, host + (size_t)l * n, (size_t)usable * 32, hipMemcpyHostToDevice, st));
+            ZG_HIP(hipMemcpyAsync(p->raw + (size_t)(2 * l + 1) * n, outbuf + (size_t)l * n, (size_t)usable * 32, hipMemcpyHostToDevice, st));
+        }
+        ZG_TRY(poly_from_raw(ctx, p->raw, p->perm, (size_t)2 * NL * n));
+        // blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j
+        ZG_TRY(poly_blind_rows(ctx, p->perm, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_INPUT));
+        ZG_TRY(poly_blind_rows(ctx, p->perm + n, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_TABLE));
+        ZG_TRY(msm_batch_dev(ctx, p->gl, p->perm, n, 2 * NL, n, p->xyzz));
+        ZG_TRY(fetch_points(p, 2 * NL, pts));
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_perm), p->perm, (size_t)2 * NL * n * 32, hipMemcpyDeviceToDevice, st));
+        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_perm), n, p->perm_cos, en, 2 * NL, k, ek));
+        ZG_TRY(wait_points(p, 2 * NL, pts));
+        for (auto& q : pts) tr.write_point(q);
+    }
+    const Fe beta = tr.squeeze();
+    const Fe gamma = tr.squeeze();
+
+    // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
+    Fe* pz = p->zs;
+    Fe* lz = p->zs + (size_t)S * n;
+    if (S) {
+        ZG_TRY(poly_perm_terms(ctx, p->dc, base_cols, p->sigma_val, p->omega_tw, beta, gamma, p->num, p->den, n));
+        std::vector<const Fe*> z0(S, nullptr);
+        for (uint32_t s = 1; s < S; s++) z0[s] = pz + (size_t)(s - 1) * n + (n - bf - 1);
+        ZG_HIP(hipMemcpyAsync(p->d_z0, z0.data(), S * sizeof(Fe*), hipMemcpyHostToDevice, st));
+        for (uint32_t s = 0; s < S; s++)
+            ZG_TRY(poly_grand_product(ctx, p->num + (size_t)s * n, p->den + (size_t)s * n, p->d_z0 + s, pz + (size_t)s * n,
+                                      p->tmp + (size_t)s * n, n, 1));
+        ZG_HIP(hipStreamSynchronize(st));  // z0 (host vector) consumed
+        ZG_TRY(poly_blind_rows(ctx, pz, n, S, n - bf, bf, seed, TAG_PERM_Z));
+    }
+    if (NL) {
+        // de-interleave views of a' / s' for the product terms
+        for (uint32_t l = 0; l < NL; l++)
+            ZG_TRY(poly_lookup_terms(ctx, p->cin + (size_t)l * n, p->ctab + (size_t)l * n, p->perm + (size_t)(2 * l) * n,
+                                     p->perm + (size_t)(2 * l + 1) * n, beta, gamma, p->num + (size_t)l * n,
+                                     p->den + (size_t)l * n, n, 1));
+        ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, lz, p->tmp, n, NL));
+        ZG_TRY(poly_blind_rows(ctx, lz, n, NL, n - bf, bf, seed, TAG_LOOKUP_Z));
+    }
+    if (S + NL) ZG_TRY(msm_batch_dev(ctx, p->gl, p->zs, n, S + NL, n, p->xyzz));
+    // vanishing::Argument::commit: random polynomial (coefficient basis)
+    ZG_TRY(poly_random(ctx, poly_at(p->ix_random), n, seed, TAG_RANDOM_POLY));
+    ZG_TRY(msm_batch_dev(ctx, p->g, poly_at(p->ix_random), n, 1, n, p->xyzz + (S + NL)));
+    ZG_TRY(fetch_points(p, S + NL + 1, pts));
+    if (S + NL) {
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_pz), p->zs, (size_t)(S + NL) * n * 32, hipMemcpyDeviceToDevice, st));
+        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
+        if (S) ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_pz), n, p->pz_cos, en, S, k, ek));
+        if (NL) ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_lz), n, p->lz_cos, en, NL, k, ek));
+    }
+    ZG_TRY(wait_points(p, S + NL + 1, pts));
+    for (auto& q : pts) tr.write_point(q);
+    const Fe y = tr.squeeze();
+
+    // ---- evaluate_h (+ division by X^n - 1), back to coefficients, h pieces
+    {
+        EvalHArgs a;
+        memset(&a, 0, sizeof(a));
+        a.c = p->dc;
+        a.cols.fixed = p->fixed_cos; a.cols.advice = p->adv_cos; a.cols.instance = p->inst_cos;
+        a.cols.log_size = ek; a.cols.rot_scale = (int32_t)(en / n);
+        a.sigma_cos = p->sigma_cos; a.pz_cos = p->pz_cos; a.lz_cos = p->lz_cos;
+        // perm_cos is interleaved [2l] = a', [2l+1] = s': the kernel wants [l] strides -> separate views
+        a.pin_cos = p->pin_cos_c; a.ptab_cos = p->ptab_cos_c;
+        for (uint32_t l = 0; l < NL; l++) {
+            ZG_HIP(hipMemcpyAsync(p->pin_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, st));
+            ZG_HIP(hipMemcpyAsync(p->ptab_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l + 1) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, st));
+        }
+        a.l0 = p->l0; a.llast = p->llast; a.lactive = p->lactive;
+        a.ext_tw = p->ext_tw; a.t_eval = p->t_eval; a.t_mask = (1u << (ek - k)) - 1;
+        a.last_rot = -(int32_t)(bf + 1);
+        a.y = y; a.beta = beta; a.gamma = gamma; a.theta = theta;
+        a.delta_start = Fr::mul(beta, fr_zeta()); a.delta = fr_delta();
+        a.h = p->h;
+        ZG_TRY(poly_evaluate_h(ctx, a, en));
+    }
+    p->have_last = true;
+    ZG_TRY(extended_to_coeff_dev(ctx, p->h, k, ek, (size_t)Q * n, poly_at(p->ix_hpiece)));
+    ZG_TRY(msm_batch_dev(ctx, p->g, poly_at(p->ix_hpiece), n, Q, n, p->xyzz));
+    ZG_TRY(fetch_points(p, Q, pts));
+    ZG_TRY(wait_points(p, Q, pts));
+    for (auto& q : pts) tr.write_point(q);
+    const Fe x = tr.squeeze();
+    const Fe xn = Fr::pow_u64(x, n);
+
+    // ---- evaluations
+    // distinct opening points, in any order (the powers table is indexed by slot)
+    std::vector<int32_t> rots = {0, 1, -1, -(int32_t)(bf + 1)};
+    auto rot_slot = [&](int32_t r) -> uint32_t {
+        for (size_t i = 0; i < rots.size(); i++)
+            if (rots[i] == r) return (uint32_t)i;
+        rots.push_back(r);
+        return (uint32_t)rots.size() - 1;
+    };
+    struct Q1 { uint32_t poly, slot; };
+    std::vector<Q1> evq;  // evaluations in transcript order, then h_poly at x
+    for (auto& q : p->advice_queries) evq.push_back({p->ix_adv + q.column, rot_slot(q.rotation)});
+    const size_t e_fixed = evq.size();
+    for (auto& q : p->fixed_queries) evq.push_back({p->ix_fixed + q.column, rot_slot(q.rotation)});
+    const size_t e_random = evq.size();
+    evq.push_back({p->ix_random, 0});
+    const size_t e_sigma = evq.size();
+    for (uint32_t c = 0; c < P; c++) evq.push_back({p->ix_sigma + c, 0});
+    const size_t e_pz = evq.size();
+    for (uint32_t s = 0; s < S; s++) {
+        evq.push_back({p->ix_pz + s, 0});
+        evq.push_back({p->ix_pz + s, 1});
+        if (s + 1 < S) evq.push_back({p->ix_pz + s, 3});
+    }
+    const size_t e_lk = evq.size();
+    for (uint32_t l = 0; l < NL; l++) {
+        evq.push_back({p->ix_lz + l, 0});            // z(x)
+        evq.push_back({p->ix_lz + l, 1});            // z(omega x)
+        evq.push_back({p->ix_perm + 2 * l, 0});      // a'(x)
+        evq.push_back({p->ix_perm + 2 * l, 2});      // a'(omega^-1 x)
+        evq.push_back({p->ix_perm + 2 * l + 1, 0});  // s'(x)
+    }
+    const size_t e_written = evq.size();
+    evq.push_back({p->ix_hpoly, 0});
+    const size_t e_h = e_written;
+
+    std::vector<Fe> points(rots.size());
+    for (size_t i = 0; i < rots.size(); i++) points[i] = rotate_omega(p, x, rots[i]);
+    // vanishing.evaluate: h(X) = sum_i xn^i h_i(X)
+    {
+        std::vector<uint32_t> list(Q);
+        for (uint32_t i = 0; i < Q; i++) list[i] = p->ix_hpiece + (Q - 1 - i);
+        ZG_HIP(hipMemcpyAsync(p->d_idx, list.data(), Q * 4, hipMemcpyHostToDevice, st));
+        ZG_TRY(poly_horner_combine(ctx, polys, n, p->d_idx, Q, xn, fe_zero(), poly_at(p->ix_hpoly), n));
+        ZG_HIP(hipStreamSynchronize(st));
+    }
+    ZG_TRY(poly_powers(ctx, points.data(), (uint32_t)points.size(), n, p->pw));
+    std::vector<uint32_t> idx(2 * evq.size());
+    for (size_t i = 0; i < evq.size(); i++) {
+        idx[i] = evq[i].poly;
+        idx[evq.size() + i] = evq[i].slot;
+    }
+    ZG_HIP(hipMemcpyAsync(p->d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
+    ZG_TRY(poly_dot(ctx, polys, n, n, p->d_idx, p->d_idx + evq.size(), p->pw, (uint32_t)evq.size(), p->evals));
+    std::vector<Fe> ev(evq.size());
+    ZG_HIP(hipMemcpyAsync(ev.data(), p->evals, ev.size() * sizeof(Fe), hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    for (size_t i = 0; i < e_written; i++) tr.write_scalar(ev[i]);
+
+    // ---- opening queries in create_proof's order: (poly, point slot, eval)
+    struct OQ { uint32_t poly, slot; Fe eval; };
+    std::vector<OQ> oq;
+    for (size_t i = 0; i < e_fixed; i++) oq.push_back({evq[i].poly, evq[i].slot, ev[i]});
+    {
+        size_t e = e_pz;
+        std::vector<size_t> e_last(S, 0), e_cur(S, 0), e_next(S, 0);
+        for (uint32_t s = 0; s < S; s++) {
+            e_cur[s] = e++;
+            e_next[s] = e++;
+            if (s + 1 < S) e_last[s] = e++;
+        }
+        for (uint32_t s = 0; s < S; s++) {
+            oq.push_back({p->ix_pz + s, 0, ev[e_cur[s]]});
+            oq.push_back({p->ix_pz + s, 1, ev[e_next[s]]});
+        }
+        for (uint32_t s = S; s-- > 0;) {
+            if (s + 1 == S) continue;
+            oq.push_back({p->ix_pz + s, 3, ev[e_last[s]]});
+        }
+    }
+    for (uint32_t l = 0; l < NL; l++) {
+        const Fe* e5 = &ev[e_lk + 5 * l];
+        oq.push_back({p->ix_lz + l, 0, e5[0]});
+        oq.push_back({p->ix_perm + 2 * l, 0, e5[2]});
+        oq.push_back({p->ix_perm + 2 * l + 1, 0, e5[4]});
+        oq.push_back({p->ix_perm + 2 * l, 2, e5[3]});
+        oq.push_back({p->ix_lz + l, 1, e5[1]});
+    }
+    for (size_t i = e_fixed; i < e_random; i++) oq.push_back({evq[i].poly, evq[i].slot, ev[i]});
+    for (uint32_t c = 0; c < P; c++) oq.push_back({p->ix_sigma + c, 0, ev[e_sigma + c]});
+    oq.push_back({p->ix_hpoly, 0, ev[e_h]});
+    oq.push_back({p->ix_random, 0, ev[e_random]});
+
+    // ---- ProverGWC::create_proof
+    const Fe v = tr.squeeze();
+    {
+        std::vector<char> done(oq.size(), 0);
+        uint32_t npts = 0;
+        std::vector<uint32_t> list;
+        for (size_t first = 0; first < oq.size(); first++) {
+            if (done[first]) continue;
+            const uint32_t slot = oq[first].slot;
+            list.clear();
+            Fe eval_batch = fe_zero();
+            for (size_t j = first; j < oq.size(); j++) {
+                if (done[j] || oq[j].slot != slot) continue;
+                done[j] = 1;
+                list.push_back(oq[j].poly);
+                eval_batch = Fr::add(Fr::mul(eval_batch, v), oq[j].eval);
+            }
+            uint32_t* dl = p->d_idx;  // lists are consumed launch by launch
+            ZG_HIP(hipMemcpyAsync(dl, list.data(), list.size() * 4, hipMemcpyHostToDevice, st));
+            Fe* batch = p->wpoly + (size_t)(2 * npts) * n;
+            Fe* wit = p->wpoly + (size_t)(2 * npts + 1) * n;
+            ZG_TRY(poly_horner_combine(ctx, polys, n, dl, (uint32_t)list.size(), v, eval_batch, batch, n));
+            ZG_TRY(poly_kate_division(ctx, batch, n, points[slot], wit));
+            ZG_HIP(hipStreamSynchronize(st));  // list (host vector) consumed before it is rebuilt
+            npts++;
+        }
+        // the witness polynomials sit at odd slots: stride 2n
+        ZG_TRY(msm_batch_dev(ctx, p->g, p->wpoly + n, (size_t)2 * n, npts, n, p->xyzz));
+        ZG_TRY(fetch_points(p, npts, pts));
+        ZG_TRY(wait_points(p, npts, pts));
+        for (auto& q : pts) tr.write_point(q);
+    }
+    ZG_REQUIRE(!tr.failed, ZG_ERR_INVALID_ARG,
+               "zg_prover_prove: a commitment is the identity point; EvmTranscript cannot absorb it");
+    ZG_REQUIRE(tr.stream.size() <= proof_cap, ZG_ERR_INVALID_ARG, "zg_prover_prove: proof buffer too small (%zu > %zu)",
+               tr.stream.size(), proof_cap);
+    memcpy(proof, tr.stream.data(), tr.stream.size());
+    *proof_len = tr.stream.size();
+    return ZG_OK;
+}
+
+int zg_prover_prove(zg_prover* p, const zg_fr* advice, const zg_fr* instance, size_t instance_len, uint64_t seed,
+                    uint8_t* proof, size_t proof_cap, size_t* proof_len) {
+    ZG_REQUIRE(p && (advice || p->A == 0), ZG_ERR_INVALID_ARG, "zg_prover_prove: null argument");
+    ZG_HIP(hipSetDevice(p->ctx->device));
+    if (p->A)
+        ZG_HIP(hipMemcpyAsync(p->adv_val, advice, (size_t)p->A * p->n * 32, hipMemcpyHostToDevice, p->ctx->stream));
+    return zg_prover_prove_dev(p, p->adv_val, instance, instance_len, seed, proof, proof_cap, proof_len);
+}
+
+int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, size_t cap_elems) {
+    ZG_REQUIRE(p && out, ZG_ERR_INVALID_ARG, "zg_prover_fetch: null argument");
+    ZG_REQUIRE(p->have_last, ZG_ERR_INVALID_ARG, "zg_prover_fetch: no proof has been produced yet");
+    const Fe* src = nullptr;
+    size_t count = 0;
+    const size_t n = p->n;
+    switch (what) {
+        case 0: src = p->h; count = p->en; break;
+        case 1: ZG_REQUIRE(index < p->sets, ZG_ERR_INVALID_ARG, "zg_prover_fetch: set %u", index);
+                src = p->zs + (size_t)index * n; count = n; break;
+        case 2: ZG_REQUIRE(index < p->NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
+                src = p->zs + (size_t)(p->sets + index) * n; count = n; break;
+        case 3: ZG_REQUIRE(index < p->NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
+                src = p->perm + (size_t)(2 * index) * n; count = n; break;
+        case 4: ZG_REQUIRE(index < p->NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
+                src = p->perm + (size_t)(2 * index + 1) * n; count = n; break;
+        case 5: src = p->polys + (size_t)p->ix_hpiece * n; count = (size_t)p->qpd * n; break;
+        default: ZG_REQUIRE(false, ZG_ERR_INVALID_ARG, "zg_prover_fetch: unknown item %u", what);
+    }
+    ZG_REQUIRE(cap_elems >= count, ZG_ERR_INVALID_ARG, "zg_prover_fetch: need %zu elements", count);
+    ZG_HIP(hipSetDevice(p->ctx->device));
+    ZG_HIP(hipMemcpy(out, src, count * 32, hipMemcpyDeviceToHost));
+    return ZG_OK;
+}
+
+// ---- stand-alone building blocks (tests) ----
+int zg_grand_product_dev(zg_ctx* ctx, const void* d_num, const void* d_den, const zg_fr* z0, size_t n, void* d_z) {
+    ZG_REQUIRE(ctx && d_num && d_den && d_z && z0, ZG_ERR_INVALID_ARG, "zg_grand_product_dev: null argument");
+    ZG_REQUIRE(n < (1u << 28), ZG_ERR_UNSUPPORTED, "zg_grand_product_dev: n too large");
+    ZG_HIP(hipSetDevice(ctx->device));
+    WsScope ws(ctx);
+    Fe* tmp = ws.get<Fe>(n + 1);
+    const Fe** zp = ws.get<const Fe*>(2);
+    if (ws.failed) return ZG_ERR_OOM;
+    Fe* z0d = tmp + n;
+    ZG_HIP(hipMemcpyAsync(z0d, z0, 32, hipMemcpyHostToDevice, ctx->stream));
+    const Fe* hp[1] = {z0d};
+    ZG_HIP(hipMemcpyAsync(zp, hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
+    ZG_TRY(poly_grand_product(ctx, (const Fe*)d_num, (const Fe*)d_den, zp, (Fe*)d_z, tmp, (uint32_t)n, 1));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+int zg_eval_polys_dev(zg_ctx* ctx, const void* d_polys, size_t stride_elems, size_t n, const uint32_t* poly_index,
+                      const zg_fr* points, size_t count, zg_fr* out) {
+    ZG_REQUIRE(ctx && d_polys && poly_index && points && out, ZG_ERR_INVALID_ARG, "zg_eval_polys_dev: null argument");
+    if (!count) return ZG_OK;
+    ZG_HIP(hipSetDevice(ctx->device));
+    WsScope ws(ctx);
+    // every pair gets its own powers row (callers with shared points should use the prover)
+    Fe* pw = ws.get<Fe>(count * n + count);
+    uint32_t* di = ws.get<uint32_t>(2 * count);
+    Fe* de = ws.get<Fe>(count);
+    if (ws.failed) return ZG_ERR_OOM;
+    std::vector<uint32_t> idx(2 * count);
+    for (size_t i = 0; i < count; i++) {
+        idx[i] = poly_index[i];
+        idx[count + i] = (uint32_t)i;
+    }
+    ZG_TRY(poly_powers(ctx, (const Fe*)points, (uint32_t)count, (uint32_t)n, pw));
+    ZG_HIP(hipMemcpyAsync(di, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    ZG_TRY(poly_dot(ctx, (const Fe*)d_polys, stride_elems, (uint32_t)n, di, di + count, pw, (uint32_t)count, de));
+    ZG_HIP(hipMemcpyAsync(out, de, count * 32, hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    return ZG_OK;
+}
+
+int zg_kate_division_dev(zg_ctx* ctx, const void* d_a, size_t n, const zg_fr* z, void* d_q) {
+    ZG_REQUIRE(ctx && d_a && z && d_q && n >= 1, ZG_ERR_INVALID_ARG, "zg_kate_division_dev: bad argument");
+    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_TRY(poly_kate_division(ctx, (const Fe*)d_a, (uint32_t)n, to_fe(z), (Fe*)d_q));
+    return ZG_OK;
+}
+
+}  // extern "C"

@@ -65,7 +65,9 @@ ABI_SYMBOLS = [
     "zg_ntt", "zg_intt", "zg_ntt_batch", "zg_intt_batch", "zg_ntt_batch_dev", "zg_coeff_to_extended",
     "zg_coeff_to_extended_batch_dev", "zg_extended_to_coeff", "zg_extended_to_coeff_dev",
     "zg_domain_omega", "zg_ctx_profile_enable", "zg_ctx_profile_collect", "zg_params_new",
-    "zg_params_new_dev",
+    "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
+    "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
+    "zg_kate_division_dev", "zg_keccak256",
 ]
 
 
@@ -254,6 +256,23 @@ class Ctx:
         _check(self.lib.zg_ntt_batch_dev(self.h, c_void_p(d_a), c_size_t(stride), c_size_t(batch),
                                          c_uint32(log_n), _ptr(omega), dv))
 
+    # ---- stand-alone prover building blocks (device pointers) ----
+    def grand_product_dev(self, d_num: int, d_den: int, z0: np.ndarray, n: int, d_z: int):
+        _check(self.lib.zg_grand_product_dev(self.h, c_void_p(d_num), c_void_p(d_den), _ptr(_fr(z0)), c_size_t(n),
+                                             c_void_p(d_z)))
+
+    def eval_polys_dev(self, d_polys: int, stride: int, n: int, poly_index, points: np.ndarray) -> np.ndarray:
+        idx = np.ascontiguousarray(poly_index, dtype=np.uint32)
+        points = _fr(points).reshape(-1, 4)
+        out = np.zeros((idx.shape[0], 4), np.uint64)
+        _check(self.lib.zg_eval_polys_dev(self.h, c_void_p(d_polys), c_size_t(stride), c_size_t(n),
+                                          c_void_p(idx.ctypes.data), _ptr(points), c_size_t(idx.shape[0]), _ptr(out)))
+        return out
+
+    def kate_division_dev(self, d_a: int, n: int, z: np.ndarray, d_q: int):
+        _check(self.lib.zg_kate_division_dev(self.h, c_void_p(d_a), c_size_t(n), _ptr(_fr(z)), c_void_p(d_q)))
+        self.sync()
+
     def coeff_to_extended(self, coeffs: np.ndarray, k: int, ext_k: int) -> np.ndarray:
         coeffs = _fr(coeffs).reshape(-1, 4)
         assert coeffs.shape[0] == 1 << k
@@ -278,6 +297,73 @@ class Ctx:
     def extended_to_coeff_dev(self, d_evals: int, k: int, ext_k: int, out_len: int, d_out: int):
         _check(self.lib.zg_extended_to_coeff_dev(self.h, c_void_p(d_evals), c_uint32(k), c_uint32(ext_k),
                                                  c_size_t(out_len), c_void_p(d_out)))
+
+
+def keccak256(data: bytes) -> bytes:
+    out = (ctypes.c_uint8 * 32)()
+    load().zg_keccak256(data, c_size_t(len(data)), out)
+    return bytes(out)
+
+
+class Prover:
+    """zg_prover: create_proof for one circuit (circuit.py CircuitImage) on one GPU."""
+
+    def __init__(self, ctx: Ctx, image, fixed_values: np.ndarray, sigma_values: np.ndarray, g: np.ndarray,
+                 g_lagrange: np.ndarray, vk_repr: np.ndarray):
+        self.ctx = ctx
+        self.image = image
+        lib = ctx.lib
+        lib.zg_prover_proof_size.restype = c_size_t
+        lib.zg_prover_proof_size.argtypes = [c_void_p]
+        lib.zg_prover_destroy.argtypes = [c_void_p]
+        lib.zg_prover_destroy.restype = None
+        fixed_values = np.ascontiguousarray(fixed_values, dtype=np.uint64)
+        sigma_values = np.ascontiguousarray(sigma_values, dtype=np.uint64)
+        g = np.ascontiguousarray(g, dtype=np.uint64)
+        g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64)
+        h = c_void_p()
+        _check(lib.zg_prover_create(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), _ptr(g),
+                                    _ptr(g_lagrange), _ptr(_fr(vk_repr)), ctypes.byref(h)))
+        self.h = h
+        self.n = 1 << image.c.k
+        self.n_advice = image.c.n_advice
+        self.proof_cap = int(lib.zg_prover_proof_size(h))
+
+    def prove(self, advice: np.ndarray, instance: np.ndarray, seed: int) -> bytes:
+        advice = np.ascontiguousarray(advice, dtype=np.uint64)
+        instance = np.ascontiguousarray(instance, dtype=np.uint64)
+        inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0
+        buf = (ctypes.c_uint8 * self.proof_cap)()
+        plen = c_size_t(0)
+        _check(self.ctx.lib.zg_prover_prove(self.h, _ptr(advice), _ptr(instance), c_size_t(inst_len),
+                                            ctypes.c_uint64(seed), buf, c_size_t(self.proof_cap), ctypes.byref(plen)))
+        return bytes(buf[: plen.value])
+
+    def prove_dev(self, d_advice: int, instance: np.ndarray, seed: int) -> bytes:
+        instance = np.ascontiguousarray(instance, dtype=np.uint64)
+        inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0
+        buf = (ctypes.c_uint8 * self.proof_cap)()
+        plen = c_size_t(0)
+        _check(self.ctx.lib.zg_prover_prove_dev(self.h, c_void_p(d_advice), _ptr(instance), c_size_t(inst_len),
+                                                ctypes.c_uint64(seed), buf, c_size_t(self.proof_cap),
+                                                ctypes.byref(plen)))
+        return bytes(buf[: plen.value])
+
+    def fetch(self, what: int, index: int, count: int) -> np.ndarray:
+        out = np.zeros((count, 4), np.uint64)
+        _check(self.ctx.lib.zg_prover_fetch(self.h, c_uint32(what), c_uint32(index), _ptr(out), c_size_t(count)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.zg_prover_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Bases:

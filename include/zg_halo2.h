@@ -231,7 +231,7 @@ int zg_prover_prove_dev(zg_prover *p, void *d_advice, const zg_fr *instance, siz
 /* Upper bound of the proof size in bytes for this circuit. */
 size_t zg_prover_proof_size(const zg_prover *p);
 /* Test hook: copies an intermediate of the LAST proof to the host.  what: 0 = h(X) on the extended
- * coset before division by (X^n - 1) [2^ext_k], 1 = permutation z (index = set) [2^k Lagrange],
+ * coset after the division by (X^n - 1) [2^ext_k], 1 = permutation z (index = set) [2^k Lagrange],
  * 2 = lookup z (index = lookup) [2^k Lagrange], 3 = permuted input a' (index = lookup),
  * 4 = permuted table s' (index = lookup), 5 = h pieces in coefficient form [5 * 2^k]. */
 int zg_prover_fetch(zg_prover *p, uint32_t what, uint32_t index, zg_fr *out, size_t cap_elems);

@@ -280,3 +280,24 @@ def rand_fr(seed: int, tag: int, index: int) -> np.ndarray:
     out = np.zeros(4, np.uint64)
     load().orc_rand_fr(_p(out), c_uint64(seed), c_uint32(tag), c_uint64(index))
     return out
+
+
+def grand_product(num: np.ndarray, den: np.ndarray, z0: np.ndarray) -> np.ndarray:
+    num, den = _c(num, 4).reshape(-1, 4), _c(den, 4).reshape(-1, 4)
+    z = np.zeros_like(num)
+    load().orc_grand_product(_p(z), _p(num), _p(den), _p(_c(z0, 4)), c_size_t(num.shape[0]))
+    return z
+
+
+def eval_poly(coeffs: np.ndarray, x: np.ndarray) -> np.ndarray:
+    coeffs = _c(coeffs, 4).reshape(-1, 4)
+    out = np.zeros(4, np.uint64)
+    load().orc_eval_poly(_p(out), _p(coeffs), c_size_t(coeffs.shape[0]), _p(_c(x, 4)))
+    return out
+
+
+def kate_division(a: np.ndarray, z: np.ndarray) -> np.ndarray:
+    a = _c(a, 4).reshape(-1, 4)
+    q = np.zeros_like(a)  # q[n-1] stays 0
+    load().orc_kate_division(_p(q), _p(a), c_size_t(a.shape[0]), _p(_c(z, 4)))
+    return q

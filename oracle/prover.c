@@ -634,13 +634,12 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
         }
         free(eo_pow);
     }
-    if (trace) {
+    /* ---- vanishing::construct: divide by X^n - 1, back to coefficients, split, commit */
+    orc_divide_by_vanishing(&dom, h);
+    if (trace) { /* h on the extended coset AFTER the division (what the GPU kernel stores) */
         trace->h_ext = (orc_fr *)malloc(en * sizeof(orc_fr));
         memcpy(trace->h_ext, h, en * sizeof(orc_fr));
     }
-
-    /* ---- vanishing::construct: divide by X^n - 1, back to coefficients, split, commit */
-    orc_divide_by_vanishing(&dom, h);
     orc_fr *h_coeff = (orc_fr *)malloc(qpd * n * sizeof(orc_fr));
     orc_extended_to_coeff(&dom, h_coeff, h);
     for (size_t i = 0; i < qpd; i++) {

@@ -52,7 +52,7 @@ typedef struct {
 
 /* Intermediates kept for piecewise parity checks against the GPU path. */
 typedef struct {
-    orc_fr *h_ext;            /* [extended_n] numerator before division by (X^n - 1) */
+    orc_fr *h_ext;            /* [extended_n] h on the coset, after division by (X^n - 1) */
     orc_fr *perm_z;           /* [sets][n]    */
     orc_fr *lookup_z;         /* [lookups][n] */
     orc_fr *permuted_input;   /* [lookups][n] */

@@ -78,3 +78,14 @@ def test_g1_sum_host_helper(zg, orc):
     got = zg.g1_sum(ident)
     assert not got[:4].any() and not got[8:].any()  # (0, 1, 0)
     assert np.array_equal(zg.g1_sum(jac[:0]), got)
+
+
+def test_product_keccak_kat(zg):
+    """EvmTranscript's hash (host code of the product library; no GPU needed)."""
+    assert zg.keccak256(b"").hex() == "c5d2460186f7233c927e7db2dcc703c0e500b653ca82273b7bfad8045d85a470"
+    assert zg.keccak256(b"abc").hex() == "4e03657aea45a94fc7d47ba826c8d667c0d1e6e33a64a036ec44f58fa12d6c45"
+    import orc
+
+    for n in (1, 31, 32, 33, 135, 136, 137, 272, 1000):
+        data = bytes((7 * i + n) & 0xFF for i in range(n))
+        assert zg.keccak256(data) == orc.keccak256(data), n

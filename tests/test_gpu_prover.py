@@ -1,0 +1,106 @@
+"""GPU parity for the rest of create_proof: lookup/permutation grand products, evaluate_h, vanishing,
+evaluations, GWC openings and the Keccak transcript.  The HIP prover (through the C ABI) must produce
+the SAME PROOF BYTES as the oracle restatement for the same circuit, witness, SRS and blinding seed,
+and the oracle's verifier must accept them."""
+import numpy as np
+import pytest
+import torch
+
+from circuits import toy_circuit
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a: np.ndarray) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+
+
+def host(t: torch.Tensor) -> np.ndarray:
+    return t.cpu().numpy().view(np.uint64)
+
+
+def setup(orc, zg, ctx, k, **kw):
+    cs, asg, ilen = toy_circuit(k, **kw)
+    img = cs.to_c()
+    params = orc.params_new(k, 0xABCDEF)
+    vk_repr = orc.fr_from_int(0x1234567)
+    pk = orc.ProvingKey(img, asg.fixed_values(), asg.sigma_values(), params, vk_repr)
+    prover = zg.Prover(ctx, img, asg.fixed_values(), asg.sigma_values(), params.g_np(), params.g_lagrange_np(), vk_repr)
+    return cs, asg, ilen, pk, prover
+
+
+@pytest.mark.parametrize("k,force_degree", [(5, None), (5, 6), (6, 8), (8, 6), (10, None)])
+def test_proof_bytes_match_oracle_and_verify(ctx, zg, orc, k, force_degree):
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, k, force_degree=force_degree)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    for seed in (1, 2):
+        st, want, tr = orc.create_proof(pk, adv, inst, seed, want_trace=True)
+        assert st == 0
+        got = prover.prove(adv, inst, seed)
+        n, en = 1 << k, 1 << cs.extended_k()
+        sets = tr.n_sets
+        # piecewise first, so that a mismatch names the stage
+        for l in range(len(cs.lookups)):
+            assert np.array_equal(prover.fetch(3, l, n), tr.array("permuted_input", (l + 1) * n)[l * n:]), "a'"
+            assert np.array_equal(prover.fetch(4, l, n), tr.array("permuted_table", (l + 1) * n)[l * n:]), "s'"
+            assert np.array_equal(prover.fetch(2, l, n), tr.array("lookup_z", (l + 1) * n)[l * n:]), "lookup z"
+        for s in range(sets):
+            assert np.array_equal(prover.fetch(1, s, n), tr.array("perm_z", (s + 1) * n)[s * n:]), "perm z"
+        assert np.array_equal(prover.fetch(0, 0, en), tr.array("h_ext", en)), "h on the extended coset"
+        qpd = cs.degree() - 1
+        assert np.array_equal(prover.fetch(5, 0, qpd * n), tr.array("h_pieces", qpd * n)), "h pieces"
+        assert got == want, "proof bytes"
+        assert orc.verify_proof(pk, inst, got) == 1
+        orc.trace_free(tr)
+    prover.close()
+
+
+def test_lookup_failure_is_constraint_system_failure(ctx, zg, orc):
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 5)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    bad = adv.copy()
+    bad[1, 2] = orc.fr_from_int(1000)
+    with pytest.raises(zg.ZgError) as e:
+        prover.prove(bad, inst, 1)
+    assert e.value.status == -5
+    assert orc.create_proof(pk, bad, inst, 1)[0] == -5
+    # the prover object stays usable
+    assert prover.prove(adv, inst, 3) == orc.create_proof(pk, adv, inst, 3)[1]
+    prover.close()
+
+
+def test_unsatisfied_witness_still_proves_but_does_not_verify(ctx, zg, orc):
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 5)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    bad = adv.copy()
+    bad[2, 3] = orc.fr_from_int(99)
+    got = prover.prove(bad, inst, 1)
+    assert got == orc.create_proof(pk, bad, inst, 1)[1]
+    assert orc.verify_proof(pk, inst, got) != 1
+    prover.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 1000, 1024, 1025, 1 << 14, (1 << 17) + 3])
+def test_grand_product(ctx, zg, orc, n):
+    num, den = orc.fill_fr(1, n), orc.fill_fr(2, n)
+    if n > 4:
+        den[3] = 0  # BatchInvert leaves zeros alone -> that ratio is zero
+    z0 = orc.fill_fr(3, 1)[0]
+    dn, dd = dev(num), dev(den)
+    dz = torch.empty_like(dn)
+    ctx.grand_product_dev(dn.data_ptr(), dd.data_ptr(), z0, n, dz.data_ptr())
+    assert np.array_equal(host(dz), orc.grand_product(num, den, z0))
+
+
+@pytest.mark.parametrize("n", [1, 7, 1 << 10, 1 << 14])
+def test_eval_polys_and_kate_division(ctx, zg, orc, n):
+    polys = np.stack([orc.fill_fr(10 + i, n) for i in range(3)])
+    pts = orc.fill_fr(99, 4)
+    d = dev(polys)
+    idx = [0, 2, 1, 2]
+    got = ctx.eval_polys_dev(d.data_ptr(), n, n, idx, pts)
+    for j, pi in enumerate(idx):
+        assert np.array_equal(got[j], orc.eval_poly(polys[pi], pts[j]))
+    dq = torch.empty((n, 4), dtype=torch.int64, device="cuda")
+    ctx.kate_division_dev(d.data_ptr(), n, pts[0], dq.data_ptr())
+    assert np.array_equal(host(dq), orc.kate_division(polys[0], pts[0]))
