@@ -1,16 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py -- create_proof hot path of zero_g's WNN circuit on MI355X (BASELINE.json metric).
+"""bench.py -- create_proof of zero_g's WNN circuit shape on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the create_proof operation schedule for
-model_28input_256entry_1hash_1bpi (k = 14, extended domain 2^17): every commitment MSM and every
-NTT of one proof, phase by phase, with a host round trip after each commitment batch exactly where
-the Fiat-Shamir transcript needs the points.  Inputs (SRS tables, witness-shaped columns) are
-resident in HBM before the timed region.
+A "step" is ONE full create_proof (zg_prover_prove_dev): from the assigned advice columns, resident
+in HBM, to the proof bytes -- 30 commitment MSMs, 21 iNTT + 21 coset NTT + 1 extended iNTT, the 4
+lookup arguments (compression, permutation, grand products), the 2-set permutation argument,
+evaluate_h over the 2^17-point extended coset, ~60 polynomial evaluations, the 4 GWC openings and the
+Keccak-256 EvmTranscript, for a circuit of the shape of model_28input_256entry_1hash_1bpi
+(k = 14; 0g-halo2_amd/wnn_shape.py).  The SRS tables, the proving key (fixed /
+sigma polynomials and cosets) and the witness are in HBM before the timed region, as in the
+reference's own bench (benches/bench.rs:30-36 times only `wnn.proof`).
 
     python bench.py --gpus N --steps K --warmup W          (N > 1 via torch.distributed.run)
 
-Prints ONE JSON line (rank 0).  value = proofs/hour over all ranks; N > 1 runs independent proof
-replicas per GPU (weak scaling, no data-path collective: SURVEY.md 8e / DESIGN.md).
+Prints ONE JSON line (rank 0).  value = proofs/hour over all ranks.  N > 1 runs independent proofs
+per GPU (weak scaling, no data-path collective: proofs do not shard below the MSM, and a 2^14-point
+MSM is too small to split -- SURVEY.md 8e / DESIGN.md); the sharded-MSM path is exercised by
+tests/test_multi_gpu.py.
 """
 import argparse
 import json
@@ -24,161 +29,16 @@ sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
 import numpy as np
 import torch
 
+import wnn_shape
 import zg_halo2 as zg
 
 R = zg.FR_MODULUS
 MONT = (1 << 256) % R
+MODEL = {14: "tiny", 15: "small", 17: "large"}
 
 
 def limbs(x):
     return [(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)]
-
-
-def to_i64(a: np.ndarray) -> torch.Tensor:
-    return torch.from_numpy(a.view(np.int64))
-
-
-def uniform_fr(gen: np.random.Generator, shape) -> np.ndarray:
-    """253-bit random limbs: every value is < r, i.e. a valid Montgomery-form element."""
-    a = gen.integers(0, 1 << 63, size=tuple(shape) + (4,), dtype=np.int64).astype(np.uint64)
-    a[..., :3] ^= gen.integers(0, 1 << 63, size=tuple(shape) + (3,), dtype=np.int64).astype(np.uint64) << np.uint64(1)
-    a[..., 3] &= np.uint64((1 << 61) - 1)
-    return a
-
-
-def advice_like_fr(gen: np.random.Generator, shape) -> np.ndarray:
-    """Witness-shaped scalars: 70% zero, 20% in {0,1}, 8% bytes, 2% uniform."""
-    small = np.array([limbs(v * MONT % R) for v in range(256)], dtype=np.uint64)
-    cls = gen.integers(0, 100, size=shape)
-    val = np.zeros(tuple(shape), dtype=np.int64)
-    m = (cls >= 70) & (cls < 90)
-    val[m] = gen.integers(0, 2, size=int(m.sum()))
-    m = (cls >= 90) & (cls < 98)
-    val[m] = gen.integers(0, 256, size=int(m.sum()))
-    out = small[val]
-    m = cls >= 98
-    out[m] = uniform_fr(gen, (int(m.sum()),))
-    return out
-
-
-class ProofSchedule:
-    """Device-resident state + the per-proof launch schedule (appendix B of SURVEY.md)."""
-
-    # model_28input_256entry_1hash_1bpi: k = 14, cs.degree() = 6 -> extended_k = 17, 5 h pieces
-    def __init__(self, ctx: zg.Ctx, dev: torch.device, k: int = 14, seed: int = 0):
-        self.ctx, self.dev, self.k = ctx, dev, k
-        self.n = 1 << k
-        self.ext_k = k + 3
-        self.en = 1 << self.ext_k
-        n, en = self.n, self.en
-        gen = np.random.default_rng(seed)
-        # SRS (ParamsKZG::new(k)) generated on the GPU, then the window tables of both base sets
-        self.d_g = torch.empty((n, 8), dtype=torch.int64, device=dev)
-        self.d_gl = torch.empty((n, 8), dtype=torch.int64, device=dev)
-        s = np.array(limbs(0x5EED5EED5EED5EED * MONT % R), dtype=np.uint64)
-        ctx.params_new_dev(k, s, self.d_g.data_ptr(), self.d_gl.data_ptr())
-        ctx.sync()
-        self.g = ctx.register_bases_dev(self.d_g.data_ptr(), n)
-        self.gl = ctx.register_bases_dev(self.d_gl.data_ptr(), n)
-        # witness-shaped columns (Lagrange basis): 6 advice + 1 instance, 8 permuted lookup columns,
-        # 2 permutation z + 4 lookup z, 1 random poly, h (extended), 4 GWC witness polys
-        self.advice = to_i64(advice_like_fr(gen, (7, n))).to(dev)
-        self.permuted = to_i64(uniform_fr(gen, (8, n))).to(dev)
-        self.zs = to_i64(uniform_fr(gen, (6, n))).to(dev)
-        self.random_poly = to_i64(uniform_fr(gen, (1, n))).to(dev)
-        self.h_ext = to_i64(uniform_fr(gen, (1, en))).to(dev)
-        self.gwc = to_i64(uniform_fr(gen, (4, n))).to(dev)
-        # outputs
-        self.ext = torch.empty((21, en, 4), dtype=torch.int64, device=dev)
-        self.h_coeff = torch.empty((5 * n, 4), dtype=torch.int64, device=dev)
-        self.xyzz = torch.empty((8, 16), dtype=torch.int64, device=dev)
-        self.work = torch.empty((21, n, 4), dtype=torch.int64, device=dev)
-        self.omega, self.omega_inv = zg.domain_omega(k)
-        self.ifft_div = np.array(limbs(pow(n, -1, R) * MONT % R), dtype=np.uint64)
-        torch.cuda.synchronize(dev)
-
-    def _commit(self, bases, col: torch.Tensor, batch: int):
-        n = self.n
-        self.ctx.msm_batch_dev(bases, col.data_ptr(), n, batch, n, self.xyzz.data_ptr())
-        return self.ctx.msm_finish(self.xyzz.data_ptr(), batch)  # D2H + normalise: transcript input
-
-    def _intt(self, col: torch.Tensor, slot: int, batch: int):
-        # lagrange_to_coeff on a copy (the Lagrange values stay, as in halo2)
-        w = self.work[slot:slot + batch]
-        w.copy_(col[:batch].view(batch, self.n, 4), non_blocking=True)
-        return w
-
-    def step(self):
-        ctx, n, k, ek, en = self.ctx, self.n, self.k, self.ext_k, self.en
-        pts = []
-        # -- advice: 6 commitments (Lagrange basis), 6 + 1 (instance) iNTT
-        pts.append(self._commit(self.gl, self.advice, 6))
-        w = self.work
-        w[0:7].copy_(self.advice.view(7, n, 4))
-        w[7:15].copy_(self.permuted.view(8, n, 4))
-        w[15:21].copy_(self.zs.view(6, n, 4))
-        torch.cuda.current_stream(self.dev).synchronize()
-        ctx.ntt_batch_dev(w[0:7].data_ptr(), n, 7, k, self.omega_inv, self.ifft_div)
-        # -- theta; lookups commit_permuted: 8 commitments, 8 iNTT
-        pts.append(self._commit(self.gl, self.permuted, 8))
-        ctx.ntt_batch_dev(w[7:15].data_ptr(), n, 8, k, self.omega_inv, self.ifft_div)
-        # -- beta, gamma; permutation (2) + lookup (4) grand products: 6 commitments, 6 iNTT, 2 ext NTT
-        pts.append(self._commit(self.gl, self.zs, 6))
-        ctx.ntt_batch_dev(w[15:21].data_ptr(), n, 6, k, self.omega_inv, self.ifft_div)
-        ctx.coeff_to_extended_batch_dev(w[15:17].data_ptr(), n, self.ext[0:2].data_ptr(), en, 2, k, ek)
-        # -- vanishing random polynomial: 1 commitment (coefficient basis)
-        pts.append(self._commit(self.g, self.random_poly, 1))
-        # -- y; evaluate_h: 7 + 12 coset NTTs (advice+instance, lookup z/a'/s'), then h: 1 ext iNTT
-        ctx.coeff_to_extended_batch_dev(w[0:7].data_ptr(), n, self.ext[2:9].data_ptr(), en, 7, k, ek)
-        ctx.coeff_to_extended_batch_dev(w[7:19].data_ptr(), n, self.ext[9:21].data_ptr(), en, 12, k, ek)
-        ctx.extended_to_coeff_dev(self.h_ext.data_ptr(), k, ek, 5 * n, self.h_coeff.data_ptr())
-        pts.append(self._commit(self.g, self.h_coeff, 5))
-        # -- x; GWC multiopen: 4 witness commitments
-        pts.append(self._commit(self.g, self.gwc, 4))
-        return pts
-
-
-def algorithmic_bytes_per_proof(k: int) -> float:
-    n, en = 1 << k, 1 << (k + 3)
-    msm = 30 * (n * 96 + 96)
-    intt = 21 * 2 * n * 32
-    ext = 21 * (n + en) * 32
-    ext_inv = (en + 5 * n) * 32
-    return float(msm + intt + ext + ext_inv)
-
-
-def cpu_baseline(k: int, threads: int):
-    """The oracle (CPU restatement of halo2's algorithms) timed on this box's host cores over the
-    same schedule: 30 MSM (best_multiexp, c = ceil(ln n) per thread chunk), 21 iNTT, 21 coset NTT,
-    1 extended iNTT.  kind = "port": halo2's own Rust prover cannot be built here (no cargo)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import orc
-
-    orc.load().orc_set_threads(threads)
-    n = 1 << k
-    prm = orc.params_new(k)
-    g, gl = prm.g_np(), prm.g_lagrange_np()
-    d = orc.domain(6, k)
-    adv = [orc.fill_fr_sparse(10 + i, n) for i in range(6)]
-    uni = [orc.fill_fr(20 + i, n) for i in range(24)]
-    hext = orc.fill_fr(99, 1 << d.extended_k)
-    t0 = time.perf_counter()
-    for a in adv:
-        orc.msm(a, gl, threads)
-    for u in uni[:14]:
-        orc.msm(u, gl, threads)
-    for u in uni[14:24]:
-        orc.msm(u, g, threads)
-    coeffs = [orc.lagrange_to_coeff(d, a) for a in (adv + uni[:15])]
-    for c in coeffs:
-        orc.coeff_to_extended(d, c)
-    orc.extended_to_coeff(d, hext)
-    dt = time.perf_counter() - t0
-    return {
-        "value": 3600.0 / dt, "unit": "proofs/hour", "cores": threads, "kind": "port",
-        "sample": f"1 full MSM+NTT schedule of one k={k} proof (30 MSM, 21 iNTT, 21 coset NTT, 1 ext iNTT) "
-                  f"in {dt:.2f} s with the oracle's OpenMP restatement of halo2 best_multiexp/best_fft",
-    }
 
 
 def host_cores() -> int:
@@ -188,6 +48,72 @@ def host_cores() -> int:
     except AttributeError:
         n = os.cpu_count() or 1
     return max(1, min(n, 16))
+
+
+class ProofJob:
+    """Proving key + witness resident on one GPU; step() = one create_proof."""
+
+    def __init__(self, ctx: zg.Ctx, dev: torch.device, k: int, seed: int):
+        self.ctx, self.k = ctx, k
+        self.cs, self.asg, self.ilen = wnn_shape.build(MODEL.get(k, "tiny"), k=k, seed=seed)
+        self.img = self.cs.to_c()
+        self.fixed, self.sigma = self.asg.fixed_values(), self.asg.sigma_values()
+        self.advice = self.asg.advice_values()
+        self.instance = self.asg.instance_values(self.ilen)
+        self.vk_repr = np.array(limbs(0xC0FFEE * MONT % R), dtype=np.uint64)
+        self.s = np.array(limbs(0x5EED5EED5EED5EED * MONT % R), dtype=np.uint64)
+        self.g, self.gl = ctx.params_new(k, self.s)  # ParamsKZG::new(k) on the GPU
+        self.prover = zg.Prover(ctx, self.img, self.fixed, self.sigma, self.g, self.gl, self.vk_repr)
+        self.d_advice = torch.from_numpy(self.advice.view(np.int64)).to(dev)
+        torch.cuda.synchronize(dev)
+        self.seed = 0
+        self.last = b""
+
+    def step(self):
+        # the last blinding_factors+1 rows of every advice column are rewritten by each proof, the
+        # other rows are only read: the buffer can be proved from again without a fresh copy
+        self.seed += 1
+        self.last = self.prover.prove_dev(self.d_advice.data_ptr(), self.instance, self.seed)
+        return self.last
+
+
+def algorithmic_bytes_per_proof(cs) -> float:
+    """MSM n*(32+64)+96, NTT 2*n*32, coeff->ext (n+8n)*32, ext->coeff 2*8n*32,
+    grand product 3*n*32, evaluate_h (inputs+1)*8n*32."""
+    n, en = 1 << cs.k, 1 << cs.extended_k()
+    sets = (len(cs.perm_columns) + cs.degree() - 3) // (cs.degree() - 2)
+    nl = len(cs.lookups)
+    msm = (cs.n_advice + 3 * nl + sets + 1 + (cs.degree() - 1) + 4) * (n * 96 + 96)
+    polys = cs.n_advice + cs.n_instance + 3 * nl + sets
+    intt = polys * 2 * n * 32
+    ext = polys * (n + en) * 32
+    ext_inv = 2 * en * 32
+    gp = (nl + sets) * 3 * n * 32
+    eh_inputs = cs.n_advice + cs.n_instance + cs.n_fixed + len(cs.perm_columns) + sets + 3 * nl + 3
+    eh = (eh_inputs + 1) * en * 32
+    return float(msm + intt + ext + ext_inv + gp + eh)
+
+
+def cpu_baseline(job: ProofJob, threads: int):
+    """The oracle's create_proof (CPU restatement of halo2's algorithms, OpenMP over MSM chunks, FFT
+    butterflies and row loops) timed on this box's host cores on the SAME circuit and witness (its own
+    seeded SRS of the same size).  kind = "port": halo2's own Rust prover cannot be built here (no cargo/rustc)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+
+    orc.load().orc_set_threads(threads)
+    params = orc.params_new(job.k, 0x5EED)
+    pk = orc.ProvingKey(job.img, job.fixed, job.sigma, params, job.vk_repr)
+    t0 = time.perf_counter()
+    st, proof, _ = orc.create_proof(pk, job.advice, job.instance, 1)
+    dt = time.perf_counter() - t0
+    assert st == 0 and len(proof) == len(job.last)
+    return {
+        "value": 3600.0 / dt, "unit": "proofs/hour", "cores": threads, "kind": "port",
+        "sample": f"1 full create_proof of the same k={job.k} circuit in {dt:.2f} s: oracle/prover.c "
+                  f"(plain-C restatement of halo2 create_proof, OpenMP {threads} threads)",
+        "wall_s": dt,
+    }
 
 
 def main():
@@ -214,7 +140,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     ctx = zg.Ctx(local_rank)
-    sched = ProofSchedule(ctx, dev, k=args.k, seed=rank)
+    job = ProofJob(ctx, dev, k=args.k, seed=rank)
 
     def barrier():
         if dist is not None:
@@ -223,12 +149,12 @@ def main():
         ctx.sync()
 
     for _ in range(args.warmup):
-        sched.step()
+        job.step()
     ctx.profile(True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        sched.step()
+        job.step()
     barrier()
     dt = time.perf_counter() - t0
     stats = ctx.profile_collect()
@@ -242,33 +168,37 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         proofs_per_hour = world * args.steps / dt * 3600.0
-        # dominant kernel by device time, its algorithmic bytes per launch / its average duration
-        dom = max(stats.items(), key=lambda kv: kv[1][1])
-        name, (launches, total_ms, abytes) = dom
+        # dominant kernel by device time: its algorithmic bytes per launch / its average duration
+        name, (launches, total_ms, abytes) = max(stats.items(), key=lambda kv: kv[1][1])
         avg_ms = total_ms / max(launches, 1)
         achieved = (abytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": None,
-            "avg_launch_ms": avg_ms, "launches": launches,
-            "note": "integer-ALU bound (254-bit Montgomery products); HBM figure reported as BASELINE asks",
+            "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms,
+            "launches_per_step": launches / args.steps,
+            "note": "BASELINE asks for the HBM roofline; the kernels are integer-ALU bound "
+                    "(254-bit Montgomery products), see DESIGN.md",
         }
+        kernel_ms = sum(v[1] for v in stats.values()) / args.steps
         out = {
-            "metric": "create_proof proofs/hour (MSM+NTT schedule), model_28input_256entry_1hash_1bpi",
+            "metric": "create_proof proofs/hour, model_28input_256entry_1hash_1bpi shape",
             "value": proofs_per_hour, "unit": "proofs/hour", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)",
             "data": "synthetic",
-            "config": {"workload": f"model_28input_256entry_1hash_1bpi k={args.k}: 30 MSM(2^{args.k}) + 21 iNTT + "
-                                   f"21 coset NTT(2^{args.k + 3}) + 1 ext iNTT per proof, 6 transcript round trips",
-                       "parallelism": f"{world} proof replica(s), one per GPU"},
+            "config": {"workload": f"full create_proof, WNN-shaped circuit (6 advice, 23 fixed, 12 gates, 4 lookups, "
+                                   f"8 equality columns, degree 6) k={args.k}, extended domain 2^{job.cs.extended_k()}, "
+                                   f"proof {len(job.last)} B",
+                       "parallelism": f"{world} independent proof stream(s), one per GPU"},
             "create_proof_wall_s": ms_per_step / 1e3,
-            "algorithmic_GBps": algorithmic_bytes_per_proof(args.k) / (ms_per_step * 1e-3) / 1e9,
+            "algorithmic_GBps": algorithmic_bytes_per_proof(job.cs) / (ms_per_step * 1e-3) / 1e9,
+            "gpu_kernel_ms_per_step": kernel_ms,
             "roofline": roofline,
-            "kernels_ms_per_step": {k_: v[1] / args.steps for k_, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
+            "kernels_ms_per_step": {k_: round(v[1] / args.steps, 4)
+                                    for k_, v in sorted(stats.items(), key=lambda kv: -kv[1][1])},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.k, host_cores())
+            out["cpu_baseline"] = cpu_baseline(job, host_cores())
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

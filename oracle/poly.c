@@ -363,14 +363,22 @@ void orc_params_free(orc_params *p) {
     p->g = p->g_lagrange = NULL;
 }
 
+static int commit_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
 void orc_commit(const orc_params *p, orc_g1a *out, const orc_fr *coeffs) {
     orc_g1 r;
-    orc_msm(&r, coeffs, p->g, (size_t)p->n);
+    orc_msm_mt(&r, coeffs, p->g, (size_t)p->n, commit_threads());
     orc_g1_to_affine(out, &r);
 }
 
 void orc_commit_lagrange(const orc_params *p, orc_g1a *out, const orc_fr *evals) {
     orc_g1 r;
-    orc_msm(&r, evals, p->g_lagrange, (size_t)p->n);
+    orc_msm_mt(&r, evals, p->g_lagrange, (size_t)p->n, commit_threads());
     orc_g1_to_affine(out, &r);
 }

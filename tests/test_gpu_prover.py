@@ -104,3 +104,31 @@ def test_eval_polys_and_kate_division(ctx, zg, orc, n):
     dq = torch.empty((n, 4), dtype=torch.int64, device="cuda")
     ctx.kate_division_dev(d.data_ptr(), n, pts[0], dq.data_ptr())
     assert np.array_equal(host(dq), orc.kate_division(polys[0], pts[0]))
+
+
+def test_wnn_shaped_circuit_parity_k12_and_verify_k14(ctx, zg, orc):
+    """zero_g's circuit shape: byte parity with the oracle at k = 12, and at the BASELINE size
+    (model_28input_256entry_1hash_1bpi, k = 14, extended domain 2^17) a proof the oracle's
+    verifier accepts, deterministic in the seed."""
+    import wnn_shape
+
+    vk_repr = orc.fr_from_int(0xC0FFEE)
+    for k, full_parity in ((12, True), (14, False)):
+        cs, asg, ilen = wnn_shape.build("tiny", k=k, seed=k)
+        img = cs.to_c()
+        params = orc.params_new(k, 0x5EED)
+        fixed, sigma = asg.fixed_values(), asg.sigma_values()
+        pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
+        prover = zg.Prover(ctx, img, fixed, sigma, params.g_np(), params.g_lagrange_np(), vk_repr)
+        adv, inst = asg.advice_values(), asg.instance_values(ilen)
+        got = prover.prove(adv, inst, 9)
+        assert len(got) == 64 * 30 + 32 * (10 + len(cs.fixed_queries) + 1 + 8 + 5 + 20)
+        assert prover.prove(adv, inst, 9) == got
+        if full_parity:
+            st, want, _ = orc.create_proof(pk, adv, inst, 9)
+            assert st == 0 and got == want
+        assert orc.verify_proof(pk, inst, got) == 1
+        bad = bytearray(got)
+        bad[100] ^= 4
+        assert orc.verify_proof(pk, inst, bytes(bad)) != 1
+        prover.close()

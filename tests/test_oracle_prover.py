@@ -76,3 +76,26 @@ def test_unsatisfied_witness_is_rejected(orc, params5):
     bad[1, 2] = orc.fr_from_int(1000)
     st, proof, _ = orc.create_proof(pk, bad, inst, seed=1)
     assert st == -5
+
+
+def test_wnn_shaped_circuit_proof_verifies(orc):
+    """The circuit of zero_g's shape (12 gates, 4 lookups, 8 equality columns,
+    degree 6) at a reduced k: witness satisfies every constraint, proof verifies."""
+    import wnn_shape
+
+    cs, asg, ilen = wnn_shape.build("tiny", k=12, seed=3)
+    asg.check()
+    assert (cs.n_fixed, cs.n_advice, cs.n_instance) == (23, 6, 1)
+    assert cs.degree() == 6 and cs.extended_k() == 15 and cs.blinding_factors() == 5
+    assert len(cs.gates) == 12 and len(cs.lookups) == 4 and len(cs.perm_columns) == 8
+    assert sorted(cs.advice_queries) == sorted([(0, 0), (0, 1), (1, 0), (2, 0), (3, 0), (4, 0), (4, 1),
+                                                (5, -1), (5, 0), (5, 1)])
+    params = orc.params_new(12, 0x5EED)
+    pk = make_pk(orc, cs, asg, params)
+    inst = asg.instance_values(ilen)
+    st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=5)
+    assert st == 0
+    # 6 advice + 8 permuted + 2 perm z + 4 lookup z + 1 random + 5 h + 4 W = 30 points
+    n_scalars = 10 + len(cs.fixed_queries) + 1 + 8 + 5 + 20
+    assert len(proof) == 64 * 30 + 32 * n_scalars
+    assert orc.verify_proof(pk, inst, proof) == 1
