@@ -142,9 +142,24 @@ struct Field {
 
     static ZG_HD Fe dbl(const Fe& a) { return add(a, a); }
 
-    // Montgomery product a*b*R^-1 mod p.  CIOS, fused multiply/reduce rows; the modulus leaves
-    // two spare top bits so the running value never needs a 10th word.
+    // Montgomery product a*b*R^-1 mod p.
+    //   device: product scanning over 16 columns, every partial product one v_mad_u64_u32 with its
+    //           carry caught by one v_addc_co_u32 (generated asm, tools/gen_mont_mul.py);
+    //   host  : CIOS with fused multiply/reduce rows (the modulus leaves two spare top bits, so the
+    //           running value never needs a 10th word).
     static ZG_HD Fe mul(const Fe& a, const Fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t acc = 0;
+        uint32_t ovf = 0;
+        uint32_t m[8], r[8];
+#include "mont_mul_gfx950.inc"
+        Fe o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = r[i];
+        // the column sums keep the value below 2p: one conditional subtraction
+        reduce_once(o);
+        return o;
+#else
         uint32_t t[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) t[i] = 0;
@@ -170,6 +185,7 @@ struct Field {
         for (int i = 0; i < 8; i++) o.l[i] = t[i];
         reduce_once(o);
         return o;
+#endif
     }
 
     static ZG_HD Fe sqr(const Fe& a) { return mul(a, a); }
