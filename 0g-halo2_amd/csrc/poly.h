@@ -80,9 +80,11 @@ int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin,
                       const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups);
 int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe* sigma_val, const Fe* omega_tw,
                     const Fe& beta, const Fe& gamma, Fe* num, Fe* den, uint32_t n);
-// z[b][0] = *z0[b] (device pointers, or one if null), z[b][i+1] = z[b][i]*num[b][i]/den[b][i]; tmp: [batch][n]
-int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* const* d_z0, Fe* z, Fe* tmp,
-                       uint32_t n, uint32_t batch);
+// z[b][0] = z0[b] (device array, or all ones if null), z[b][i+1] = z[b][i]*num[b][i]/den[b][i]; the first
+// `chain` products are chained: product b starts from product b-1's value at row `last`.
+size_t poly_grand_product_tmp_elems(uint32_t n, uint32_t batch);
+int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
+                       uint32_t batch, uint32_t chain, uint32_t last);
 int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en);
 int poly_powers(zg_ctx* ctx, const Fe* points_host, uint32_t npoints, uint32_t n, Fe* d_pow);
 int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint32_t* d_poly_idx,
@@ -90,7 +92,9 @@ int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint
 // out[i] = sum_j horner in `v` over the polys listed (first listed = highest power), then out[0] -= sub
 int poly_horner_combine(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_list, uint32_t count,
                         const Fe& v, const Fe& sub, Fe* out, uint32_t n);
-int poly_kate_division(zg_ctx* ctx, const Fe* a, uint32_t n, const Fe& z, Fe* q);
+size_t poly_kate_tmp_elems(uint32_t n, uint32_t batch);
+int poly_kate_division(zg_ctx* ctx, const Fe* a, size_t a_stride, const Fe* zs_host, Fe* q, size_t q_stride, Fe* tmp,
+                       uint32_t n, uint32_t batch);
 int poly_l_cosets_init(zg_ctx* ctx, Fe* l0, Fe* llast, Fe* lblind, uint32_t n, uint32_t bf);
 int poly_lactive(zg_ctx* ctx, Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en);
 

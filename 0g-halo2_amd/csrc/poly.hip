@@ -216,62 +216,158 @@ int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe
 }
 
 // ------------------------------------------------------------------ grand product
-// z[0] = z0, z[i+1] = z[i] * num[i] / den[i].  One 1024-lane workgroup per product: every lane owns a
-// strip; strip-local Montgomery batch inversion (one binary-Euclid inversion per lane), then a
-// Hillis-Steele product scan across the lanes through LDS.  Zero denominators invert to zero, as
-// halo2's BatchInvert leaves them.
-__global__ __launch_bounds__(1024) void grand_product_kernel(const Fe* __restrict__ num, const Fe* __restrict__ den,
-                                                             const Fe* const* __restrict__ z0p, Fe* __restrict__ z,
-                                                             Fe* __restrict__ tmp, uint32_t n) {
-    __shared__ Fe sh[1024];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    num += (size_t)b * n; den += (size_t)b * n; z += (size_t)b * n; tmp += (size_t)b * n;
-    const uint32_t L = (n + 1023) / 1024;
-    uint32_t lo = tid * L, hi = lo + L;
-    if (lo > n) lo = n;
-    if (hi > n) hi = n;
-    // forward: prefix products of the strip's denominators
-    Fe p = Fr::one();
-    for (uint32_t i = lo; i < hi; i++) {
-        stg(tmp + i, p);
-        Fe d = ldg(den + i);
-        if (!fe_is_zero(d)) p = Fr::mul(p, d);
-    }
-    Fe acc = Fr::inv(p);
-    // backward: inverse of each denominator, ratio = num/den (kept in tmp), strip product of ratios
-    for (uint32_t i = hi; i-- > lo;) {
-        Fe d = ldg(den + i);
-        Fe inv = fe_zero();
-        if (!fe_is_zero(d)) {
-            inv = Fr::mul(acc, ldg(tmp + i));
-            acc = Fr::mul(acc, d);
+// z[0] = z0, z[i+1] = z[i] * num[i] / den[i], as z[i] = z0 * N(i-1) * D'(i) / T with
+//   N(i)  = prod_{j<=i} num'_j          (prefix products)
+//   D'(i) = prod_{j>=i} den'_j          (suffix products),  T = prod_j den'_j
+// where a zero denominator counts as den' = 1, num' = 0 (halo2's BatchInvert leaves zeros alone, so
+// that ratio is 0).  Three launches for ALL products of a proof phase: block-local scans (one lane per
+// row, Hillis-Steele through LDS), one workgroup per product for the block totals + the single field
+// inversion of T, and the combining pass.  `chain` leading products are chained like the permutation
+// sets: z0 of product b is product b-1's value at row `last`.
+constexpr uint32_t GP_BLOCK = 256;
+
+__global__ __launch_bounds__(GP_BLOCK) void gp_local_kernel(const Fe* __restrict__ num, const Fe* __restrict__ den,
+                                                             Fe* __restrict__ locn, Fe* __restrict__ locd,
+                                                             Fe* __restrict__ totn, Fe* __restrict__ totd, uint32_t n,
+                                                             uint32_t nblk) {
+    __shared__ Fe shn[GP_BLOCK], shd[GP_BLOCK];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    const uint32_t i = blk * GP_BLOCK + tid;
+    Fe nv = Fr::one(), dv = Fr::one();
+    if (i < n) {
+        Fe d = ldg(den + (size_t)b * n + i);
+        if (fe_is_zero(d)) {
+            nv = fe_zero();
+        } else {
+            nv = ldg(num + (size_t)b * n + i);
+            dv = d;
         }
-        stg(tmp + i, Fr::mul(ldg(num + i), inv));
     }
-    Fe r = Fr::one();
-    for (uint32_t i = lo; i < hi; i++) r = Fr::mul(r, ldg(tmp + i));
-    sh[tid] = r;
+    shn[tid] = nv;
+    shd[tid] = dv;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        Fe v = Fr::one();
-        if (tid >= off) v = sh[tid - off];
+    for (uint32_t off = 1; off < GP_BLOCK; off <<= 1) {
+        Fe pn = Fr::one(), pd = Fr::one();
+        const bool hn = tid >= off, hd = tid + off < GP_BLOCK;
+        if (hn) pn = shn[tid - off];
+        if (hd) pd = shd[tid + off];
         __syncthreads();
-        if (tid >= off) sh[tid] = Fr::mul(sh[tid], v);
+        if (hn) shn[tid] = Fr::mul(shn[tid], pn);
+        if (hd) shd[tid] = Fr::mul(shd[tid], pd);
         __syncthreads();
     }
-    Fe start = (z0p && z0p[b]) ? ldg(z0p[b]) : Fr::one();
-    if (tid > 0) start = Fr::mul(start, sh[tid - 1]);
-    for (uint32_t i = lo; i < hi; i++) {
-        stg(z + i, start);
-        start = Fr::mul(start, ldg(tmp + i));
+    if (i < n) {
+        stg(locn + (size_t)b * n + i, shn[tid]);  // inclusive prefix inside the block
+        stg(locd + (size_t)b * n + i, shd[tid]);  // inclusive suffix inside the block
+    }
+    if (tid == 0) {
+        stg(totn + (size_t)b * nblk + blk, shn[GP_BLOCK - 1]);
+        stg(totd + (size_t)b * nblk + blk, shd[0]);
     }
 }
 
-int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* const* d_z0, Fe* z, Fe* tmp, uint32_t n,
-                       uint32_t batch) {
+// per product: exclusive prefix of the block totals of num', exclusive suffix of those of den', 1/T,
+// and the product's value at row `last` for z0 = 1 (feeds the chain)
+__global__ __launch_bounds__(1024) void gp_totals_kernel(Fe* __restrict__ totn, Fe* __restrict__ totd,
+                                                         const Fe* __restrict__ locn, const Fe* __restrict__ locd,
+                                                         Fe* __restrict__ tinv, Fe* __restrict__ zlast, uint32_t n,
+                                                         uint32_t nblk, uint32_t last) {
+    __shared__ Fe shn[1024], shd[1024];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    Fe* tn = totn + (size_t)b * nblk;
+    Fe* td = totd + (size_t)b * nblk;
+    Fe vn = Fr::one(), vd = Fr::one();
+    if (tid < nblk) {
+        vn = ldg(tn + tid);
+        vd = ldg(td + tid);
+    }
+    shn[tid] = vn;
+    shd[tid] = vd;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        Fe pn = Fr::one(), pd = Fr::one();
+        const bool hn = tid >= off, hd = tid + off < 1024;
+        if (hn) pn = shn[tid - off];
+        if (hd) pd = shd[tid + off];
+        __syncthreads();
+        if (hn) shn[tid] = Fr::mul(shn[tid], pn);
+        if (hd) shd[tid] = Fr::mul(shd[tid], pd);
+        __syncthreads();
+    }
+    // exclusive forms
+    Fe en = tid > 0 ? shn[tid - 1] : Fr::one();
+    Fe ed = tid + 1 < 1024 ? shd[tid + 1] : Fr::one();
+    Fe total_d = shd[0];
+    __syncthreads();
+    if (tid < nblk) {
+        stg(tn + tid, en);
+        stg(td + tid, ed);
+    }
+    shn[tid] = en;
+    shd[tid] = ed;
+    __syncthreads();
+    if (tid == 0) {
+        Fe ti = Fr::inv(total_d);
+        stg(tinv + b, ti);
+        // z(last) for z0 = 1: N(last-1) * D'(last) / T
+        Fe v = ti;
+        if (last < n) {
+            uint32_t lb = last / GP_BLOCK;
+            v = Fr::mul(v, Fr::mul(ldg(locd + (size_t)b * n + last), shd[lb]));
+            if (last > 0) {
+                uint32_t pb = (last - 1) / GP_BLOCK;
+                v = Fr::mul(v, Fr::mul(ldg(locn + (size_t)b * n + last - 1), shn[pb]));
+            }
+        }
+        stg(zlast + b, v);
+    }
+}
+
+__global__ __launch_bounds__(GP_BLOCK) void gp_apply_kernel(const Fe* __restrict__ locn, const Fe* __restrict__ locd,
+                                                            const Fe* __restrict__ totn, const Fe* __restrict__ totd,
+                                                            const Fe* __restrict__ tinv, const Fe* __restrict__ zlast,
+                                                            const Fe* __restrict__ z0, Fe* __restrict__ z, uint32_t n,
+                                                            uint32_t nblk, uint32_t chain) {
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    const uint32_t i = blk * GP_BLOCK + tid;
+    if (i >= n) return;
+    // start value: z0[b] (if given) times the chained last values of the products before b
+    Fe c = z0 ? ldg(z0 + b) : Fr::one();
+    if (b < chain)
+        for (uint32_t s = 0; s < b; s++) c = Fr::mul(c, ldg(zlast + s));
+    Fe v = Fr::mul(c, ldg(tinv + b));
+    v = Fr::mul(v, Fr::mul(ldg(locd + (size_t)b * n + i), ldg(totd + (size_t)b * nblk + blk)));
+    if (i > 0) {
+        uint32_t pb = (i - 1) / GP_BLOCK;
+        v = Fr::mul(v, Fr::mul(ldg(locn + (size_t)b * n + i - 1), ldg(totn + (size_t)b * nblk + pb)));
+    }
+    stg(z + (size_t)b * n + i, v);
+}
+
+// tmp: 2*batch*n + 2*batch*nblk + 2*batch elements
+size_t poly_grand_product_tmp_elems(uint32_t n, uint32_t batch) {
+    size_t nblk = (n + GP_BLOCK - 1) / GP_BLOCK;
+    return (size_t)2 * batch * n + (size_t)2 * batch * nblk + (size_t)2 * batch;
+}
+
+int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
+                       uint32_t batch, uint32_t chain, uint32_t last) {
     if (!batch || !n) return ZG_OK;
-    ZG_LAUNCH(ctx, "grand_product", (double)batch * n * 96, grand_product_kernel, dim3(batch), dim3(1024), 0, num, den,
-              d_z0, z, tmp, n);
+    const uint32_t nblk = (n + GP_BLOCK - 1) / GP_BLOCK;
+    ZG_REQUIRE(nblk <= 1024, ZG_ERR_UNSUPPORTED, "grand product: n=%u > 2^18 not built", n);
+    Fe* locn = tmp;
+    Fe* locd = locn + (size_t)batch * n;
+    Fe* totn = locd + (size_t)batch * n;
+    Fe* totd = totn + (size_t)batch * nblk;
+    Fe* tinv = totd + (size_t)batch * nblk;
+    Fe* zlast = tinv + batch;
+    const double bytes = (double)batch * n * 96;
+    ZG_LAUNCH(ctx, "grand_product_local", bytes, gp_local_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, num, den, locn,
+              locd, totn, totd, n, nblk);
+    ZG_LAUNCH(ctx, "grand_product_totals", bytes, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
+              tinv, zlast, n, nblk, last);
+    ZG_LAUNCH(ctx, "grand_product_apply", bytes, gp_apply_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, locn, locd, totn,
+              totd, tinv, zlast, d_z0, z, n, nblk, chain);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -431,40 +527,91 @@ int poly_horner_combine(zg_ctx* ctx, const Fe* polys, size_t stride, const uint3
     return ZG_OK;
 }
 
-// kate_division: q_i = a_{i+1} + z q_{i+1}, i = n-2 .. 0, q_{n-1} = 0.  Strip-local recurrences joined by
-// a weighted suffix scan across the 1024 lanes (weights z^(L*s)).
-__global__ __launch_bounds__(1024) void kate_division_kernel(const Fe* __restrict__ a, uint32_t n, Fe z,
-                                                             Fe* __restrict__ q) {
-    __shared__ Fe sh[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t L = (n + 1023) / 1024;
-    const uint32_t lo = tid * L, hi = lo + L;  // strip of q indices [lo, hi); a beyond n-1 counts as 0
-    Fe loc = fe_zero();
-    for (uint32_t i = hi; i-- > lo;) {
-        Fe an = (i + 1 < n) ? ldg(a + i + 1) : fe_zero();
-        loc = Fr::add(an, Fr::mul(z, loc));
-    }
-    sh[tid] = loc;  // q_lo assuming q_hi = 0
+// kate_division: q_i = a_{i+1} + z q_{i+1} (i = n-2 .. 0, q_{n-1} = 0), i.e. the weighted suffix sums
+// q_i = sum_{j>=i} a_{j+1} z^(j-i).  Same three-launch shape as the grand product: block-local weighted
+// suffix scans (weight z^off at step off), one workgroup per polynomial for the block heads (weight
+// z^256 per block), then q_i = local_i + z^(block_end - i) * carry.  Batched over (polynomial, point).
+constexpr uint32_t KD_BLOCK = 256;
+
+__global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const Fe* __restrict__ a, size_t a_stride,
+                                                            const Fe* __restrict__ zs, Fe* __restrict__ loc,
+                                                            Fe* __restrict__ heads, uint32_t n, uint32_t nblk) {
+    __shared__ Fe sh[KD_BLOCK];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    const uint32_t i = blk * KD_BLOCK + tid;
+    const Fe* ap = a + (size_t)b * a_stride;
+    Fe v = (i + 1 < n) ? ldg(ap + i + 1) : fe_zero();
+    sh[tid] = v;
     __syncthreads();
-    Fe w = Fr::pow_u64(z, L);  // z^L
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        Fe v = fe_zero();
-        if (tid + off < 1024) v = sh[tid + off];
+    Fe w = ldg(zs + b);  // z^off
+    for (uint32_t off = 1; off < KD_BLOCK; off <<= 1) {
+        Fe t = fe_zero();
+        const bool has = tid + off < KD_BLOCK;
+        if (has) t = sh[tid + off];
         __syncthreads();
-        if (tid + off < 1024) sh[tid] = Fr::add(sh[tid], Fr::mul(w, v));
+        if (has) sh[tid] = Fr::add(sh[tid], Fr::mul(w, t));
         w = Fr::sqr(w);
         __syncthreads();
     }
-    Fe carry = (tid + 1 < 1024) ? sh[tid + 1] : fe_zero();  // true q at index hi
-    for (uint32_t i = hi; i-- > lo;) {
-        Fe an = (i + 1 < n) ? ldg(a + i + 1) : fe_zero();
-        carry = Fr::add(an, Fr::mul(z, carry));
-        if (i < n) stg(q + i, carry);
-    }
+    if (i < n) stg(loc + (size_t)b * n + i, sh[tid]);
+    if (tid == 0) stg(heads + (size_t)b * nblk + blk, sh[0]);
 }
 
-int poly_kate_division(zg_ctx* ctx, const Fe* a, uint32_t n, const Fe& z, Fe* q) {
-    ZG_LAUNCH(ctx, "kate_division", (double)n * 64, kate_division_kernel, dim3(1), dim3(1024), 0, a, n, z, q);
+// heads[blk] <- sum_{blk' > blk} heads[blk'] * (z^256)^(blk' - blk - 1): the carry entering block blk from above
+__global__ __launch_bounds__(1024) void kd_heads_kernel(Fe* __restrict__ heads, const Fe* __restrict__ zs, uint32_t nblk) {
+    __shared__ Fe sh[1024];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    Fe* hp = heads + (size_t)b * nblk;
+    sh[tid] = tid < nblk ? ldg(hp + tid) : fe_zero();
+    __syncthreads();
+    Fe w = Fr::pow_u64(ldg(zs + b), KD_BLOCK);
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        Fe t = fe_zero();
+        const bool has = tid + off < 1024;
+        if (has) t = sh[tid + off];
+        __syncthreads();
+        if (has) sh[tid] = Fr::add(sh[tid], Fr::mul(w, t));
+        w = Fr::sqr(w);
+        __syncthreads();
+    }
+    Fe carry = tid + 1 < 1024 ? sh[tid + 1] : fe_zero();
+    __syncthreads();
+    if (tid < nblk) stg(hp + tid, carry);
+}
+
+__global__ __launch_bounds__(KD_BLOCK) void kd_apply_kernel(const Fe* __restrict__ loc, const Fe* __restrict__ heads,
+                                                            const Fe* __restrict__ zs, Fe* __restrict__ q, size_t q_stride,
+                                                            uint32_t n, uint32_t nblk) {
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    const uint32_t i = blk * KD_BLOCK + tid;
+    if (i >= n) return;
+    Fe v = ldg(loc + (size_t)b * n + i);
+    Fe carry = ldg(heads + (size_t)b * nblk + blk);
+    if (!fe_is_zero(carry)) v = Fr::add(v, Fr::mul(Fr::pow_u64(ldg(zs + b), KD_BLOCK - tid), carry));
+    stg(q + (size_t)b * q_stride + i, v);
+}
+
+size_t poly_kate_tmp_elems(uint32_t n, uint32_t batch) {
+    size_t nblk = (n + KD_BLOCK - 1) / KD_BLOCK;
+    return (size_t)batch * n + (size_t)batch * nblk + batch;
+}
+
+// zs_host: `batch` opening points; a_b = a + b*a_stride, q_b = q + b*q_stride; tmp per poly_kate_tmp_elems
+int poly_kate_division(zg_ctx* ctx, const Fe* a, size_t a_stride, const Fe* zs_host, Fe* q, size_t q_stride, Fe* tmp,
+                       uint32_t n, uint32_t batch) {
+    if (!batch || !n) return ZG_OK;
+    const uint32_t nblk = (n + KD_BLOCK - 1) / KD_BLOCK;
+    ZG_REQUIRE(nblk <= 1024, ZG_ERR_UNSUPPORTED, "kate division: n=%u > 2^18 not built", n);
+    Fe* loc = tmp;
+    Fe* heads = loc + (size_t)batch * n;
+    Fe* zs = heads + (size_t)batch * nblk;
+    ZG_HIP(hipMemcpyAsync(zs, zs_host, batch * sizeof(Fe), hipMemcpyHostToDevice, ctx->stream));
+    const double bytes = (double)batch * n * 64;
+    ZG_LAUNCH(ctx, "kate_local", bytes, kd_local_kernel, dim3(nblk, batch), dim3(KD_BLOCK), 0, a, a_stride, zs, loc, heads,
+              n, nblk);
+    ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(batch), dim3(1024), 0, heads, zs, nblk);
+    ZG_LAUNCH(ctx, "kate_apply", bytes, kd_apply_kernel, dim3(nblk, batch), dim3(KD_BLOCK), 0, loc, heads, zs, q, q_stride,
+              n, nblk);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

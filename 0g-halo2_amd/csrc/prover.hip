@@ -156,7 +156,7 @@ struct zg_prover {
     Fe *pin_cos_c = nullptr, *ptab_cos_c = nullptr, *pin_c = nullptr, *ptab_c = nullptr;
     XYZZ* xyzz = nullptr;
     uint32_t* d_idx = nullptr;
-    const Fe** d_z0 = nullptr;
+    Fe* ktmp = nullptr;
     hipEvent_t ev = nullptr;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
@@ -364,10 +364,10 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     ZG_TRY(dalloc(p, &p->ctab, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->perm, (size_t)2 * NL * n));
     ZG_TRY(dalloc(p, &p->zs, (size_t)(S + NL) * n));
-    const uint32_t mb = std::max(S, NL);
+    const uint32_t mb = S + NL;
     ZG_TRY(dalloc(p, &p->num, (size_t)mb * n));
     ZG_TRY(dalloc(p, &p->den, (size_t)mb * n));
-    ZG_TRY(dalloc(p, &p->tmp, (size_t)mb * n));
+    ZG_TRY(dalloc(p, &p->tmp, poly_grand_product_tmp_elems(n, mb)));
     ZG_TRY(dalloc(p, &p->h, (size_t)en));
     ZG_TRY(dalloc(p, &p->raw, (size_t)2 * NL * n));
     const uint32_t max_points = 4 + (uint32_t)(p->advice_queries.size() + p->fixed_queries.size());
@@ -376,8 +376,8 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     ZG_TRY(dalloc(p, &p->evals, max_evals));
     ZG_TRY(dalloc(p, &p->wpoly, (size_t)2 * max_points * n));
     ZG_TRY(dalloc(p, &p->xyzz, std::max<size_t>(std::max<size_t>(A, 2 * NL), std::max<size_t>(S + NL + 1, std::max<size_t>(Q, max_points)))));
-    ZG_TRY(dalloc(p, &p->d_idx, (size_t)4 * max_evals + 64));
-    ZG_TRY(dalloc(p, &p->d_z0, mb + 1));
+    ZG_TRY(dalloc(p, &p->d_idx, (size_t)4 * max_evals + 64 + (size_t)max_points * 512));
+    ZG_TRY(dalloc(p, &p->ktmp, poly_kate_tmp_elems(n, max_points)));
     p->pinned_cap = std::max<size_t>((size_t)4 * NL * n * 32, 1u << 20);
     ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocDefault));
 
@@ -523,25 +523,17 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
     Fe* pz = p->zs;
     Fe* lz = p->zs + (size_t)S * n;
-    if (S) {
-        ZG_TRY(poly_perm_terms(ctx, p->dc, base_cols, p->sigma_val, p->omega_tw, beta, gamma, p->num, p->den, n));
-        std::vector<const Fe*> z0(S, nullptr);
-        for (uint32_t s = 1; s < S; s++) z0[s] = pz + (size_t)(s - 1) * n + (n - bf - 1);
-        ZG_HIP(hipMemcpyAsync(p->d_z0, z0.data(), S * sizeof(Fe*), hipMemcpyHostToDevice, st));
-        for (uint32_t s = 0; s < S; s++)
-            ZG_TRY(poly_grand_product(ctx, p->num + (size_t)s * n, p->den + (size_t)s * n, p->d_z0 + s, pz + (size_t)s * n,
-                                      p->tmp + (size_t)s * n, n, 1));
-        ZG_HIP(hipStreamSynchronize(st));  // z0 (host vector) consumed
-        ZG_TRY(poly_blind_rows(ctx, pz, n, S, n - bf, bf, seed, TAG_PERM_Z));
-    }
-    if (NL) {
-        // de-interleave views of a' / s' for the product terms
-        for (uint32_t l = 0; l < NL; l++)
-            ZG_TRY(poly_lookup_terms(ctx, p->cin + (size_t)l * n, p->ctab + (size_t)l * n, p->perm + (size_t)(2 * l) * n,
-                                     p->perm + (size_t)(2 * l + 1) * n, beta, gamma, p->num + (size_t)l * n,
-                                     p->den + (size_t)l * n, n, 1));
-        ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, lz, p->tmp, n, NL));
-        ZG_TRY(poly_blind_rows(ctx, lz, n, NL, n - bf, bf, seed, TAG_LOOKUP_Z));
+    if (S) ZG_TRY(poly_perm_terms(ctx, p->dc, base_cols, p->sigma_val, p->omega_tw, beta, gamma, p->num, p->den, n));
+    for (uint32_t l = 0; l < NL; l++)  // a'_l / s'_l are interleaved in `perm`
+        ZG_TRY(poly_lookup_terms(ctx, p->cin + (size_t)l * n, p->ctab + (size_t)l * n, p->perm + (size_t)(2 * l) * n,
+                                 p->perm + (size_t)(2 * l + 1) * n, beta, gamma, p->num + (size_t)(S + l) * n,
+                                 p->den + (size_t)(S + l) * n, n, 1));
+    if (S + NL) {
+        // all running products of the proof in one scan sequence; the S permutation sets are chained
+        // through row n - bf - 1, the lookup products start from one
+        ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, S + NL, S, n - bf - 1));
+        if (S) ZG_TRY(poly_blind_rows(ctx, pz, n, S, n - bf, bf, seed, TAG_PERM_Z));
+        if (NL) ZG_TRY(poly_blind_rows(ctx, lz, n, NL, n - bf, bf, seed, TAG_LOOKUP_Z));
     }
     if (S + NL) ZG_TRY(msm_batch_dev(ctx, p->gl, p->zs, n, S + NL, n, p->xyzz));
     // vanishing::Argument::commit: random polynomial (coefficient basis)
@@ -631,9 +623,9 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     {
         std::vector<uint32_t> list(Q);
         for (uint32_t i = 0; i < Q; i++) list[i] = p->ix_hpiece + (Q - 1 - i);
-        ZG_HIP(hipMemcpyAsync(p->d_idx, list.data(), Q * 4, hipMemcpyHostToDevice, st));
-        ZG_TRY(poly_horner_combine(ctx, polys, n, p->d_idx, Q, xn, fe_zero(), poly_at(p->ix_hpoly), n));
-        ZG_HIP(hipStreamSynchronize(st));
+        uint32_t* dl = p->d_idx + (size_t)4 * (p->advice_queries.size() + p->fixed_queries.size() + P + 3 * S + 5 * NL + 4);
+        ZG_HIP(hipMemcpyAsync(dl, list.data(), Q * 4, hipMemcpyHostToDevice, st));
+        ZG_TRY(poly_horner_combine(ctx, polys, n, dl, Q, xn, fe_zero(), poly_at(p->ix_hpoly), n));
     }
     ZG_TRY(poly_powers(ctx, points.data(), (uint32_t)points.size(), n, p->pw));
     std::vector<uint32_t> idx(2 * evq.size());
@@ -688,6 +680,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         std::vector<char> done(oq.size(), 0);
         uint32_t npts = 0;
         std::vector<uint32_t> list;
+        std::vector<Fe> open_points;
         for (size_t first = 0; first < oq.size(); first++) {
             if (done[first]) continue;
             const uint32_t slot = oq[first].slot;
@@ -699,15 +692,18 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
                 list.push_back(oq[j].poly);
                 eval_batch = Fr::add(Fr::mul(eval_batch, v), oq[j].eval);
             }
-            uint32_t* dl = p->d_idx;  // lists are consumed launch by launch
+            // (hipMemcpyAsync from pageable memory stages the bytes before it returns, so `list` can be rebuilt)
+            ZG_REQUIRE(list.size() <= 512, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %zu polynomials opened at one point", list.size());
+            uint32_t* dl = p->d_idx + (size_t)npts * 512;
             ZG_HIP(hipMemcpyAsync(dl, list.data(), list.size() * 4, hipMemcpyHostToDevice, st));
             Fe* batch = p->wpoly + (size_t)(2 * npts) * n;
-            Fe* wit = p->wpoly + (size_t)(2 * npts + 1) * n;
             ZG_TRY(poly_horner_combine(ctx, polys, n, dl, (uint32_t)list.size(), v, eval_batch, batch, n));
-            ZG_TRY(poly_kate_division(ctx, batch, n, points[slot], wit));
-            ZG_HIP(hipStreamSynchronize(st));  // list (host vector) consumed before it is rebuilt
+            open_points.push_back(points[slot]);
             npts++;
         }
+        // one batched kate_division: poly j at wpoly[2j], quotient at wpoly[2j+1]
+        ZG_TRY(poly_kate_division(ctx, p->wpoly, (size_t)2 * n, open_points.data(), p->wpoly + n, (size_t)2 * n, p->ktmp,
+                                  n, npts));
         // the witness polynomials sit at odd slots: stride 2n
         ZG_TRY(msm_batch_dev(ctx, p->g, p->wpoly + n, (size_t)2 * n, npts, n, p->xyzz));
         ZG_TRY(fetch_points(p, npts, pts));
@@ -763,14 +759,11 @@ int zg_grand_product_dev(zg_ctx* ctx, const void* d_num, const void* d_den, cons
     ZG_REQUIRE(n < (1u << 28), ZG_ERR_UNSUPPORTED, "zg_grand_product_dev: n too large");
     ZG_HIP(hipSetDevice(ctx->device));
     WsScope ws(ctx);
-    Fe* tmp = ws.get<Fe>(n + 1);
-    const Fe** zp = ws.get<const Fe*>(2);
+    Fe* tmp = ws.get<Fe>(poly_grand_product_tmp_elems((uint32_t)n, 1) + 1);
     if (ws.failed) return ZG_ERR_OOM;
-    Fe* z0d = tmp + n;
+    Fe* z0d = tmp + poly_grand_product_tmp_elems((uint32_t)n, 1);
     ZG_HIP(hipMemcpyAsync(z0d, z0, 32, hipMemcpyHostToDevice, ctx->stream));
-    const Fe* hp[1] = {z0d};
-    ZG_HIP(hipMemcpyAsync(zp, hp, sizeof(hp), hipMemcpyHostToDevice, ctx->stream));
-    ZG_TRY(poly_grand_product(ctx, (const Fe*)d_num, (const Fe*)d_den, zp, (Fe*)d_z, tmp, (uint32_t)n, 1));
+    ZG_TRY(poly_grand_product(ctx, (const Fe*)d_num, (const Fe*)d_den, z0d, (Fe*)d_z, tmp, (uint32_t)n, 1, 0, 0));
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     return ZG_OK;
 }
@@ -802,7 +795,13 @@ int zg_eval_polys_dev(zg_ctx* ctx, const void* d_polys, size_t stride_elems, siz
 int zg_kate_division_dev(zg_ctx* ctx, const void* d_a, size_t n, const zg_fr* z, void* d_q) {
     ZG_REQUIRE(ctx && d_a && z && d_q && n >= 1, ZG_ERR_INVALID_ARG, "zg_kate_division_dev: bad argument");
     ZG_HIP(hipSetDevice(ctx->device));
-    ZG_TRY(poly_kate_division(ctx, (const Fe*)d_a, (uint32_t)n, to_fe(z), (Fe*)d_q));
+    ZG_REQUIRE(n < (1u << 28), ZG_ERR_UNSUPPORTED, "zg_kate_division_dev: n too large");
+    WsScope ws(ctx);
+    Fe* tmp = ws.get<Fe>(poly_kate_tmp_elems((uint32_t)n, 1));
+    if (ws.failed) return ZG_ERR_OOM;
+    Fe zz = to_fe(z);
+    ZG_TRY(poly_kate_division(ctx, (const Fe*)d_a, n, &zz, (Fe*)d_q, n, tmp, (uint32_t)n, 1));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
     return ZG_OK;
 }
 
