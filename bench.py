@@ -50,11 +50,11 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
-class ProofJob:
-    """Proving key + witness resident on one GPU; step() = one create_proof."""
+class Circuit:
+    """Host-side material shared by every proof stream: circuit image, pk values, witness, SRS."""
 
-    def __init__(self, ctx: zg.Ctx, dev: torch.device, k: int, seed: int):
-        self.ctx, self.k = ctx, k
+    def __init__(self, ctx: zg.Ctx, k: int, seed: int):
+        self.k = k
         self.cs, self.asg, self.ilen = wnn_shape.build(MODEL.get(k, "tiny"), k=k, seed=seed)
         self.img = self.cs.to_c()
         self.fixed, self.sigma = self.asg.fixed_values(), self.asg.sigma_values()
@@ -63,10 +63,19 @@ class ProofJob:
         self.vk_repr = np.array(limbs(0xC0FFEE * MONT % R), dtype=np.uint64)
         self.s = np.array(limbs(0x5EED5EED5EED5EED * MONT % R), dtype=np.uint64)
         self.g, self.gl = ctx.params_new(k, self.s)  # ParamsKZG::new(k) on the GPU
-        self.prover = zg.Prover(ctx, self.img, self.fixed, self.sigma, self.g, self.gl, self.vk_repr)
-        self.d_advice = torch.from_numpy(self.advice.view(np.int64)).to(dev)
+
+
+class ProofJob:
+    """One proof stream: its own context (HIP stream + workspace) and prover, pk + witness resident
+    in HBM; step() = one create_proof."""
+
+    def __init__(self, ctx: zg.Ctx, dev: torch.device, c: Circuit, stream_id: int):
+        self.ctx, self.c, self.k, self.cs = ctx, c, c.k, c.cs
+        self.prover = zg.Prover(ctx, c.img, c.fixed, c.sigma, c.g, c.gl, c.vk_repr)
+        self.d_advice = torch.from_numpy(c.advice.view(np.int64)).to(dev)
         torch.cuda.synchronize(dev)
-        self.seed = 0
+        self.instance = c.instance
+        self.seed = 1000 * stream_id
         self.last = b""
 
     def step(self):
@@ -102,10 +111,11 @@ def cpu_baseline(job: ProofJob, threads: int):
     import orc
 
     orc.load().orc_set_threads(threads)
+    c = job.c
     params = orc.params_new(job.k, 0x5EED)
-    pk = orc.ProvingKey(job.img, job.fixed, job.sigma, params, job.vk_repr)
+    pk = orc.ProvingKey(c.img, c.fixed, c.sigma, params, c.vk_repr)
     t0 = time.perf_counter()
-    st, proof, _ = orc.create_proof(pk, job.advice, job.instance, 1)
+    st, proof, _ = orc.create_proof(pk, c.advice, c.instance, 1)
     dt = time.perf_counter() - t0
     assert st == 0 and len(proof) == len(job.last)
     return {
@@ -122,6 +132,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--k", type=int, default=14)
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent proofs in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -139,26 +151,55 @@ def main():
         dist = dist_mod
         dist.init_process_group("nccl", device_id=dev)
 
-    ctx = zg.Ctx(local_rank)
-    job = ProofJob(ctx, dev, k=args.k, seed=rank)
+    import threading
+
+    nstreams = max(1, min(args.streams, max(1, args.steps)))
+    ctxs = [zg.Ctx(local_rank) for _ in range(nstreams)]
+    circuit = Circuit(ctxs[0], args.k, seed=rank)
+    jobs = [ProofJob(ctxs[i], dev, circuit, rank * 64 + i) for i in range(nstreams)]
+    job = jobs[0]
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
 
-    for _ in range(args.warmup):
-        job.step()
-    ctx.profile(True)
+    def run(total_steps):
+        """total_steps proofs shared by the streams (ctypes drops the GIL inside the library)."""
+        per = [total_steps // nstreams + (1 if i < total_steps % nstreams else 0) for i in range(nstreams)]
+
+        def work(j, cnt):
+            for _ in range(cnt):
+                j.step()
+
+        th = [threading.Thread(target=work, args=(jobs[i], per[i])) for i in range(nstreams)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+
+    run(max(args.warmup, nstreams))
+    # single-proof latency: one stream alone, a few proofs
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(3):
         job.step()
+    latency_s = (time.perf_counter() - t0) / 3
+    for c in ctxs:
+        c.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    stats = ctx.profile_collect()
-    ctx.profile(False)
+    stats = {}
+    for c in ctxs:
+        for name, (l, ms, by) in c.profile_collect().items():
+            a = stats.get(name, (0, 0.0, 0.0))
+            stats[name] = (a[0] + l, a[1] + ms, a[2] + by)
+        c.profile(False)
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -189,8 +230,9 @@ def main():
             "config": {"workload": f"full create_proof, WNN-shaped circuit (6 advice, 23 fixed, 12 gates, 4 lookups, "
                                    f"8 equality columns, degree 6) k={args.k}, extended domain 2^{job.cs.extended_k()}, "
                                    f"proof {len(job.last)} B",
-                       "parallelism": f"{world} independent proof stream(s), one per GPU"},
-            "create_proof_wall_s": ms_per_step / 1e3,
+                       "parallelism": f"{world} GPU(s) x {nstreams} independent proof stream(s) per GPU"},
+            "create_proof_wall_s": latency_s,
+            "streams_per_gpu": nstreams,
             "algorithmic_GBps": algorithmic_bytes_per_proof(job.cs) / (ms_per_step * 1e-3) / 1e9,
             "gpu_kernel_ms_per_step": kernel_ms,
             "roofline": roofline,
