@@ -1,0 +1,61 @@
+"""Point-range sharding of one MSM across ranks (one process per GPU, torch.distributed).
+
+Rank r registers bases[lo_r:hi_r) once (zg_bases_register) and, per MSM, multiplies its scalar slice;
+the normalised 96-byte partial points are all-gathered (RCCL when the backend is "nccl", i.e. over
+xGMI; gloo in CPU tests) and added on every rank with zg_g1_sum.  EC addition is not an ncclRedOp, so
+this is a gather + local adds, never an all-reduce.  NTT, evaluate_h and the grand
+products do not shard (north_star): multi-GPU proving otherwise means independent proofs per GPU.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import zg_halo2 as zg
+
+
+def shard_range(n: int, rank: int, world: int):
+    """Contiguous point range of `rank`: sizes differ by at most one, empty shards allowed."""
+    lo = rank * n // world
+    hi = (rank + 1) * n // world
+    return lo, hi
+
+
+def gather_partials(part: np.ndarray, group=None, device=None) -> np.ndarray:
+    """all_gather of one normalised Jacobian point (uint64[12]) -> uint64[world, 12]."""
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(part, dtype=np.uint64).view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out).cpu().numpy().view(np.uint64)
+
+
+def msm_sharded(local_msm, scalars_shard: np.ndarray, group=None, device=None) -> np.ndarray:
+    """local_msm(scalars_shard) -> this rank's partial (normalised Jacobian); returns the full MSM."""
+    part = local_msm(scalars_shard)
+    parts = gather_partials(part, group, device)
+    return zg.g1_sum(parts)
+
+
+class ShardedBases:
+    """This rank's slice of a base set, resident on its GPU."""
+
+    def __init__(self, ctx: zg.Ctx, bases: np.ndarray, group=None, window_bits: int = 0):
+        self.ctx, self.group = ctx, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.n = bases.shape[0]
+        self.lo, self.hi = shard_range(self.n, self.rank, self.world)
+        self.local = ctx.register_bases(bases[self.lo:self.hi], window_bits) if self.hi > self.lo else None
+
+    def msm(self, scalars: np.ndarray, device=None) -> np.ndarray:
+        assert scalars.shape[0] == self.n
+
+        def local(s):
+            if self.local is None:
+                return zg.g1_sum(np.zeros((0, 12), np.uint64))  # identity
+            return self.ctx.msm(self.local, s)
+
+        return msm_sharded(local, scalars[self.lo:self.hi], self.group, device)
