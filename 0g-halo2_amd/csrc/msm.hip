@@ -9,21 +9,23 @@
 //     ONE bucket set per scalar vector, and the 254-doubling window combine -- a serial chain that
 //     a 64-lane SIMT machine cannot hide -- disappears.
 //   * signed c-bit digits halve the bucket count (buckets 1 .. 2^(c-1)).
-//   * digits are counted with integer atomics, scanned, scattered into bucket order, then split
-//     into tasks of at most K points so that hot buckets (advice columns are mostly 0/1/bytes)
-//     cannot serialise a wavefront; each lane accumulates one task in XYZZ coordinates.
-//   * sum_k k*B_k is taken bit-wise: G_j = sum of task partials whose bucket index has bit j,
-//     result = sum_j 2^j G_j -- strip sums, an LDS tree per (vector, bit), and one wavefront per
-//     vector for the final 2^j ladder.
+//   * digits are counted in per-(vector, window) LDS histograms (no global atomics), scanned,
+//     scattered into bucket order, then split into tasks of at most K points so that hot buckets
+//     (advice columns are mostly 0/1/bytes) cannot serialise a wavefront; each lane accumulates one
+//     task in XYZZ coordinates.
+//   * sum_k k*B_k = sum_k S_k (S = suffix sums of the bucket sums): per block of 256 buckets a
+//     Hillis-Steele suffix scan + tree through LDS ("LDS-staged window partials"), then one
+//     workgroup per vector combines the block results; no 2^j doubling ladder.
 //   * batches of scalar vectors sharing one base set (6+8+7+5+4 per proof) run as one launch
 //     sequence: grid.y = vector index.
 // Integer-ALU bound (a mixed add is 10 field products of ~130 v_mad_u64_u32 each); no MFMA.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace zg {
 
 constexpr uint32_t MSM_K = 16;       // max points per accumulate task
-constexpr uint32_t MSM_STRIP = 16;   // task partials per level-1 reduce strip
 constexpr uint32_t MSM_MAX_C = 16;
 
 __device__ __forceinline__ Fe ld_fe_g(const Fe* p) {
@@ -69,10 +71,6 @@ __global__ void msm_table_kernel(const Affine* __restrict__ bases, Affine* __res
 }
 
 // ---------------------------------------------------------------- digits
-struct Digits {
-    uint32_t raw[8];
-};
-
 // bits [lo, lo+c) of the canonical scalar (zero beyond bit 255)
 __device__ __forceinline__ uint32_t window_bits(const uint32_t raw[8], uint32_t lo, uint32_t c) {
     uint32_t limb = lo >> 5, sh = lo & 31;
@@ -82,62 +80,80 @@ __device__ __forceinline__ uint32_t window_bits(const uint32_t raw[8], uint32_t 
     return (uint32_t)(v >> sh) & ((1u << c) - 1);
 }
 
-// Pass 1 over the scalars: signed digits, bucket histogram; the slot each entry takes inside its
-// bucket is the value its atomic returned.
-__global__ void msm_count_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n, uint32_t c,
-                                 uint32_t windows, uint32_t* __restrict__ cnt, uint32_t* __restrict__ slot) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t b = blockIdx.y;
-    if (i >= n) return;
-    const uint32_t nb = 1u << (c - 1);
-    Fe s = Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i));
-    uint32_t* cb = cnt + (size_t)b * (nb + 1);
-    uint32_t* sb = slot + (size_t)b * windows * n;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < windows; w++) {
-        uint32_t d = window_bits(s.l, w * c, c) + carry;
-        carry = 0;
-        uint32_t k = d;
-        if (d > nb) {
-            k = (1u << c) - d;
-            carry = 1;
-        }
-        uint32_t sl = 0xffffffffu;
-        if (k != 0) sl = atomicAdd(&cb[k], 1u);
-        sb[(size_t)w * n + i] = sl;
+// signed digit of window w: value in [-(nb-1), nb], returned as bucket index k (0 = none) and sign
+__device__ __forceinline__ void digit_at(const uint32_t raw[8], uint32_t w, uint32_t c, uint32_t nb, uint32_t& k,
+                                         uint32_t& neg) {
+    uint32_t carry = 0, d = 0;
+    for (uint32_t ww = 0; ww <= w; ww++) {
+        d = window_bits(raw, ww * c, c) + carry;
+        carry = d > nb ? 1u : 0u;
     }
+    neg = carry;
+    k = carry ? (1u << c) - d : d;
 }
 
-// Exclusive scans of the bucket histogram (entry offsets) and of ceil(count / K) (task offsets).
-// One 1024-thread workgroup per scalar vector.
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t c,
-                                                        uint32_t* __restrict__ boff,
-                                                        uint32_t* __restrict__ toff,
+// canonical (non-Montgomery) scalars, once per MSM
+__global__ __launch_bounds__(256) void msm_raw_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n,
+                                                      Fe* __restrict__ raw) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= n) return;
+    st_fe_g(raw + (size_t)b * n + i, Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i)));
+}
+
+// One workgroup per (window, vector): bucket histogram of that window in LDS (LDS atomics return the
+// entry's slot inside its (window, bucket) cell), then one coalesced write of the counts.  No global
+// atomics: on this chip scattered device-scope atomics top out near 2*10^10/s, which made the old
+// global-histogram pass the second most expensive MSM kernel.
+__global__ __launch_bounds__(1024) void msm_hist_kernel(const Fe* __restrict__ raw, uint32_t n, uint32_t c,
+                                                        uint32_t windows, uint32_t* __restrict__ cnt,
+                                                        uint32_t* __restrict__ slot) {
+    extern __shared__ uint32_t hist[];
+    const uint32_t w = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const uint32_t nb = 1u << (c - 1);
+    for (uint32_t k = tid; k <= nb; k += 1024) hist[k] = 0;
+    __syncthreads();
+    const Fe* rb = raw + (size_t)b * n;
+    uint32_t* sb = slot + ((size_t)b * windows + w) * n;
+    for (uint32_t i = tid; i < n; i += 1024) {
+        Fe s = ld_fe_g(rb + i);
+        uint32_t k, neg;
+        digit_at(s.l, w, c, nb, k, neg);
+        if (k != 0) sb[i] = atomicAdd(&hist[k], 1u);
+    }
+    __syncthreads();
+    uint32_t* cb = cnt + ((size_t)b * windows + w) * (nb + 1);
+    for (uint32_t k = tid; k <= nb; k += 1024) cb[k] = hist[k];
+}
+
+// Per vector: bucket totals over the windows, exclusive scans (entry offsets and ceil(total/K) task
+// offsets), and the absolute offset of every (window, bucket) cell.  One 1024-lane workgroup.
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t c, uint32_t windows,
+                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ toff,
                                                         uint32_t* __restrict__ ttotal) {
     __shared__ uint32_t se[1024], st[1024];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t* cb = cnt + (size_t)b * (nb + 1);
-    uint32_t* bo = boff + (size_t)b * (nb + 2);
+    const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
+    uint32_t* ob = off + (size_t)b * windows * (nb + 1);
     uint32_t* to = toff + (size_t)b * (nb + 2);
     const uint32_t per = (nb + 1 + 1023) / 1024;
     uint32_t lo = tid * per, hi = lo + per;
     if (hi > nb + 1) hi = nb + 1;
     uint32_t es = 0, ts = 0;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t v = cb[k];
+        uint32_t v = 0;
+        for (uint32_t w = 0; w < windows; w++) v += cb[(size_t)w * (nb + 1) + k];
         es += v;
         ts += (v + MSM_K - 1) / MSM_K;
     }
     se[tid] = es;
     st[tid] = ts;
     __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partials
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
         uint32_t ve = 0, vt = 0;
-        if (tid >= off) {
-            ve = se[tid - off];
-            vt = st[tid - off];
+        if (tid >= o) {
+            ve = se[tid - o];
+            vt = st[tid - o];
         }
         __syncthreads();
         se[tid] += ve;
@@ -146,54 +162,44 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     uint32_t eb = se[tid] - es, tb = st[tid] - ts;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t v = cb[k];
-        bo[k] = eb;
+        uint32_t v = 0;
+        for (uint32_t w = 0; w < windows; w++) {
+            ob[(size_t)w * (nb + 1) + k] = eb + v;
+            v += cb[(size_t)w * (nb + 1) + k];
+        }
         to[k] = tb;
         eb += v;
         tb += (v + MSM_K - 1) / MSM_K;
     }
     if (tid == 1023) {
-        bo[nb + 1] = se[1023];
         to[nb + 1] = st[1023];
         ttotal[b] = st[1023];
     }
 }
 
-// Pass 2 over the scalars: write (point, window, sign) into bucket order.
-__global__ void msm_scatter_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n, uint32_t c,
-                                   uint32_t windows, const uint32_t* __restrict__ boff,
-                                   const uint32_t* __restrict__ slot, uint32_t* __restrict__ sorted) {
+// Write (point, window, sign) into bucket order: position = cell offset + slot inside the cell.
+__global__ __launch_bounds__(256) void msm_scatter_kernel(const Fe* __restrict__ raw, uint32_t n, uint32_t c,
+                                                          uint32_t windows, const uint32_t* __restrict__ off,
+                                                          const uint32_t* __restrict__ slot,
+                                                          uint32_t* __restrict__ sorted) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t b = blockIdx.y;
+    uint32_t w = blockIdx.y, b = blockIdx.z;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
-    Fe s = Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i));
-    const uint32_t* bo = boff + (size_t)b * (nb + 2);
-    const uint32_t* sb = slot + (size_t)b * windows * n;
-    uint32_t* so = sorted + (size_t)b * windows * n;
-    uint32_t carry = 0;
-    for (uint32_t w = 0; w < windows; w++) {
-        uint32_t d = window_bits(s.l, w * c, c) + carry;
-        carry = 0;
-        uint32_t k = d, neg = 0;
-        if (d > nb) {
-            k = (1u << c) - d;
-            carry = 1;
-            neg = 1;
-        }
-        if (k != 0) {
-            uint32_t sl = sb[(size_t)w * n + i];
-            so[bo[k] + sl] = i | (w << 24) | (neg << 31);
-        }
-    }
+    Fe s = ld_fe_g(raw + (size_t)b * n + i);
+    uint32_t k, neg;
+    digit_at(s.l, w, c, nb, k, neg);
+    if (k == 0) return;
+    uint32_t pos = off[((size_t)b * windows + w) * (nb + 1) + k] + slot[((size_t)b * windows + w) * n + i];
+    sorted[(size_t)b * windows * n + pos] = i | (w << 24) | (neg << 31);
 }
 
 // One lane per task: at most K points of one bucket, mixed adds in XYZZ.
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* __restrict__ table, uint32_t n_table, uint32_t c, uint32_t windows, uint32_t n,
-    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ boff, const uint32_t* __restrict__ toff,
+    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff,
     const uint32_t* __restrict__ ttotal, const uint32_t* __restrict__ sorted, uint32_t max_tasks,
-    XYZZ* __restrict__ partial, uint32_t* __restrict__ pkey) {
+    XYZZ* __restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t b = blockIdx.y;
     if (t >= ttotal[b]) return;
@@ -208,9 +214,13 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     }
     const uint32_t k = lo;
     const uint32_t j = t - to[k];
-    const uint32_t count = cnt[(size_t)b * (nb + 1) + k];
-    const uint32_t start = boff[(size_t)b * (nb + 2) + k] + j * MSM_K;
-    uint32_t len = count - j * MSM_K;
+    // bucket k's entries are contiguous: [off[0][k], off[0][k] + total_k)
+    const uint32_t first = off[(size_t)b * windows * (nb + 1) + k];
+    const uint32_t last_w = windows - 1;
+    const uint32_t total = off[((size_t)b * windows + last_w) * (nb + 1) + k] +
+                           cnt[((size_t)b * windows + last_w) * (nb + 1) + k] - first;
+    const uint32_t start = first + j * MSM_K;
+    uint32_t len = total - j * MSM_K;
     if (len > MSM_K) len = MSM_K;
     const uint32_t* so = sorted + (size_t)b * windows * n + start;
     XYZZ acc = xyzz_identity();
@@ -225,71 +235,124 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
         acc = xyzz_madd(acc, p);
     }
     st_xyzz(partial + (size_t)b * max_tasks + t, acc);
-    pkey[(size_t)b * max_tasks + t] = k;
 }
 
-// Level 1 of sum_k k*B_k: lane (strip, bit j, vector b) adds the partials of its strip whose
-// bucket index has bit j set.
-__global__ __launch_bounds__(256) void msm_reduce1_kernel(const XYZZ* __restrict__ partial,
-                                                          const uint32_t* __restrict__ pkey,
-                                                          const uint32_t* __restrict__ ttotal,
-                                                          uint32_t max_tasks, uint32_t max_strips,
-                                                          uint32_t c, XYZZ* __restrict__ l1) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t j = blockIdx.y, b = blockIdx.z;
-    uint32_t total = ttotal[b];
-    uint32_t nstrips = (total + MSM_STRIP - 1) / MSM_STRIP;
-    if (s >= nstrips) return;
-    uint32_t t0 = s * MSM_STRIP, t1 = t0 + MSM_STRIP;
-    if (t1 > total) t1 = total;
+// sum_k k*B_k = sum_k S_k with S_k = sum_{k' >= k} B_k' (the classic running sum of running sums), cut
+// into blocks of 256 buckets so that it parallelises: per block, lane j merges the task partials of
+// bucket k0 + j + 1 (buckets with many tasks -- hot buckets of sparse scalars -- are summed by the
+// whole workgroup), a Hillis-Steele suffix scan through LDS gives S_j, a tree gives
+// W = sum_j S_j = sum_j (j+1) B_j, and P = S_0 is the block total.
+constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
+constexpr uint32_t MSM_HEAVY = 8;    // more tasks than this: cooperative merge
+
+__global__ __launch_bounds__(MSM_RB) void msm_bucket_reduce_kernel(const XYZZ* __restrict__ partial,
+                                                                  const uint32_t* __restrict__ toff,
+                                                                  uint32_t max_tasks, uint32_t c,
+                                                                  XYZZ* __restrict__ blk_w, XYZZ* __restrict__ blk_p,
+                                                                  uint32_t nblk) {
+    __shared__ XYZZ sh[MSM_RB];
+    __shared__ uint32_t heavy[MSM_RB];
+    __shared__ uint32_t n_heavy;
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    const uint32_t k = blk * MSM_RB + tid + 1;
+    const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ* pp = partial + (size_t)b * max_tasks;
-    const uint32_t* pk = pkey + (size_t)b * max_tasks;
-    XYZZ acc = xyzz_identity();
-    for (uint32_t t = t0; t < t1; t++)
-        if ((pk[t] >> j) & 1u) acc = xyzz_add(acc, ld_xyzz(pp + t));
-    st_xyzz(l1 + ((size_t)b * c + j) * max_strips + s, acc);
-}
-
-// Level 2: one 256-thread workgroup per (vector, bit): strided serial sums, then an LDS tree.
-__global__ __launch_bounds__(256) void msm_reduce2_kernel(const XYZZ* __restrict__ l1,
-                                                          const uint32_t* __restrict__ ttotal,
-                                                          uint32_t max_strips, uint32_t c,
-                                                          XYZZ* __restrict__ g) {
-    __shared__ XYZZ sh[256];
-    uint32_t j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    uint32_t nstrips = (ttotal[b] + MSM_STRIP - 1) / MSM_STRIP;
-    const XYZZ* src = l1 + ((size_t)b * c + j) * max_strips;
-    XYZZ acc = xyzz_identity();
-    for (uint32_t s = tid; s < nstrips; s += 256) acc = xyzz_add(acc, ld_xyzz(src + s));
-    sh[tid] = acc;
+    if (tid == 0) n_heavy = 0;
     __syncthreads();
-    for (uint32_t off = 128; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
-        __syncthreads();
-    }
-    if (tid == 0) st_xyzz(g + (size_t)b * c + j, sh[0]);
-}
-
-// Final ladder: lane j doubles G_j j times, then the c lanes are added pairwise through LDS.
-__global__ __launch_bounds__(64) void msm_final_kernel(const XYZZ* __restrict__ g, uint32_t c,
-                                                       XYZZ* __restrict__ out) {
-    __shared__ XYZZ sh[64];
-    uint32_t b = blockIdx.x, tid = threadIdx.x;
     XYZZ acc = xyzz_identity();
-    if (tid < c) {
-        acc = ld_xyzz(g + (size_t)b * c + tid);
-        for (uint32_t d = 0; d < tid; d++) acc = xyzz_dbl(acc);
+    if (k <= nb) {
+        uint32_t t0 = to[k], t1 = to[k + 1];
+        if (t1 - t0 > MSM_HEAVY) {
+            heavy[atomicAdd(&n_heavy, 1u)] = tid;
+        } else {
+            for (uint32_t t = t0; t < t1; t++) acc = xyzz_add(acc, ld_xyzz(pp + t));
+        }
     }
     sh[tid] = acc;
     __syncthreads();
-    for (uint32_t off = 32; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] = xyzz_add(sh[tid], sh[tid + off]);
+    // hot buckets: every lane takes a strided share of the tasks, tree through LDS
+    const uint32_t nh = n_heavy;
+    for (uint32_t h = 0; h < nh; h++) {
+        const uint32_t owner = heavy[h];
+        const uint32_t kk = blk * MSM_RB + owner + 1;
+        const uint32_t t0 = to[kk], t1 = to[kk + 1];
+        XYZZ save = sh[tid];
+        __syncthreads();
+        XYZZ a2 = xyzz_identity();
+        for (uint32_t t = t0 + tid; t < t1; t += MSM_RB) a2 = xyzz_add(a2, ld_xyzz(pp + t));
+        sh[tid] = a2;
+        __syncthreads();
+        for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
+            if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+            __syncthreads();
+        }
+        XYZZ total = sh[0];
+        __syncthreads();
+        sh[tid] = (tid == owner) ? total : save;
         __syncthreads();
     }
-    if (tid == 0) st_xyzz(out + b, sh[0]);
+    // suffix scan: S_j = sum_{j' >= j} B_j'
+    for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
+        XYZZ v = xyzz_identity();
+        const bool has = tid + o < MSM_RB;
+        if (has) v = sh[tid + o];
+        __syncthreads();
+        if (has) sh[tid] = xyzz_add(sh[tid], v);
+        __syncthreads();
+    }
+    XYZZ s0 = sh[0];
+    __syncthreads();
+    // W = sum_j S_j
+    for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        st_xyzz(blk_w + (size_t)b * nblk + blk, sh[0]);
+        st_xyzz(blk_p + (size_t)b * nblk + blk, s0);
+    }
+}
+
+// result = sum_blk W_blk + 256 * sum_blk blk * P_blk, the second sum again as a sum of suffix sums.
+__global__ __launch_bounds__(256) void msm_finish_kernel(const XYZZ* __restrict__ blk_w, const XYZZ* __restrict__ blk_p,
+                                                         uint32_t nblk, XYZZ* __restrict__ out) {
+    __shared__ XYZZ shw[256], shp[256];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    shw[tid] = tid < nblk ? ld_xyzz(blk_w + (size_t)b * nblk + tid) : xyzz_identity();
+    shp[tid] = tid < nblk ? ld_xyzz(blk_p + (size_t)b * nblk + tid) : xyzz_identity();
+    __syncthreads();
+    uint32_t span = 1;
+    while (span < nblk) span <<= 1;
+    for (uint32_t o = 1; o < span; o <<= 1) {  // suffix sums of P
+        XYZZ v = xyzz_identity();
+        const bool has = tid + o < span;
+        if (has) v = shp[tid + o];
+        __syncthreads();
+        if (has && tid < span) shp[tid] = xyzz_add(shp[tid], v);
+        __syncthreads();
+    }
+    if (tid == 0) shp[0] = xyzz_identity();  // Q = sum_{t >= 1} SufP_t
+    __syncthreads();
+    for (uint32_t o = span / 2; o > 0; o >>= 1) {
+        if (tid < o) {
+            shp[tid] = xyzz_add(shp[tid], shp[tid + o]);
+            shw[tid] = xyzz_add(shw[tid], shw[tid + o]);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        XYZZ q = shp[0];
+        for (uint32_t d = 0; d < 8; d++) q = xyzz_dbl(q);  // * MSM_RB
+        st_xyzz(out + b, xyzz_add(shw[0], q));
+    }
 }
 
 static uint32_t default_window_bits(size_t n) {
+    if (const char* e = getenv("ZG_MSM_C")) {  // tuning override
+        int v = atoi(e);
+        if (v >= 2 && v <= (int)MSM_MAX_C) return (uint32_t)v;
+    }
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     int c = (int)lg - 1;
@@ -346,37 +409,41 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
     uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
     const uint32_t max_tasks = (uint32_t)mt;
-    const uint32_t max_strips = (max_tasks + MSM_STRIP - 1) / MSM_STRIP;
+    const uint32_t nblk = (nb + MSM_RB - 1) / MSM_RB;
+    ZG_REQUIRE(nblk <= 256, ZG_ERR_UNSUPPORTED, "zg_msm: window_bits %u too large", c);
 
     WsScope ws(ctx);
-    uint32_t* cnt = ws.get<uint32_t>((size_t)B * (nb + 1));
+    Fe* raw = ws.get<Fe>((size_t)B * N);
+    uint32_t* cnt = ws.get<uint32_t>((size_t)B * W * (nb + 1));
     uint32_t* slot = ws.get<uint32_t>((size_t)B * entries);
-    uint32_t* boff = ws.get<uint32_t>((size_t)B * (nb + 2));
+    uint32_t* off = ws.get<uint32_t>((size_t)B * W * (nb + 1));
     uint32_t* toff = ws.get<uint32_t>((size_t)B * (nb + 2));
     uint32_t* ttotal = ws.get<uint32_t>(B);
     uint32_t* sorted = ws.get<uint32_t>((size_t)B * entries);
     XYZZ* partial = ws.get<XYZZ>((size_t)B * max_tasks);
-    uint32_t* pkey = ws.get<uint32_t>((size_t)B * max_tasks);
-    XYZZ* l1 = ws.get<XYZZ>((size_t)B * c * max_strips);
-    XYZZ* g = ws.get<XYZZ>((size_t)B * c);
+    XYZZ* blk_w = ws.get<XYZZ>((size_t)B * nblk);
+    XYZZ* blk_p = ws.get<XYZZ>((size_t)B * nblk);
     if (ws.failed) return ZG_ERR_OOM;
 
-    ZG_HIP(hipMemsetAsync(cnt, 0, (size_t)B * (nb + 1) * sizeof(uint32_t), ctx->stream));
-    dim3 gs((N + 255) / 256, B);
+    static bool lds_attr = false;
+    if (!lds_attr) {
+        ZG_HIP(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        lds_attr = true;
+    }
     // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out.  Every
     // stage kernel processes the same B MSMs per launch, so each is charged the same figure.
     const double msm_bytes = (double)B * ((double)N * 96.0 + 96.0);
-    ZG_LAUNCH(ctx, "msm_count", msm_bytes, msm_count_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, cnt, slot);
-    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, boff, toff, ttotal);
-    ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, gs, dim3(256), 0, d_scalars, stride, N, c, W, boff,
-              slot, sorted);
-    ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B),
-              dim3(256), 0, bases->table, (uint32_t)bases->n, c, W, N, cnt, boff, toff, ttotal, sorted,
-              max_tasks, partial, pkey);
-    ZG_LAUNCH(ctx, "msm_reduce1", msm_bytes, msm_reduce1_kernel, dim3((max_strips + 255) / 256, c, B), dim3(256), 0,
-              partial, pkey, ttotal, max_tasks, max_strips, c, l1);
-    ZG_LAUNCH(ctx, "msm_reduce2", msm_bytes, msm_reduce2_kernel, dim3(c, B), dim3(256), 0, l1, ttotal, max_strips, c, g);
-    ZG_LAUNCH(ctx, "msm_final", msm_bytes, msm_final_kernel, dim3(B), dim3(64), 0, g, c, d_out);
+    ZG_LAUNCH(ctx, "msm_raw", msm_bytes, msm_raw_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, raw);
+    ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, raw, N, c, W, cnt,
+              slot);
+    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, W, off, toff, ttotal);
+    ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, raw, N, c, W,
+              off, slot, sorted);
+    ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
+              bases->table, (uint32_t)bases->n, c, W, N, cnt, off, toff, ttotal, sorted, max_tasks, partial);
+    ZG_LAUNCH(ctx, "msm_bucket_reduce", msm_bytes, msm_bucket_reduce_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff,
+              max_tasks, c, blk_w, blk_p, nblk);
+    ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel, dim3(B), dim3(256), 0, blk_w, blk_p, nblk, d_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
