@@ -27,6 +27,7 @@ namespace zg {
 
 constexpr uint32_t MSM_K = 16;       // max points per accumulate task
 constexpr uint32_t MSM_MAX_C = 16;
+constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
 
 __device__ __forceinline__ Fe ld_fe_g(const Fe* p) {
     Fe r;
@@ -129,8 +130,12 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const Fe* __restrict__ r
 // offsets), and the absolute offset of every (window, bucket) cell.  One 1024-lane workgroup.
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t c, uint32_t windows,
                                                         uint32_t* __restrict__ off, uint32_t* __restrict__ toff,
-                                                        uint32_t* __restrict__ ttotal) {
+                                                        uint32_t* __restrict__ ttotal, uint32_t* __restrict__ hmap,
+                                                        uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
+                                                        uint32_t max_heavy) {
     __shared__ uint32_t se[1024], st[1024];
+    __shared__ uint32_t hcount;
+    if (threadIdx.x == 0) hcount = 0;
     const uint32_t nb = 1u << (c - 1);
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
@@ -169,11 +174,21 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
         }
         to[k] = tb;
         eb += v;
-        tb += (v + MSM_K - 1) / MSM_K;
+        const uint32_t nt = (v + MSM_K - 1) / MSM_K;
+        tb += nt;
+        // hot bucket (repeated or tiny scalars): merged by its own workgroup in msm_heavy_kernel
+        uint32_t slot_h = 0xffffffffu;
+        if (nt > MSM_HEAVY) {
+            slot_h = atomicAdd(&hcount, 1u);
+            if (slot_h < max_heavy) hlist[(size_t)b * max_heavy + slot_h] = k;
+        }
+        hmap[(size_t)b * (nb + 1) + k] = slot_h;
     }
+    __syncthreads();
     if (tid == 1023) {
         to[nb + 1] = st[1023];
         ttotal[b] = st[1023];
+        nheavy[b] = hcount;
     }
 }
 
@@ -243,55 +258,63 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
 // whole workgroup), a Hillis-Steele suffix scan through LDS gives S_j, a tree gives
 // W = sum_j S_j = sum_j (j+1) B_j, and P = S_0 is the block total.
 constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
-constexpr uint32_t MSM_HEAVY = 8;    // more tasks than this: cooperative merge
+
+// One workgroup per hot bucket: lanes take a strided share of its task partials, tree through LDS.
+__global__ __launch_bounds__(256) void msm_heavy_kernel(const XYZZ* __restrict__ partial, const uint32_t* __restrict__ toff,
+                                                        const uint32_t* __restrict__ hlist,
+                                                        const uint32_t* __restrict__ nheavy, uint32_t max_tasks,
+                                                        uint32_t max_heavy, uint32_t c, XYZZ* __restrict__ hsum) {
+    __shared__ XYZZ sh[256];
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t tid = threadIdx.x, b = blockIdx.y;
+    const uint32_t nh = nheavy[b];
+    const uint32_t* to = toff + (size_t)b * (nb + 2);
+    const XYZZ* pp = partial + (size_t)b * max_tasks;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        const uint32_t k = hlist[(size_t)b * max_heavy + h];
+        const uint32_t t0 = to[k], t1 = to[k + 1];
+        {
+            XYZZ acc = xyzz_identity();
+            for (uint32_t t = t0 + tid; t < t1; t += 256) acc = xyzz_add(acc, ld_xyzz(pp + t));
+            sh[tid] = acc;
+        }
+        __syncthreads();
+        for (uint32_t o = 128; o > 0; o >>= 1) {
+            if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+            __syncthreads();
+        }
+        if (tid == 0) st_xyzz(hsum + (size_t)b * max_heavy + h, sh[0]);
+        __syncthreads();
+    }
+}
 
 __global__ __launch_bounds__(MSM_RB) void msm_bucket_reduce_kernel(const XYZZ* __restrict__ partial,
                                                                   const uint32_t* __restrict__ toff,
-                                                                  uint32_t max_tasks, uint32_t c,
+                                                                  const uint32_t* __restrict__ hmap,
+                                                                  const XYZZ* __restrict__ hsum, uint32_t max_tasks,
+                                                                  uint32_t max_heavy, uint32_t c,
                                                                   XYZZ* __restrict__ blk_w, XYZZ* __restrict__ blk_p,
                                                                   uint32_t nblk) {
     __shared__ XYZZ sh[MSM_RB];
-    __shared__ uint32_t heavy[MSM_RB];
-    __shared__ uint32_t n_heavy;
     const uint32_t nb = 1u << (c - 1);
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     const uint32_t k = blk * MSM_RB + tid + 1;
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ* pp = partial + (size_t)b * max_tasks;
-    if (tid == 0) n_heavy = 0;
-    __syncthreads();
-    XYZZ acc = xyzz_identity();
-    if (k <= nb) {
-        uint32_t t0 = to[k], t1 = to[k + 1];
-        if (t1 - t0 > MSM_HEAVY) {
-            heavy[atomicAdd(&n_heavy, 1u)] = tid;
-        } else {
-            for (uint32_t t = t0; t < t1; t++) acc = xyzz_add(acc, ld_xyzz(pp + t));
+    {
+        XYZZ acc = xyzz_identity();
+        if (k <= nb) {
+            const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
+            if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
+                acc = ld_xyzz(hsum + (size_t)b * max_heavy + hs);
+            } else {
+                const uint32_t t0 = to[k], t1 = to[k + 1];
+                for (uint32_t t = t0; t < t1; t++) acc = xyzz_add(acc, ld_xyzz(pp + t));
+            }
         }
+        sh[tid] = acc;
     }
-    sh[tid] = acc;
     __syncthreads();
-    // hot buckets: every lane takes a strided share of the tasks, tree through LDS
-    const uint32_t nh = n_heavy;
-    for (uint32_t h = 0; h < nh; h++) {
-        const uint32_t owner = heavy[h];
-        const uint32_t kk = blk * MSM_RB + owner + 1;
-        const uint32_t t0 = to[kk], t1 = to[kk + 1];
-        XYZZ save = sh[tid];
-        __syncthreads();
-        XYZZ a2 = xyzz_identity();
-        for (uint32_t t = t0 + tid; t < t1; t += MSM_RB) a2 = xyzz_add(a2, ld_xyzz(pp + t));
-        sh[tid] = a2;
-        __syncthreads();
-        for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
-            if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
-            __syncthreads();
-        }
-        XYZZ total = sh[0];
-        __syncthreads();
-        sh[tid] = (tid == owner) ? total : save;
-        __syncthreads();
-    }
     // suffix scan: S_j = sum_{j' >= j} B_j'
     for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
         XYZZ v = xyzz_identity();
@@ -301,17 +324,14 @@ __global__ __launch_bounds__(MSM_RB) void msm_bucket_reduce_kernel(const XYZZ* _
         if (has) sh[tid] = xyzz_add(sh[tid], v);
         __syncthreads();
     }
-    XYZZ s0 = sh[0];
+    if (tid == 0) st_xyzz(blk_p + (size_t)b * nblk + blk, sh[0]);  // P = S_0
     __syncthreads();
     // W = sum_j S_j
     for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
         if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
         __syncthreads();
     }
-    if (tid == 0) {
-        st_xyzz(blk_w + (size_t)b * nblk + blk, sh[0]);
-        st_xyzz(blk_p + (size_t)b * nblk + blk, s0);
-    }
+    if (tid == 0) st_xyzz(blk_w + (size_t)b * nblk + blk, sh[0]);
 }
 
 // result = sum_blk W_blk + 256 * sum_blk blk * P_blk, the second sum again as a sum of suffix sums.
@@ -423,6 +443,12 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
     XYZZ* partial = ws.get<XYZZ>((size_t)B * max_tasks);
     XYZZ* blk_w = ws.get<XYZZ>((size_t)B * nblk);
     XYZZ* blk_p = ws.get<XYZZ>((size_t)B * nblk);
+    // a hot bucket holds more than MSM_HEAVY * MSM_K entries
+    const uint32_t max_heavy = (uint32_t)(entries / ((uint64_t)MSM_HEAVY * MSM_K)) + 1;
+    uint32_t* hmap = ws.get<uint32_t>((size_t)B * (nb + 1));
+    uint32_t* hlist = ws.get<uint32_t>((size_t)B * max_heavy);
+    uint32_t* nheavy = ws.get<uint32_t>(B);
+    XYZZ* hsum = ws.get<XYZZ>((size_t)B * max_heavy);
     if (ws.failed) return ZG_ERR_OOM;
 
     static bool lds_attr = false;
@@ -436,13 +462,16 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
     ZG_LAUNCH(ctx, "msm_raw", msm_bytes, msm_raw_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, raw);
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, raw, N, c, W, cnt,
               slot);
-    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, W, off, toff, ttotal);
+    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, W, off, toff, ttotal, hmap, hlist,
+              nheavy, max_heavy);
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, raw, N, c, W,
               off, slot, sorted);
     ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
               bases->table, (uint32_t)bases->n, c, W, N, cnt, off, toff, ttotal, sorted, max_tasks, partial);
-    ZG_LAUNCH(ctx, "msm_bucket_reduce", msm_bytes, msm_bucket_reduce_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff,
-              max_tasks, c, blk_w, blk_p, nblk);
+    ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel, dim3(max_heavy < 64 ? max_heavy : 64, B), dim3(256), 0, partial,
+              toff, hlist, nheavy, max_tasks, max_heavy, c, hsum);
+    ZG_LAUNCH(ctx, "msm_bucket_reduce", msm_bytes, msm_bucket_reduce_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff, hmap,
+              hsum, max_tasks, max_heavy, c, blk_w, blk_p, nblk);
     ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel, dim3(B), dim3(256), 0, blk_w, blk_p, nblk, d_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
