@@ -81,12 +81,14 @@ struct zg_ctx {
     std::mutex mu;
     // optional per-kernel HIP-event timing (zg_ctx_profile_*): events bracket every launch
     bool profiling = false;
+    std::string prof_filter;  // when non-empty only launches of this kernel are bracketed
     struct ProfRec {
         const char* name;
         hipEvent_t e0, e1;
         double bytes;
     };
     std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;  // recycled by zg_ctx_profile_collect
 };
 
 struct zg_bases {
@@ -126,13 +128,13 @@ int pinned_reserve(zg_ctx* ctx, size_t bytes);
 
 // Launch wrapper: when profiling is on, two hipEvents bracket the kernel on the context stream and
 // `algo_bytes` (the ALGORITHMIC bytes this launch is charged with) is recorded beside it.
-void prof_begin(zg_ctx* ctx, const char* name, double algo_bytes);
+bool prof_begin(zg_ctx* ctx, const char* name, double algo_bytes);  // false: filtered out
 void prof_end(zg_ctx* ctx);
 #define ZG_LAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                 \
     do {                                                                           \
-        if ((ctx)->profiling) ::zg::prof_begin((ctx), (name), (double)(bytes));    \
+        const bool _zg_p = (ctx)->profiling && ::zg::prof_begin((ctx), (name), (double)(bytes)); \
         hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);  \
-        if ((ctx)->profiling) ::zg::prof_end((ctx));                               \
+        if (_zg_p) ::zg::prof_end((ctx));                                          \
     } while (0)
 
 // twiddle table for (log_n, omega), created on first use

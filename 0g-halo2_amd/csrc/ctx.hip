@@ -56,14 +56,27 @@ int pinned_reserve(zg_ctx* ctx, size_t bytes) {
     return ZG_OK;
 }
 
-void prof_begin(zg_ctx* ctx, const char* name, double algo_bytes) {
+static hipEvent_t pool_event(zg_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+bool prof_begin(zg_ctx* ctx, const char* name, double algo_bytes) {
+    if (!ctx->prof_filter.empty() && ctx->prof_filter != name) return false;
     zg_ctx::ProfRec r;
     r.name = name;
     r.bytes = algo_bytes;
-    (void)hipEventCreate(&r.e0);
-    (void)hipEventCreate(&r.e1);
+    r.e0 = pool_event(ctx);
+    r.e1 = pool_event(ctx);
     (void)hipEventRecord(r.e0, ctx->stream);
     ctx->prof.push_back(r);
+    return true;
 }
 
 void prof_end(zg_ctx* ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->stream); }
@@ -116,6 +129,11 @@ void zg_ctx_destroy(zg_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto& b : ctx->pool) (void)hipFree(b.p);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -137,6 +155,12 @@ int zg_ctx_profile_enable(zg_ctx* ctx, int on) {
     return ZG_OK;
 }
 
+int zg_ctx_profile_filter(zg_ctx* ctx, const char* kernel_name) {
+    ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_profile_filter: ctx is null");
+    ctx->prof_filter = kernel_name ? kernel_name : "";
+    return ZG_OK;
+}
+
 // Synchronises, folds the recorded launches into per-kernel totals and clears the log.
 int zg_ctx_profile_collect(zg_ctx* ctx, zg_kernel_stat* out, size_t cap, size_t* count) {
     ZG_REQUIRE(ctx && count, ZG_ERR_INVALID_ARG, "zg_ctx_profile_collect: null argument");
@@ -145,8 +169,8 @@ int zg_ctx_profile_collect(zg_ctx* ctx, zg_kernel_stat* out, size_t cap, size_t*
     for (auto& r : ctx->prof) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);
-        (void)hipEventDestroy(r.e0);
-        (void)hipEventDestroy(r.e1);
+        ctx->event_pool.push_back(r.e0);
+        ctx->event_pool.push_back(r.e1);
         zg_kernel_stat* s = nullptr;
         for (auto& a : acc)
             if (strcmp(a.name, r.name) == 0) s = &a;

@@ -93,19 +93,39 @@ __device__ __forceinline__ void digit_at(const uint32_t raw[8], uint32_t w, uint
     k = carry ? (1u << c) - d : d;
 }
 
-// canonical (non-Montgomery) scalars, once per MSM
-__global__ __launch_bounds__(256) void msm_raw_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n,
-                                                      Fe* __restrict__ raw) {
+// All signed digits of a scalar, once: dig[b][w][i] = bucket index k (0 = no entry) | sign << 31.
+__global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n,
+                                                         uint32_t c, uint32_t windows, uint32_t* __restrict__ dig) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= n) return;
-    st_fe_g(raw + (size_t)b * n + i, Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i)));
+    const uint32_t nb = 1u << (c - 1);
+    Fe s = Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i));
+    // walk the 256-bit value with a 64-bit sliding register (no runtime-indexed limb array)
+    uint64_t bits = (uint64_t)s.l[0] | ((uint64_t)s.l[1] << 32);
+    uint32_t have = 64, next = 2, carry = 0;
+    uint32_t* db = dig + (size_t)b * windows * n + i;
+    for (uint32_t w = 0; w < windows; w++) {
+        if (have < c && next < 8) {  // refill: c <= 16 so 32 fresh bits always fit
+            uint32_t limb = next == 2 ? s.l[2] : next == 3 ? s.l[3] : next == 4 ? s.l[4] : next == 5 ? s.l[5]
+                          : next == 6 ? s.l[6] : s.l[7];
+            bits |= (uint64_t)limb << have;
+            have += 32;
+            next++;
+        }
+        uint32_t d = (uint32_t)(bits & ((1u << c) - 1)) + carry;
+        bits >>= c;
+        have = have >= c ? have - c : 0;
+        carry = d > nb ? 1u : 0u;
+        uint32_t k = carry ? (1u << c) - d : d;
+        db[(size_t)w * n] = k | (carry << 31);
+    }
 }
 
 // One workgroup per (window, vector): bucket histogram of that window in LDS (LDS atomics return the
 // entry's slot inside its (window, bucket) cell), then one coalesced write of the counts.  No global
 // atomics: on this chip scattered device-scope atomics top out near 2*10^10/s, which made the old
 // global-histogram pass the second most expensive MSM kernel.
-__global__ __launch_bounds__(1024) void msm_hist_kernel(const Fe* __restrict__ raw, uint32_t n, uint32_t c,
+__global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t* __restrict__ dig, uint32_t n, uint32_t c,
                                                         uint32_t windows, uint32_t* __restrict__ cnt,
                                                         uint32_t* __restrict__ slot) {
     extern __shared__ uint32_t hist[];
@@ -113,12 +133,10 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const Fe* __restrict__ r
     const uint32_t nb = 1u << (c - 1);
     for (uint32_t k = tid; k <= nb; k += 1024) hist[k] = 0;
     __syncthreads();
-    const Fe* rb = raw + (size_t)b * n;
+    const uint32_t* db = dig + ((size_t)b * windows + w) * n;
     uint32_t* sb = slot + ((size_t)b * windows + w) * n;
     for (uint32_t i = tid; i < n; i += 1024) {
-        Fe s = ld_fe_g(rb + i);
-        uint32_t k, neg;
-        digit_at(s.l, w, c, nb, k, neg);
+        uint32_t k = db[i] & 0x7fffffffu;
         if (k != 0) sb[i] = atomicAdd(&hist[k], 1u);
     }
     __syncthreads();
@@ -127,27 +145,35 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const Fe* __restrict__ r
 }
 
 // Per vector: bucket totals over the windows, exclusive scans (entry offsets and ceil(total/K) task
-// offsets), and the absolute offset of every (window, bucket) cell.  One 1024-lane workgroup.
+// offsets), the absolute offset of every (window, bucket) cell and the list of hot buckets.  One
+// 1024-lane workgroup; the two passes over the count table are coalesced (lane <-> bucket).
 __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t c, uint32_t windows,
                                                         uint32_t* __restrict__ off, uint32_t* __restrict__ toff,
-                                                        uint32_t* __restrict__ ttotal, uint32_t* __restrict__ hmap,
-                                                        uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
-                                                        uint32_t max_heavy) {
+                                                        uint32_t* __restrict__ tot, uint32_t* __restrict__ ttotal,
+                                                        uint32_t* __restrict__ hmap, uint32_t* __restrict__ hlist,
+                                                        uint32_t* __restrict__ nheavy, uint32_t max_heavy) {
     __shared__ uint32_t se[1024], st[1024];
     __shared__ uint32_t hcount;
-    if (threadIdx.x == 0) hcount = 0;
     const uint32_t nb = 1u << (c - 1);
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
     uint32_t* ob = off + (size_t)b * windows * (nb + 1);
     uint32_t* to = toff + (size_t)b * (nb + 2);
+    uint32_t* tt = tot + (size_t)b * (nb + 2);  // bucket totals, then exclusive entry offsets
+    if (tid == 0) hcount = 0;
+    for (uint32_t k = tid; k <= nb; k += 1024) {
+        uint32_t v = 0;
+        for (uint32_t w = 0; w < windows; w++) v += cb[(size_t)w * (nb + 1) + k];
+        tt[k] = v;
+    }
+    __syncthreads();
     const uint32_t per = (nb + 1 + 1023) / 1024;
     uint32_t lo = tid * per, hi = lo + per;
+    if (lo > nb + 1) lo = nb + 1;
     if (hi > nb + 1) hi = nb + 1;
     uint32_t es = 0, ts = 0;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t v = 0;
-        for (uint32_t w = 0; w < windows; w++) v += cb[(size_t)w * (nb + 1) + k];
+        uint32_t v = tt[k];
         es += v;
         ts += (v + MSM_K - 1) / MSM_K;
     }
@@ -167,11 +193,8 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     uint32_t eb = se[tid] - es, tb = st[tid] - ts;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t v = 0;
-        for (uint32_t w = 0; w < windows; w++) {
-            ob[(size_t)w * (nb + 1) + k] = eb + v;
-            v += cb[(size_t)w * (nb + 1) + k];
-        }
+        const uint32_t v = tt[k];
+        tt[k] = eb;
         to[k] = tb;
         eb += v;
         const uint32_t nt = (v + MSM_K - 1) / MSM_K;
@@ -187,13 +210,21 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     __syncthreads();
     if (tid == 1023) {
         to[nb + 1] = st[1023];
+        tt[nb + 1] = se[1023];
         ttotal[b] = st[1023];
         nheavy[b] = hcount;
+    }
+    for (uint32_t k = tid; k <= nb; k += 1024) {
+        uint32_t run = tt[k];
+        for (uint32_t w = 0; w < windows; w++) {
+            ob[(size_t)w * (nb + 1) + k] = run;
+            run += cb[(size_t)w * (nb + 1) + k];
+        }
     }
 }
 
 // Write (point, window, sign) into bucket order: position = cell offset + slot inside the cell.
-__global__ __launch_bounds__(256) void msm_scatter_kernel(const Fe* __restrict__ raw, uint32_t n, uint32_t c,
+__global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __restrict__ dig, uint32_t n, uint32_t c,
                                                           uint32_t windows, const uint32_t* __restrict__ off,
                                                           const uint32_t* __restrict__ slot,
                                                           uint32_t* __restrict__ sorted) {
@@ -201,20 +232,19 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const Fe* __restrict__
     uint32_t w = blockIdx.y, b = blockIdx.z;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
-    Fe s = ld_fe_g(raw + (size_t)b * n + i);
-    uint32_t k, neg;
-    digit_at(s.l, w, c, nb, k, neg);
+    const size_t cell = ((size_t)b * windows + w);
+    const uint32_t d = dig[cell * n + i];
+    const uint32_t k = d & 0x7fffffffu;
     if (k == 0) return;
-    uint32_t pos = off[((size_t)b * windows + w) * (nb + 1) + k] + slot[((size_t)b * windows + w) * n + i];
-    sorted[(size_t)b * windows * n + pos] = i | (w << 24) | (neg << 31);
+    uint32_t pos = off[cell * (nb + 1) + k] + slot[cell * n + i];
+    sorted[(size_t)b * windows * n + pos] = i | (w << 24) | (d & 0x80000000u);
 }
 
 // One lane per task: at most K points of one bucket, mixed adds in XYZZ.
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* __restrict__ table, uint32_t n_table, uint32_t c, uint32_t windows, uint32_t n,
-    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, const uint32_t* __restrict__ toff,
-    const uint32_t* __restrict__ ttotal, const uint32_t* __restrict__ sorted, uint32_t max_tasks,
-    XYZZ* __restrict__ partial) {
+    const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
+    const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ* __restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t b = blockIdx.y;
     if (t >= ttotal[b]) return;
@@ -229,11 +259,9 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     }
     const uint32_t k = lo;
     const uint32_t j = t - to[k];
-    // bucket k's entries are contiguous: [off[0][k], off[0][k] + total_k)
-    const uint32_t first = off[(size_t)b * windows * (nb + 1) + k];
-    const uint32_t last_w = windows - 1;
-    const uint32_t total = off[((size_t)b * windows + last_w) * (nb + 1) + k] +
-                           cnt[((size_t)b * windows + last_w) * (nb + 1) + k] - first;
+    // bucket k's entries are contiguous: [tot[k], tot[k+1])  (exclusive entry offsets)
+    const uint32_t first = tot[(size_t)b * (nb + 2) + k];
+    const uint32_t total = tot[(size_t)b * (nb + 2) + k + 1] - first;
     const uint32_t start = first + j * MSM_K;
     uint32_t len = total - j * MSM_K;
     if (len > MSM_K) len = MSM_K;
@@ -433,11 +461,12 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
     ZG_REQUIRE(nblk <= 256, ZG_ERR_UNSUPPORTED, "zg_msm: window_bits %u too large", c);
 
     WsScope ws(ctx);
-    Fe* raw = ws.get<Fe>((size_t)B * N);
+    uint32_t* dig = ws.get<uint32_t>((size_t)B * entries);
     uint32_t* cnt = ws.get<uint32_t>((size_t)B * W * (nb + 1));
     uint32_t* slot = ws.get<uint32_t>((size_t)B * entries);
     uint32_t* off = ws.get<uint32_t>((size_t)B * W * (nb + 1));
     uint32_t* toff = ws.get<uint32_t>((size_t)B * (nb + 2));
+    uint32_t* tot = ws.get<uint32_t>((size_t)B * (nb + 2));
     uint32_t* ttotal = ws.get<uint32_t>(B);
     uint32_t* sorted = ws.get<uint32_t>((size_t)B * entries);
     XYZZ* partial = ws.get<XYZZ>((size_t)B * max_tasks);
@@ -459,15 +488,16 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
     // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out.  Every
     // stage kernel processes the same B MSMs per launch, so each is charged the same figure.
     const double msm_bytes = (double)B * ((double)N * 96.0 + 96.0);
-    ZG_LAUNCH(ctx, "msm_raw", msm_bytes, msm_raw_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, raw);
-    ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, raw, N, c, W, cnt,
+    ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, c,
+              W, dig);
+    ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
-    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, W, off, toff, ttotal, hmap, hlist,
-              nheavy, max_heavy);
-    ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, raw, N, c, W,
+    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, W, off, toff, tot, ttotal, hmap,
+              hlist, nheavy, max_heavy);
+    ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted);
     ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
-              bases->table, (uint32_t)bases->n, c, W, N, cnt, off, toff, ttotal, sorted, max_tasks, partial);
+              bases->table, (uint32_t)bases->n, c, W, N, tot, toff, ttotal, sorted, max_tasks, partial);
     ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel, dim3(max_heavy < 64 ? max_heavy : 64, B), dim3(256), 0, partial,
               toff, hlist, nheavy, max_tasks, max_heavy, c, hsum);
     ZG_LAUNCH(ctx, "msm_bucket_reduce", msm_bytes, msm_bucket_reduce_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff, hmap,

@@ -10,6 +10,7 @@
 // on the next challenge (iNTTs, coset NTTs) is queued behind the commitment MSM so that it runs while
 // the host hashes.
 #include <algorithm>
+#include <chrono>
 #include <memory>
 #include <thread>
 
@@ -161,6 +162,7 @@ struct zg_prover {
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     bool have_last = false;
+    double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -445,6 +447,13 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     EvmTranscript tr;
     std::vector<Jac> pts;
     p->have_last = false;
+    using clk = std::chrono::steady_clock;
+    auto t_start = clk::now(), t_prev = t_start;
+    auto lap = [&](int slot) {
+        auto now = clk::now();
+        p->phase_ms[slot] = std::chrono::duration<double, std::milli>(now - t_prev).count();
+        t_prev = now;
+    };
 
     // ---- vk + instance values into the transcript; instance polynomial
     tr.common_scalar(p->vk_repr);
@@ -474,6 +483,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         for (auto& q : pts) tr.write_point(q);
     }
     const Fe theta = tr.squeeze();
+    lap(0);
 
     Cols base_cols;
     base_cols.fixed = p->fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
@@ -488,6 +498,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_HIP(hipMemcpyAsync(host, p->raw, (size_t)2 * NL * n * 32, hipMemcpyDeviceToHost, st));
         ZG_HIP(hipStreamSynchronize(st));
         Raw* outbuf = host + (size_t)2 * NL * n;
+        auto t_sort = clk::now();
         std::vector<int> okv(NL, 1);
         std::vector<std::thread> th;
         for (uint32_t l = 0; l < NL; l++)
@@ -495,6 +506,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
                 okv[l] = permute_pair_host(host + (size_t)l * n, host + (size_t)(NL + l) * n, outbuf + (size_t)l * n, usable) ? 1 : 0;
             });
         for (auto& t : th) t.join();
+        p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
         for (uint32_t l = 0; l < NL; l++)
             if (!okv[l]) {
                 set_error("zg_prover_prove: lookup %u has an input outside its table (ConstraintSystemFailure)", l);
@@ -518,6 +530,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         for (auto& q : pts) tr.write_point(q);
     }
     const Fe beta = tr.squeeze();
+    lap(1);
     const Fe gamma = tr.squeeze();
 
     // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
@@ -549,6 +562,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     ZG_TRY(wait_points(p, S + NL + 1, pts));
     for (auto& q : pts) tr.write_point(q);
     const Fe y = tr.squeeze();
+    lap(2);
 
     // ---- evaluate_h (+ division by X^n - 1), back to coefficients, h pieces
     {
@@ -579,6 +593,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     ZG_TRY(wait_points(p, Q, pts));
     for (auto& q : pts) tr.write_point(q);
     const Fe x = tr.squeeze();
+    lap(3);
     const Fe xn = Fr::pow_u64(x, n);
 
     // ---- evaluations
@@ -676,6 +691,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
 
     // ---- ProverGWC::create_proof
     const Fe v = tr.squeeze();
+    lap(4);
     {
         std::vector<char> done(oq.size(), 0);
         uint32_t npts = 0;
@@ -716,6 +732,8 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
                tr.stream.size(), proof_cap);
     memcpy(proof, tr.stream.data(), tr.stream.size());
     *proof_len = tr.stream.size();
+    lap(5);
+    p->phase_ms[6] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
     return ZG_OK;
 }
 
@@ -726,6 +744,12 @@ int zg_prover_prove(zg_prover* p, const zg_fr* advice, const zg_fr* instance, si
     if (p->A)
         ZG_HIP(hipMemcpyAsync(p->adv_val, advice, (size_t)p->A * p->n * 32, hipMemcpyHostToDevice, p->ctx->stream));
     return zg_prover_prove_dev(p, p->adv_val, instance, instance_len, seed, proof, proof_cap, proof_len);
+}
+
+int zg_prover_phase_ms(const zg_prover* p, double* out, size_t cap) {
+    ZG_REQUIRE(p && out, ZG_ERR_INVALID_ARG, "zg_prover_phase_ms: null argument");
+    for (size_t i = 0; i < cap && i < 8; i++) out[i] = p->phase_ms[i];
+    return ZG_OK;
 }
 
 int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, size_t cap_elems) {

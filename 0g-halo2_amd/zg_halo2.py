@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "zg_domain_omega", "zg_ctx_profile_enable", "zg_ctx_profile_collect", "zg_params_new",
     "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
     "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
-    "zg_kate_division_dev", "zg_keccak256",
+    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms",
 ]
 
 
@@ -159,6 +159,9 @@ class Ctx:
 
     def profile(self, on: bool):
         _check(self.lib.zg_ctx_profile_enable(self.h, c_int(1 if on else 0)))
+
+    def profile_filter(self, kernel_name: str | None):
+        _check(self.lib.zg_ctx_profile_filter(self.h, kernel_name.encode() if kernel_name else None))
 
     def profile_collect(self) -> dict:
         """{kernel: (launches, total_ms, algo_bytes)} since the last collect; synchronises."""
@@ -348,6 +351,11 @@ class Prover:
                                                 ctypes.c_uint64(seed), buf, c_size_t(self.proof_cap),
                                                 ctypes.byref(plen)))
         return bytes(buf[: plen.value])
+
+    def phase_ms(self) -> list:
+        out = (ctypes.c_double * 8)()
+        _check(self.ctx.lib.zg_prover_phase_ms(self.h, out, c_size_t(8)))
+        return list(out)
 
     def fetch(self, what: int, index: int, count: int) -> np.ndarray:
         out = np.zeros((count, 4), np.uint64)

@@ -76,6 +76,9 @@ typedef struct {
     double algo_bytes;
 } zg_kernel_stat;
 int zg_ctx_profile_enable(zg_ctx *ctx, int on);
+/* Bracket only launches of the named kernel (NULL or "" = every kernel): two event records per launch
+ * are cheap for one kernel, not for the ~90 launches of a whole proof. */
+int zg_ctx_profile_filter(zg_ctx *ctx, const char *kernel_name);
 int zg_ctx_profile_collect(zg_ctx *ctx, zg_kernel_stat *out, size_t cap, size_t *count);
 
 /* ------------------------------------------------------------------ MSM
@@ -235,6 +238,12 @@ size_t zg_prover_proof_size(const zg_prover *p);
  * 2 = lookup z (index = lookup) [2^k Lagrange], 3 = permuted input a' (index = lookup),
  * 4 = permuted table s' (index = lookup), 5 = h pieces in coefficient form [5 * 2^k]. */
 int zg_prover_fetch(zg_prover *p, uint32_t what, uint32_t index, zg_fr *out, size_t cap_elems);
+
+/* Host wall-clock milliseconds the LAST proof spent per phase (diagnostics): 0 instance+advice
+ * commitments, 1 lookup compression + permutation (of which out[7] is the host sort) + commitments,
+ * 2 permutation/lookup products + random poly, 3 evaluate_h + h commitments, 4 evaluations,
+ * 5 GWC openings, 6 total. */
+int zg_prover_phase_ms(const zg_prover *p, double *out, size_t cap);
 
 /* Stand-alone building blocks of the above (device pointers, context stream), exposed for tests. */
 /* z[0] = z0, z[i+1] = z[i] * num[i] / den[i]  (lookup::prover::commit_product / permutation commit). */
