@@ -89,6 +89,7 @@ struct zg_ctx {
     };
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;  // recycled by zg_ctx_profile_collect
+    zg_ctx* side = nullptr;  // optional second stream + workspace pool (created on demand, same device)
 };
 
 struct zg_bases {

@@ -127,6 +127,10 @@ int zg_ctx_create(int device_id, zg_ctx** out) {
 
 void zg_ctx_destroy(zg_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->side) {
+        zg_ctx_destroy(ctx->side);
+        ctx->side = nullptr;
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& r : ctx->prof) {
@@ -144,6 +148,7 @@ void zg_ctx_destroy(zg_ctx* ctx) {
 int zg_ctx_sync(zg_ctx* ctx) {
     ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_sync: ctx is null");
     ZG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->side) ZG_HIP(hipStreamSynchronize(ctx->side->stream));
     return ZG_OK;
 }
 
@@ -152,12 +157,14 @@ void* zg_ctx_stream(zg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int zg_ctx_profile_enable(zg_ctx* ctx, int on) {
     ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_profile_enable: ctx is null");
     ctx->profiling = on != 0;
+    if (ctx->side) ctx->side->profiling = ctx->profiling;
     return ZG_OK;
 }
 
 int zg_ctx_profile_filter(zg_ctx* ctx, const char* kernel_name) {
     ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_profile_filter: ctx is null");
     ctx->prof_filter = kernel_name ? kernel_name : "";
+    if (ctx->side) ctx->side->prof_filter = ctx->prof_filter;
     return ZG_OK;
 }
 
@@ -166,6 +173,11 @@ int zg_ctx_profile_collect(zg_ctx* ctx, zg_kernel_stat* out, size_t cap, size_t*
     ZG_REQUIRE(ctx && count, ZG_ERR_INVALID_ARG, "zg_ctx_profile_collect: null argument");
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<zg_kernel_stat> acc;
+    if (ctx->side) {  // fold the side stream's launches in
+        ZG_HIP(hipStreamSynchronize(ctx->side->stream));
+        for (auto& r : ctx->side->prof) ctx->prof.push_back(r);
+        ctx->side->prof.clear();
+    }
     for (auto& r : ctx->prof) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, r.e0, r.e1);

@@ -25,6 +25,9 @@
 
 namespace zg {
 
+int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t batch, size_t n, XYZZ* d_out);
+
 constexpr uint32_t MSM_K = 16;       // max points per accumulate task
 constexpr uint32_t MSM_MAX_C = 16;
 constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
@@ -242,12 +245,14 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __rest
 
 // One lane per task: at most K points of one bucket, mixed adds in XYZZ.
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(
-    const Affine* __restrict__ table, uint32_t n_table, uint32_t c, uint32_t windows, uint32_t n,
+    const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table,
+    uint32_t c, uint32_t windows, uint32_t n,
     const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
     const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ* __restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t b = blockIdx.y;
     if (t >= ttotal[b]) return;
+    const Affine* table = b < split ? table_a : table_b;  // vectors >= split use the second base set
     const uint32_t nb = 1u << (c - 1);
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     // largest k with to[k] <= t  (to is non-decreasing, to[nb+1] = total > t)
@@ -442,6 +447,16 @@ int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t wi
 
 int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch,
                   size_t n, XYZZ* d_out) {
+    return msm_batch2_dev(ctx, bases, nullptr, batch, d_scalars, stride, batch, n, d_out);
+}
+
+// Vectors [0, split) are multiplied against `bases`, vectors [split, batch) against `bases_b` (same
+// length and window size, e.g. ParamsKZG::g_lagrange and ::g) in ONE launch sequence.
+int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t batch, size_t n, XYZZ* d_out) {
+    if (bases_b)
+        ZG_REQUIRE(bases_b->n == bases->n && bases_b->c == bases->c, ZG_ERR_INVALID_ARG,
+                   "zg_msm: the two base sets differ in length or window size");
     ZG_REQUIRE(n <= bases->n, ZG_ERR_INVALID_ARG, "zg_msm: %zu scalars for %zu bases", n, bases->n);
     ZG_REQUIRE(batch <= 65535, ZG_ERR_UNSUPPORTED, "zg_msm: batch %zu > 65535", batch);
     if (batch == 0) return ZG_OK;
@@ -497,7 +512,8 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted);
     ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
-              bases->table, (uint32_t)bases->n, c, W, N, tot, toff, ttotal, sorted, max_tasks, partial);
+              bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot, toff,
+              ttotal, sorted, max_tasks, partial);
     ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel, dim3(max_heavy < 64 ? max_heavy : 64, B), dim3(256), 0, partial,
               toff, hlist, nheavy, max_tasks, max_heavy, c, hsum);
     ZG_LAUNCH(ctx, "msm_bucket_reduce", msm_bytes, msm_bucket_reduce_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff, hmap,

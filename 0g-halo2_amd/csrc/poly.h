@@ -107,6 +107,8 @@ int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, 
 // from msm.hip
 int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch, size_t n,
                   XYZZ* d_out);
+int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t batch, size_t n, XYZZ* d_out);
 int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t window_bits, zg_bases** out);
 void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
 

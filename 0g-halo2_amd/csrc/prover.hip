@@ -158,7 +158,7 @@ struct zg_prover {
     XYZZ* xyzz = nullptr;
     uint32_t* d_idx = nullptr;
     Fe* ktmp = nullptr;
-    hipEvent_t ev = nullptr;
+    hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     bool have_last = false;
@@ -225,10 +225,13 @@ void zg_prover_destroy(zg_prover* p) {
     if (!p) return;
     (void)hipSetDevice(p->ctx->device);
     (void)hipStreamSynchronize(p->ctx->stream);
+    if (p->ctx->side) (void)hipStreamSynchronize(p->ctx->side->stream);
     for (void* q : p->owned) (void)hipFree(q);
     if (p->g) zg_bases_free(p->g);
     if (p->gl) zg_bases_free(p->gl);
     if (p->ev) (void)hipEventDestroy(p->ev);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->pinned) (void)hipHostFree(p->pinned);
     delete p;
 }
@@ -267,6 +270,9 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     const uint32_t n = p->n, en = p->en;
     hipStream_t st = ctx->stream;
     ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    if (!ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
 
     // ---- validate and upload the circuit tables
     for (uint32_t q = 0; q < cs->n_queries; q++) {
@@ -364,8 +370,8 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     ZG_TRY(dalloc(p, &p->ptab_c, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->cin, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->ctab, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->perm, (size_t)2 * NL * n));
-    ZG_TRY(dalloc(p, &p->zs, (size_t)(S + NL) * n));
+    ZG_TRY(dalloc(p, &p->perm, (size_t)(2 * NL + 1) * n));  // + the vanishing argument's random polynomial
+    ZG_TRY(dalloc(p, &p->zs, (size_t)(S + NL + 1) * n));
     const uint32_t mb = S + NL;
     ZG_TRY(dalloc(p, &p->num, (size_t)mb * n));
     ZG_TRY(dalloc(p, &p->den, (size_t)mb * n));
@@ -377,7 +383,7 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     const uint32_t max_evals = (uint32_t)(p->advice_queries.size() + p->fixed_queries.size()) + P + 3 * S + 5 * NL + 4;
     ZG_TRY(dalloc(p, &p->evals, max_evals));
     ZG_TRY(dalloc(p, &p->wpoly, (size_t)2 * max_points * n));
-    ZG_TRY(dalloc(p, &p->xyzz, std::max<size_t>(std::max<size_t>(A, 2 * NL), std::max<size_t>(S + NL + 1, std::max<size_t>(Q, max_points)))));
+    ZG_TRY(dalloc(p, &p->xyzz, std::max<size_t>(std::max<size_t>(A, 2 * NL + 1), std::max<size_t>(S + NL + 1, std::max<size_t>(Q, max_points)))));
     ZG_TRY(dalloc(p, &p->d_idx, (size_t)4 * max_evals + 64 + (size_t)max_points * 512));
     ZG_TRY(dalloc(p, &p->ktmp, poly_kate_tmp_elems(n, max_points)));
     p->pinned_cap = std::max<size_t>((size_t)4 * NL * n * 32, 1u << 20);
@@ -455,8 +461,28 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         t_prev = now;
     };
 
+    // side stream: coefficient / coset forms of committed columns are computed there while the main
+    // stream runs the commitment MSM (whose tail is a chain of dependent EC additions on a few CUs)
+    zg_ctx* sx = ctx->side;
+    hipStream_t ss = sx->stream;
+    auto fork = [&]() -> int {  // side stream continues after everything queued on the main stream so far
+        ZG_HIP(hipEventRecord(p->ev_fork, st));
+        ZG_HIP(hipStreamWaitEvent(ss, p->ev_fork, 0));
+        return ZG_OK;
+    };
+    auto join = [&]() -> int {  // main stream continues after everything queued on the side stream so far
+        ZG_HIP(hipEventRecord(p->ev_join, ss));
+        ZG_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+        return ZG_OK;
+    };
+
     // ---- vk + instance values into the transcript; instance polynomial
     tr.common_scalar(p->vk_repr);
+    // vanishing::Argument::commit's random polynomial depends on no challenge: generate it now and
+    // commit it inside the permuted-lookup batch (coefficient basis `g` next to `g_lagrange` vectors)
+    Fe* random_row = p->perm + (size_t)(2 * NL) * n;
+    ZG_TRY(poly_random(ctx, random_row, n, seed, TAG_RANDOM_POLY));
+    ZG_HIP(hipMemcpyAsync(poly_at(p->ix_random), random_row, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
     if (I) {
         ZG_HIP(hipMemsetAsync(p->inst_val, 0, (size_t)I * n * 32, st));
         for (uint32_t c = 0; c < I; c++) {
@@ -465,20 +491,23 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
                 ZG_HIP(hipMemcpyAsync(p->inst_val + (size_t)c * n, instance + c * instance_len, instance_len * 32,
                                       hipMemcpyHostToDevice, st));
         }
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_inst), p->inst_val, (size_t)I * n * 32, hipMemcpyDeviceToDevice, st));
-        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_inst), n, p->inst_cos, en, I, k, ek));
     }
 
-    // ---- advice: blind, commit (Lagrange basis); coefficient + coset forms queued behind the MSM
+    // ---- advice: blind, commit (Lagrange basis)
     Fe* adv = reinterpret_cast<Fe*>(d_advice);
+    if (A) ZG_TRY(poly_blind_rows(ctx, adv, n, A, usable, bf + 1, seed, TAG_ADVICE_BLIND));
+    ZG_TRY(fork());
+    if (I) {
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_inst), p->inst_val, (size_t)I * n * 32, hipMemcpyDeviceToDevice, ss));
+        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_inst), n, p->inst_cos, en, I, k, ek));
+    }
     if (A) {
-        ZG_TRY(poly_blind_rows(ctx, adv, n, A, usable, bf + 1, seed, TAG_ADVICE_BLIND));
         ZG_TRY(msm_batch_dev(ctx, p->gl, adv, n, A, n, p->xyzz));
         ZG_TRY(fetch_points(p, A, pts));
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_adv), adv, (size_t)A * n * 32, hipMemcpyDeviceToDevice, st));
-        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_adv), n, p->adv_cos, en, A, k, ek));
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_adv), adv, (size_t)A * n * 32, hipMemcpyDeviceToDevice, ss));
+        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_adv), n, p->adv_cos, en, A, k, ek));
         ZG_TRY(wait_points(p, A, pts));
         for (auto& q : pts) tr.write_point(q);
     }
@@ -489,7 +518,9 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     base_cols.fixed = p->fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
     base_cols.log_size = k; base_cols.rot_scale = 1;
 
-    // ---- lookups: commit_permuted
+    // ---- lookups: commit_permuted (+ the random polynomial's commitment)
+    Jac random_commit;
+    bool have_random = false;
     if (NL) {
         ZG_TRY(poly_lookup_compress(ctx, p->dc, base_cols, theta, p->cin, p->ctab, n));
         ZG_TRY(poly_to_raw(ctx, p->cin, p->raw, (size_t)NL * n));
@@ -510,6 +541,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         for (uint32_t l = 0; l < NL; l++)
             if (!okv[l]) {
                 set_error("zg_prover_prove: lookup %u has an input outside its table (ConstraintSystemFailure)", l);
+                (void)hipStreamSynchronize(ss);
                 return ZG_ERR_CONSTRAINT;
             }
         // back to the device: perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form), then the blinding tail
@@ -521,13 +553,21 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         // blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j
         ZG_TRY(poly_blind_rows(ctx, p->perm, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_INPUT));
         ZG_TRY(poly_blind_rows(ctx, p->perm + n, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_TABLE));
-        ZG_TRY(msm_batch_dev(ctx, p->gl, p->perm, n, 2 * NL, n, p->xyzz));
-        ZG_TRY(fetch_points(p, 2 * NL, pts));
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_perm), p->perm, (size_t)2 * NL * n * 32, hipMemcpyDeviceToDevice, st));
-        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_perm), n, p->perm_cos, en, 2 * NL, k, ek));
-        ZG_TRY(wait_points(p, 2 * NL, pts));
-        for (auto& q : pts) tr.write_point(q);
+        ZG_TRY(fork());
+        ZG_TRY(msm_batch2_dev(ctx, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, n, p->xyzz));
+        ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_perm), p->perm, (size_t)2 * NL * n * 32, hipMemcpyDeviceToDevice, ss));
+        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_perm), n, p->perm_cos, en, 2 * NL, k, ek));
+        // evaluate_h wants a'_l and s'_l cosets in separate [l] slabs
+        for (uint32_t l = 0; l < NL; l++) {
+            ZG_HIP(hipMemcpyAsync(p->pin_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, ss));
+            ZG_HIP(hipMemcpyAsync(p->ptab_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l + 1) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, ss));
+        }
+        ZG_TRY(wait_points(p, 2 * NL + 1, pts));
+        for (uint32_t i = 0; i < 2 * NL; i++) tr.write_point(pts[i]);
+        random_commit = pts[2 * NL];
+        have_random = true;
     }
     const Fe beta = tr.squeeze();
     lap(1);
@@ -547,20 +587,34 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, S + NL, S, n - bf - 1));
         if (S) ZG_TRY(poly_blind_rows(ctx, pz, n, S, n - bf, bf, seed, TAG_PERM_Z));
         if (NL) ZG_TRY(poly_blind_rows(ctx, lz, n, NL, n - bf, bf, seed, TAG_LOOKUP_Z));
+        ZG_TRY(fork());
+        if (have_random) {
+            ZG_TRY(msm_batch_dev(ctx, p->gl, p->zs, n, S + NL, n, p->xyzz));
+        } else {  // no lookups: the random polynomial rides here instead (row S+NL of zs)
+            ZG_HIP(hipMemcpyAsync(p->zs + (size_t)(S + NL) * n, random_row, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
+            ZG_TRY(msm_batch2_dev(ctx, p->gl, p->g, S + NL, p->zs, n, S + NL + 1, n, p->xyzz));
+        }
+        const uint32_t npts = S + NL + (have_random ? 0 : 1);
+        ZG_TRY(fetch_points(p, npts, pts));
+        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_pz), p->zs, (size_t)(S + NL) * n * 32, hipMemcpyDeviceToDevice, ss));
+        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
+        if (S) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_pz), n, p->pz_cos, en, S, k, ek));
+        if (NL) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_lz), n, p->lz_cos, en, NL, k, ek));
+        ZG_TRY(wait_points(p, npts, pts));
+        for (uint32_t i = 0; i < S + NL; i++) tr.write_point(pts[i]);
+        if (!have_random) {
+            random_commit = pts[S + NL];
+            have_random = true;
+        }
     }
-    if (S + NL) ZG_TRY(msm_batch_dev(ctx, p->gl, p->zs, n, S + NL, n, p->xyzz));
-    // vanishing::Argument::commit: random polynomial (coefficient basis)
-    ZG_TRY(poly_random(ctx, poly_at(p->ix_random), n, seed, TAG_RANDOM_POLY));
-    ZG_TRY(msm_batch_dev(ctx, p->g, poly_at(p->ix_random), n, 1, n, p->xyzz + (S + NL)));
-    ZG_TRY(fetch_points(p, S + NL + 1, pts));
-    if (S + NL) {
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_pz), p->zs, (size_t)(S + NL) * n * 32, hipMemcpyDeviceToDevice, st));
-        ZG_TRY(ntt_batch_dev(ctx, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
-        if (S) ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_pz), n, p->pz_cos, en, S, k, ek));
-        if (NL) ZG_TRY(coeff_to_extended_dev(ctx, poly_at(p->ix_lz), n, p->lz_cos, en, NL, k, ek));
+    if (!have_random) {  // neither lookups nor permutation: commit the random polynomial on its own
+        ZG_TRY(msm_batch_dev(ctx, p->g, random_row, n, 1, n, p->xyzz));
+        ZG_TRY(fetch_points(p, 1, pts));
+        ZG_TRY(wait_points(p, 1, pts));
+        random_commit = pts[0];
     }
-    ZG_TRY(wait_points(p, S + NL + 1, pts));
-    for (auto& q : pts) tr.write_point(q);
+    tr.write_point(random_commit);
+    ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
     const Fe y = tr.squeeze();
     lap(2);
 
@@ -574,10 +628,6 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         a.sigma_cos = p->sigma_cos; a.pz_cos = p->pz_cos; a.lz_cos = p->lz_cos;
         // perm_cos is interleaved [2l] = a', [2l+1] = s': the kernel wants [l] strides -> separate views
         a.pin_cos = p->pin_cos_c; a.ptab_cos = p->ptab_cos_c;
-        for (uint32_t l = 0; l < NL; l++) {
-            ZG_HIP(hipMemcpyAsync(p->pin_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, st));
-            ZG_HIP(hipMemcpyAsync(p->ptab_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l + 1) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, st));
-        }
         a.l0 = p->l0; a.llast = p->llast; a.lactive = p->lactive;
         a.ext_tw = p->ext_tw; a.t_eval = p->t_eval; a.t_mask = (1u << (ek - k)) - 1;
         a.last_rot = -(int32_t)(bf + 1);
