@@ -97,20 +97,55 @@ __device__ __forceinline__ void digit_at(const uint32_t raw[8], uint32_t w, uint
 }
 
 // All signed digits of a scalar, once: dig[b][w][i] = bucket index k (0 = no entry) | sign << 31.
+//
+// Balancing: W*c exceeds 254, so the top window of a 254-bit scalar only reaches its lowest few
+// digit values and the buckets 1..2^(254-c(W-1)) would collect W/(W-1) times the load plus a whole
+// extra window share.  Because every base has order r, s*P = (s + t*r)*P: large scalars (top window
+// non-zero) are shifted by a pseudo-random multiple t*r, t < 2^tbits, chosen so that the sum still
+// fits below 2^(cW-1) (no carry out of the top window).  Small / sparse scalars are left alone so
+// that their zero windows stay zero.
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n,
-                                                         uint32_t c, uint32_t windows, uint32_t* __restrict__ dig) {
+                                                         uint32_t c, uint32_t windows, uint32_t tbits,
+                                                         uint32_t* __restrict__ dig) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
     Fe s = Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i));
-    // walk the 256-bit value with a 64-bit sliding register (no runtime-indexed limb array)
-    uint64_t bits = (uint64_t)s.l[0] | ((uint64_t)s.l[1] << 32);
+    uint32_t l[9];
+#pragma unroll
+    for (int j = 0; j < 8; j++) l[j] = s.l[j];
+    l[8] = 0;
+    // top window non-zero <=> s >= 2^(c*(W-1))
+    const uint32_t top_lo = c * (windows - 1);
+    bool large = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t lo_bit = 32u * j;
+        if (lo_bit + 32 > top_lo) {
+            uint32_t v = l[j];
+            if (lo_bit < top_lo) v >>= (top_lo - lo_bit);
+            large |= v != 0;
+        }
+    }
+    if (large && tbits) {
+        const uint32_t t = ((l[0] >> 5) ^ (l[1] >> 11) ^ l[2]) & ((1u << tbits) - 1);
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            carry += (uint64_t)l[j] + (uint64_t)t * FrParams::p(j);
+            l[j] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        l[8] = (uint32_t)carry;
+    }
+    // walk the value with a 64-bit sliding register (no runtime-indexed limb array)
+    uint64_t bits = (uint64_t)l[0] | ((uint64_t)l[1] << 32);
     uint32_t have = 64, next = 2, carry = 0;
     uint32_t* db = dig + (size_t)b * windows * n + i;
     for (uint32_t w = 0; w < windows; w++) {
-        if (have < c && next < 8) {  // refill: c <= 16 so 32 fresh bits always fit
-            uint32_t limb = next == 2 ? s.l[2] : next == 3 ? s.l[3] : next == 4 ? s.l[4] : next == 5 ? s.l[5]
-                          : next == 6 ? s.l[6] : s.l[7];
+        if (have < c && next < 9) {  // refill: c <= 16 so 32 fresh bits always fit
+            uint32_t limb = next == 2 ? l[2] : next == 3 ? l[3] : next == 4 ? l[4] : next == 5 ? l[5]
+                          : next == 6 ? l[6] : next == 7 ? l[7] : l[8];
             bits |= (uint64_t)limb << have;
             have += 32;
             next++;
@@ -286,10 +321,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
 }
 
 // sum_k k*B_k = sum_k S_k with S_k = sum_{k' >= k} B_k' (the classic running sum of running sums), cut
-// into blocks of 256 buckets so that it parallelises: per block, lane j merges the task partials of
-// bucket k0 + j + 1 (buckets with many tasks -- hot buckets of sparse scalars -- are summed by the
-// whole workgroup), a Hillis-Steele suffix scan through LDS gives S_j, a tree gives
-// W = sum_j S_j = sum_j (j+1) B_j, and P = S_0 is the block total.
+// into blocks of 256 buckets so that it parallelises (msm_bucket_scan / msm_bucket_sum / msm_finish).
 constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
 
 // One workgroup per hot bucket: lanes take a strided share of its task partials, tree through LDS.
@@ -321,13 +353,17 @@ __global__ __launch_bounds__(256) void msm_heavy_kernel(const XYZZ* __restrict__
     }
 }
 
-__global__ __launch_bounds__(MSM_RB) void msm_bucket_reduce_kernel(const XYZZ* __restrict__ partial,
-                                                                  const uint32_t* __restrict__ toff,
-                                                                  const uint32_t* __restrict__ hmap,
-                                                                  const XYZZ* __restrict__ hsum, uint32_t max_tasks,
-                                                                  uint32_t max_heavy, uint32_t c,
-                                                                  XYZZ* __restrict__ blk_w, XYZZ* __restrict__ blk_p,
-                                                                  uint32_t nblk) {
+// Stage 1 of sum_k k*B_k = sum_k S_k (S = suffix sums of the bucket sums B): per block of 256 buckets,
+// lane j merges the task partials of bucket k0 + j + 1 (hot buckets arrive pre-merged from
+// msm_heavy_kernel), a Hillis-Steele suffix scan through LDS gives the block-local S_j, stored for
+// stage 2 together with the block total P = S_0.
+__global__ __launch_bounds__(MSM_RB) void msm_bucket_scan_kernel(const XYZZ* __restrict__ partial,
+                                                                const uint32_t* __restrict__ toff,
+                                                                const uint32_t* __restrict__ hmap,
+                                                                const XYZZ* __restrict__ hsum, uint32_t max_tasks,
+                                                                uint32_t max_heavy, uint32_t c,
+                                                                XYZZ* __restrict__ sfx, XYZZ* __restrict__ blk_p,
+                                                                uint32_t nblk) {
     __shared__ XYZZ sh[MSM_RB];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
@@ -348,7 +384,6 @@ __global__ __launch_bounds__(MSM_RB) void msm_bucket_reduce_kernel(const XYZZ* _
         sh[tid] = acc;
     }
     __syncthreads();
-    // suffix scan: S_j = sum_{j' >= j} B_j'
     for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
         XYZZ v = xyzz_identity();
         const bool has = tid + o < MSM_RB;
@@ -357,9 +392,37 @@ __global__ __launch_bounds__(MSM_RB) void msm_bucket_reduce_kernel(const XYZZ* _
         if (has) sh[tid] = xyzz_add(sh[tid], v);
         __syncthreads();
     }
-    if (tid == 0) st_xyzz(blk_p + (size_t)b * nblk + blk, sh[0]);  // P = S_0
+    st_xyzz(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid, sh[tid]);
+    if (tid == 0) st_xyzz(blk_p + (size_t)b * nblk + blk, sh[0]);
+}
+
+// Stage 2: the global suffix sum at bucket (blk, j) is S_j + BS with BS = sum of the totals of the
+// blocks above.  Every lane adds BS once -- the factor 256 of "256 * BS" is supplied by the 256 lanes,
+// not by a doubling chain -- and a tree gives W' = sum_j (S_j + BS).
+__global__ __launch_bounds__(MSM_RB) void msm_bucket_sum_kernel(const XYZZ* __restrict__ sfx,
+                                                               const XYZZ* __restrict__ blk_p,
+                                                               XYZZ* __restrict__ blk_w, uint32_t nblk) {
+    __shared__ XYZZ sh[MSM_RB];
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    // BS = sum_{blk' > blk} P_blk'   (nblk <= 256)
+    {
+        XYZZ v = xyzz_identity();
+        if (blk + 1 + tid < nblk) v = ld_xyzz(blk_p + (size_t)b * nblk + blk + 1 + tid);
+        sh[tid] = v;
+    }
     __syncthreads();
-    // W = sum_j S_j
+    uint32_t span = 1;
+    while (span < nblk) span <<= 1;
+    for (uint32_t o = span / 2; o > 0; o >>= 1) {
+        if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+        __syncthreads();
+    }
+    {
+        XYZZ bs = sh[0];
+        __syncthreads();
+        sh[tid] = xyzz_add(ld_xyzz(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid), bs);
+    }
+    __syncthreads();
     for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
         if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
         __syncthreads();
@@ -367,38 +430,20 @@ __global__ __launch_bounds__(MSM_RB) void msm_bucket_reduce_kernel(const XYZZ* _
     if (tid == 0) st_xyzz(blk_w + (size_t)b * nblk + blk, sh[0]);
 }
 
-// result = sum_blk W_blk + 256 * sum_blk blk * P_blk, the second sum again as a sum of suffix sums.
-__global__ __launch_bounds__(256) void msm_finish_kernel(const XYZZ* __restrict__ blk_w, const XYZZ* __restrict__ blk_p,
-                                                         uint32_t nblk, XYZZ* __restrict__ out) {
-    __shared__ XYZZ shw[256], shp[256];
+// result = sum_blk W'_blk
+__global__ __launch_bounds__(256) void msm_finish_kernel(const XYZZ* __restrict__ blk_w, uint32_t nblk,
+                                                         XYZZ* __restrict__ out) {
+    __shared__ XYZZ sh[256];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    shw[tid] = tid < nblk ? ld_xyzz(blk_w + (size_t)b * nblk + tid) : xyzz_identity();
-    shp[tid] = tid < nblk ? ld_xyzz(blk_p + (size_t)b * nblk + tid) : xyzz_identity();
+    sh[tid] = tid < nblk ? ld_xyzz(blk_w + (size_t)b * nblk + tid) : xyzz_identity();
     __syncthreads();
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
-    for (uint32_t o = 1; o < span; o <<= 1) {  // suffix sums of P
-        XYZZ v = xyzz_identity();
-        const bool has = tid + o < span;
-        if (has) v = shp[tid + o];
-        __syncthreads();
-        if (has && tid < span) shp[tid] = xyzz_add(shp[tid], v);
-        __syncthreads();
-    }
-    if (tid == 0) shp[0] = xyzz_identity();  // Q = sum_{t >= 1} SufP_t
-    __syncthreads();
     for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (tid < o) {
-            shp[tid] = xyzz_add(shp[tid], shp[tid + o]);
-            shw[tid] = xyzz_add(shw[tid], shw[tid + o]);
-        }
+        if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
         __syncthreads();
     }
-    if (tid == 0) {
-        XYZZ q = shp[0];
-        for (uint32_t d = 0; d < 8; d++) q = xyzz_dbl(q);  // * MSM_RB
-        st_xyzz(out + b, xyzz_add(shw[0], q));
-    }
+    if (tid == 0) st_xyzz(out + b, sh[0]);
 }
 
 static uint32_t default_window_bits(size_t n) {
@@ -487,6 +532,7 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     XYZZ* partial = ws.get<XYZZ>((size_t)B * max_tasks);
     XYZZ* blk_w = ws.get<XYZZ>((size_t)B * nblk);
     XYZZ* blk_p = ws.get<XYZZ>((size_t)B * nblk);
+    XYZZ* sfx = ws.get<XYZZ>((size_t)B * nblk * MSM_RB);
     // a hot bucket holds more than MSM_HEAVY * MSM_K entries
     const uint32_t max_heavy = (uint32_t)(entries / ((uint64_t)MSM_HEAVY * MSM_K)) + 1;
     uint32_t* hmap = ws.get<uint32_t>((size_t)B * (nb + 1));
@@ -503,8 +549,16 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out.  Every
     // stage kernel processes the same B MSMs per launch, so each is charged the same figure.
     const double msm_bytes = (double)B * ((double)N * 96.0 + 96.0);
+    // largest t with r + t*r < 2^(c*W - 1):  t_max = floor(2^(cW-1) / r) - 1, r ~ 2^253.6
+    uint32_t tbits = 0;
+    {
+        const int spare = (int)(c * W) - 1 - 254;  // 2^(cW-1) / 2^254
+        if (spare >= 1) tbits = (uint32_t)spare;   // 2^spare * (2^254 / r) - 1 >= 2^spare with 2^254/r ~ 1.32
+        if (tbits > 6) tbits = 6;
+    }
+    if (const char* e = getenv("ZG_MSM_BALANCE")) tbits = atoi(e) ? tbits : 0;
     ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, c,
-              W, dig);
+              W, tbits, dig);
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, W, off, toff, tot, ttotal, hmap,
@@ -516,9 +570,10 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               ttotal, sorted, max_tasks, partial);
     ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel, dim3(max_heavy < 64 ? max_heavy : 64, B), dim3(256), 0, partial,
               toff, hlist, nheavy, max_tasks, max_heavy, c, hsum);
-    ZG_LAUNCH(ctx, "msm_bucket_reduce", msm_bytes, msm_bucket_reduce_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff, hmap,
-              hsum, max_tasks, max_heavy, c, blk_w, blk_p, nblk);
-    ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel, dim3(B), dim3(256), 0, blk_w, blk_p, nblk, d_out);
+    ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_bucket_scan_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff, hmap,
+              hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
+    ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_bucket_sum_kernel, dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p, blk_w, nblk);
+    ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel, dim3(B), dim3(256), 0, blk_w, nblk, d_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
