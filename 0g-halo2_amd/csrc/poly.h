@@ -76,6 +76,8 @@ int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, con
                          uint32_t n);
 int poly_to_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
 int poly_from_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
+int poly_from_raw_rows(zg_ctx* ctx, const Fe* src, size_t src_stride, Fe* dst, size_t dst_stride, uint32_t rows,
+                       uint32_t len);
 int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab, const Fe& beta,
                       const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups);
 int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe* sigma_val, const Fe* omega_tw,
@@ -97,6 +99,12 @@ int poly_kate_division(zg_ctx* ctx, const Fe* a, size_t a_stride, const Fe* zs_h
                        uint32_t n, uint32_t batch);
 int poly_l_cosets_init(zg_ctx* ctx, Fe* l0, Fe* llast, Fe* lblind, uint32_t n, uint32_t bf);
 int poly_lactive(zg_ctx* ctx, Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en);
+
+// from sort.hip: lookup::prover::permute_expression_pair on the device
+int poly_sort_pad(zg_ctx* ctx, Fe* keys, uint32_t n, uint32_t usable, uint32_t batch);
+int poly_sort_keys(zg_ctx* ctx, Fe* keys, uint32_t n, uint32_t batch);
+int poly_permute_pairs(zg_ctx* ctx, const Fe* a, const Fe* t, Fe* sprime, uint32_t n, uint32_t usable, uint32_t batch,
+                       uint32_t* scratch_u32, Fe* scratch_fe, uint32_t* d_err);
 
 // from ntt.hip
 int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,

@@ -148,6 +148,20 @@ __global__ void from_raw_kernel(const Fe* in, Fe* out, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) stg(out + i, Fr::from_raw(ldg(in + i)));
 }
+// rows of `len` elements: dst[r*dst_stride + i] = from_raw(src[r*src_stride + i])
+__global__ void from_raw_rows_kernel(const Fe* src, size_t src_stride, Fe* dst, size_t dst_stride, uint32_t len) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (i < len) stg(dst + (size_t)r * dst_stride + i, Fr::from_raw(ldg(src + (size_t)r * src_stride + i)));
+}
+int poly_from_raw_rows(zg_ctx* ctx, const Fe* src, size_t src_stride, Fe* dst, size_t dst_stride, uint32_t rows,
+                       uint32_t len) {
+    if (!rows || !len) return ZG_OK;
+    ZG_LAUNCH(ctx, "from_raw", (double)rows * len * 64, from_raw_rows_kernel, dim3((len + 255) / 256, rows), dim3(256), 0, src,
+              src_stride, dst, dst_stride, len);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int poly_to_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count) {
     if (!count) return ZG_OK;
     ZG_LAUNCH(ctx, "to_raw", (double)count * 64, to_raw_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, in, out, count);

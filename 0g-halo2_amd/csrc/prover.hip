@@ -4,15 +4,13 @@
 //
 // Everything between "advice columns assigned" and "proof bytes" stays in HBM: columns, coefficient
 // forms, extended cosets, lookup/permutation products, h(X).  The host only sees what the Fiat-Shamir
-// transcript needs -- commitments (one 128-B XYZZ point each), evaluations (32 B each) -- plus, for
-// now, the compressed lookup columns that lookup::prover::permute_expression_pair sorts (a host
-// std::sort in this round; SURVEY.md 8f item 2 moves it to the device).  Work that does not depend
-// on the next challenge (iNTTs, coset NTTs) is queued behind the commitment MSM so that it runs while
-// the host hashes.
+// transcript needs -- commitments (one 128-B XYZZ point each), evaluations (32 B each).  Even
+// lookup::prover::permute_expression_pair (a sort + BTreeMap walk upstream) runs on the device
+// (sort.hip).  Work that does not depend on the next challenge (iNTTs, coset NTTs) runs on a side
+// stream while the main stream works through the commitment MSM and the host hashes.
 #include <algorithm>
 #include <chrono>
 #include <memory>
-#include <thread>
 
 #include "poly.h"
 #include "transcript.h"
@@ -73,57 +71,6 @@ void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
         for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(st[i] >> (8 * j));
 }
 
-// ------------------------------------------------------------------ host sort of permute_expression_pair
-struct Raw {
-    uint64_t l[4];
-};
-static inline bool raw_less(const Raw& a, const Raw& b) {
-    for (int i = 3; i >= 0; i--) {
-        if (a.l[i] != b.l[i]) return a.l[i] < b.l[i];
-    }
-    return false;
-}
-static inline bool raw_eq(const Raw& a, const Raw& b) { return memcmp(a.l, b.l, 32) == 0; }
-
-// lookup::prover::permute_expression_pair on canonical values (without the blinding tail).
-// a: compressed input (usable entries, sorted in place -> a'), t: compressed table (sorted in place,
-// scratch), out: s'.  Returns false when an input value is missing from the table.
-static bool permute_pair_host(Raw* a, Raw* t, Raw* out, size_t usable) {
-    std::sort(a, a + usable, raw_less);
-    std::sort(t, t + usable, raw_less);
-    // unique table values with multiplicities: the BTreeMap<value, count>
-    std::vector<uint32_t> cnt;
-    size_t nu = 0;
-    for (size_t i = 0; i < usable; i++) {
-        if (i == 0 || !raw_eq(t[i], t[nu - 1])) {
-            t[nu++] = t[i];
-            cnt.push_back(1);
-        } else {
-            cnt.back()++;
-        }
-    }
-    std::vector<uint32_t> repeated;
-    repeated.reserve(usable);
-    size_t cur = 0;  // both sequences ascend: a merge pointer replaces the map lookup
-    for (size_t row = 0; row < usable; row++) {
-        if (row == 0 || !raw_eq(a[row], a[row - 1])) {
-            out[row] = a[row];
-            while (cur < nu && raw_less(t[cur], a[row])) cur++;
-            if (cur == nu || !raw_eq(t[cur], a[row]) || cnt[cur] == 0) return false;
-            cnt[cur]--;
-        } else {
-            repeated.push_back((uint32_t)row);
-        }
-    }
-    for (size_t u = 0; u < nu; u++)
-        for (uint32_t c = 0; c < cnt[u]; c++) {
-            if (repeated.empty()) return false;
-            out[repeated.back()] = t[u];
-            repeated.pop_back();
-        }
-    return repeated.empty();
-}
-
 }  // namespace zg
 
 using namespace zg;
@@ -153,7 +100,8 @@ struct zg_prover {
        *lz_cos = nullptr, *perm_cos = nullptr;
     Fe *cin = nullptr, *ctab = nullptr, *perm = nullptr /* [2NL][n]: a'_l, s'_l */, *zs = nullptr /* [sets+NL][n] */;
     Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *h = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr,
-       *raw = nullptr;
+       *raw = nullptr, *sraw = nullptr, *sort_fe = nullptr;
+    uint32_t *sort_u32 = nullptr, *d_err = nullptr;
     Fe *pin_cos_c = nullptr, *ptab_cos_c = nullptr, *pin_c = nullptr, *ptab_c = nullptr;
     XYZZ* xyzz = nullptr;
     uint32_t* d_idx = nullptr;
@@ -378,6 +326,11 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     ZG_TRY(dalloc(p, &p->tmp, poly_grand_product_tmp_elems(n, mb)));
     ZG_TRY(dalloc(p, &p->h, (size_t)en));
     ZG_TRY(dalloc(p, &p->raw, (size_t)2 * NL * n));
+    ZG_TRY(dalloc(p, &p->sraw, (size_t)NL * n));
+    ZG_TRY(dalloc(p, &p->sort_fe, (size_t)NL * n));
+    ZG_TRY(dalloc(p, &p->sort_u32, (size_t)2 * NL * n + 2 * NL + 2));
+    ZG_TRY(dalloc(p, &p->d_err, NL + 1));
+    ZG_REQUIRE(NL <= 60, ZG_ERR_UNSUPPORTED, "zg_prover_create: %u lookups", NL);
     const uint32_t max_points = 4 + (uint32_t)(p->advice_queries.size() + p->fixed_queries.size());
     ZG_TRY(dalloc(p, &p->pw, (size_t)max_points * n + max_points));
     const uint32_t max_evals = (uint32_t)(p->advice_queries.size() + p->fixed_queries.size()) + P + 3 * S + 5 * NL + 4;
@@ -386,7 +339,7 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     ZG_TRY(dalloc(p, &p->xyzz, std::max<size_t>(std::max<size_t>(A, 2 * NL + 1), std::max<size_t>(S + NL + 1, std::max<size_t>(Q, max_points)))));
     ZG_TRY(dalloc(p, &p->d_idx, (size_t)4 * max_evals + 64 + (size_t)max_points * 512));
     ZG_TRY(dalloc(p, &p->ktmp, poly_kate_tmp_elems(n, max_points)));
-    p->pinned_cap = std::max<size_t>((size_t)4 * NL * n * 32, 1u << 20);
+    p->pinned_cap = 1u << 20;  // commitments (128 B each), evaluations, error flags
     ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocDefault));
 
     // ---- keygen_pk's derived data: fixed / sigma polys + cosets, l_0 / l_last / l_active_row
@@ -523,38 +476,26 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     bool have_random = false;
     if (NL) {
         ZG_TRY(poly_lookup_compress(ctx, p->dc, base_cols, theta, p->cin, p->ctab, n));
+        // permute_expression_pair on the device: canonical keys, bitonic sort of inputs and tables,
+        // scan-based construction of s' (sort.hip).  raw rows [0,NL) = inputs -> a', [NL,2NL) = tables.
         ZG_TRY(poly_to_raw(ctx, p->cin, p->raw, (size_t)NL * n));
         ZG_TRY(poly_to_raw(ctx, p->ctab, p->raw + (size_t)NL * n, (size_t)NL * n));
-        Raw* host = reinterpret_cast<Raw*>(p->pinned);  // [a_0..a_NL-1][t_0..t_NL-1][out s'_0..]  (n each)
-        ZG_HIP(hipMemcpyAsync(host, p->raw, (size_t)2 * NL * n * 32, hipMemcpyDeviceToHost, st));
-        ZG_HIP(hipStreamSynchronize(st));
-        Raw* outbuf = host + (size_t)2 * NL * n;
         auto t_sort = clk::now();
-        std::vector<int> okv(NL, 1);
-        std::vector<std::thread> th;
-        for (uint32_t l = 0; l < NL; l++)
-            th.emplace_back([&, l]() {
-                okv[l] = permute_pair_host(host + (size_t)l * n, host + (size_t)(NL + l) * n, outbuf + (size_t)l * n, usable) ? 1 : 0;
-            });
-        for (auto& t : th) t.join();
+        ZG_TRY(poly_sort_pad(ctx, p->raw, n, usable, 2 * NL));
+        ZG_TRY(poly_sort_keys(ctx, p->raw, n, 2 * NL));
+        ZG_TRY(poly_permute_pairs(ctx, p->raw, p->raw + (size_t)NL * n, p->sraw, n, usable, NL, p->sort_u32, p->sort_fe,
+                                  p->d_err));
+        // perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form) on the usable rows, then the blinding tail
+        ZG_TRY(poly_from_raw_rows(ctx, p->raw, n, p->perm, (size_t)2 * n, NL, usable));
+        ZG_TRY(poly_from_raw_rows(ctx, p->sraw, n, p->perm + n, (size_t)2 * n, NL, usable));
         p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
-        for (uint32_t l = 0; l < NL; l++)
-            if (!okv[l]) {
-                set_error("zg_prover_prove: lookup %u has an input outside its table (ConstraintSystemFailure)", l);
-                (void)hipStreamSynchronize(ss);
-                return ZG_ERR_CONSTRAINT;
-            }
-        // back to the device: perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form), then the blinding tail
-        for (uint32_t l = 0; l < NL; l++) {
-            ZG_HIP(hipMemcpyAsync(p->raw + (size_t)(2 * l) * n, host + (size_t)l * n, (size_t)usable * 32, hipMemcpyHostToDevice, st));
-            ZG_HIP(hipMemcpyAsync(p->raw + (size_t)(2 * l + 1) * n, outbuf + (size_t)l * n, (size_t)usable * 32, hipMemcpyHostToDevice, st));
-        }
-        ZG_TRY(poly_from_raw(ctx, p->raw, p->perm, (size_t)2 * NL * n));
         // blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j
         ZG_TRY(poly_blind_rows(ctx, p->perm, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_INPUT));
         ZG_TRY(poly_blind_rows(ctx, p->perm + n, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_TABLE));
         ZG_TRY(fork());
         ZG_TRY(msm_batch2_dev(ctx, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, n, p->xyzz));
+        uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pinned_cap - 256);
+        ZG_HIP(hipMemcpyAsync(h_err, p->d_err, NL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
         ZG_HIP(hipMemcpyAsync(poly_at(p->ix_perm), p->perm, (size_t)2 * NL * n * 32, hipMemcpyDeviceToDevice, ss));
         ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
@@ -565,6 +506,12 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
             ZG_HIP(hipMemcpyAsync(p->ptab_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l + 1) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, ss));
         }
         ZG_TRY(wait_points(p, 2 * NL + 1, pts));
+        for (uint32_t l = 0; l < NL; l++)
+            if (h_err[l]) {
+                set_error("zg_prover_prove: lookup %u has an input outside its table (ConstraintSystemFailure)", l);
+                (void)hipStreamSynchronize(ss);
+                return ZG_ERR_CONSTRAINT;
+            }
         for (uint32_t i = 0; i < 2 * NL; i++) tr.write_point(pts[i]);
         random_commit = pts[2 * NL];
         have_random = true;
