@@ -109,6 +109,7 @@ struct zg_prover {
     hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
     void* pinned = nullptr;
     size_t pinned_cap = 0;
+    size_t stage_off = 0;
     bool have_last = false;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -140,17 +141,38 @@ Fe rotate_omega(const zg_prover* p, const Fe& x, int32_t rot) {
     return Fr::mul(x, w);
 }
 
+// Small host->device transfers go through a pinned staging arena: hipMemcpyAsync from pageable memory
+// blocks the calling thread until the stream has drained up to the copy, which serialises host and
+// GPU inside a proof and throttles concurrent proof streams.  The arena is a bump allocator reset at
+// the start of every proof; each region is written once per proof.
+constexpr size_t PIN_RESULTS = 0;            // commitments D2H
+constexpr size_t PIN_EVALS = 64 * 1024;      // evaluations D2H
+constexpr size_t PIN_STAGE = 128 * 1024;     // H2D staging arena starts here
+void* stage(zg_prover* p, const void* src, size_t bytes) {
+    size_t off = (p->stage_off + 63) & ~size_t(63);
+    if (off + bytes > p->pinned_cap - 4096) return nullptr;  // caller falls back to a direct copy
+    void* dst = (char*)p->pinned + off;
+    memcpy(dst, src, bytes);
+    p->stage_off = off + bytes;
+    return dst;
+}
+int h2d(zg_prover* p, void* d_dst, const void* src, size_t bytes) {
+    const void* s = stage(p, src, bytes);
+    ZG_HIP(hipMemcpyAsync(d_dst, s ? s : src, bytes, hipMemcpyHostToDevice, p->ctx->stream));
+    return ZG_OK;
+}
+
 // D2H of `count` XYZZ results behind the work already queued; returns after ONLY that copy is done
 int fetch_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
     zg_ctx* ctx = p->ctx;
-    ZG_HIP(hipMemcpyAsync(p->pinned, p->xyzz, count * sizeof(XYZZ), hipMemcpyDeviceToHost, ctx->stream));
+    ZG_HIP(hipMemcpyAsync((char*)p->pinned + PIN_RESULTS, p->xyzz, count * sizeof(XYZZ), hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(hipEventRecord(p->ev, ctx->stream));
     return ZG_OK;
 }
 int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
     ZG_HIP(hipEventSynchronize(p->ev));
     out.resize(count);
-    xyzz_batch_normalise((const XYZZ*)p->pinned, count, reinterpret_cast<zg_g1*>(out.data()));
+    xyzz_batch_normalise((const XYZZ*)((char*)p->pinned + PIN_RESULTS), count, reinterpret_cast<zg_g1*>(out.data()));
     return ZG_OK;
 }
 
@@ -406,6 +428,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     EvmTranscript tr;
     std::vector<Jac> pts;
     p->have_last = false;
+    p->stage_off = PIN_STAGE;
     using clk = std::chrono::steady_clock;
     auto t_start = clk::now(), t_prev = t_start;
     auto lap = [&](int slot) {
@@ -441,8 +464,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         for (uint32_t c = 0; c < I; c++) {
             for (size_t i = 0; i < instance_len; i++) tr.common_scalar(to_fe(&instance[c * instance_len + i]));
             if (instance_len)
-                ZG_HIP(hipMemcpyAsync(p->inst_val + (size_t)c * n, instance + c * instance_len, instance_len * 32,
-                                      hipMemcpyHostToDevice, st));
+                ZG_TRY(h2d(p, p->inst_val + (size_t)c * n, instance + c * instance_len, instance_len * 32));
         }
     }
 
@@ -636,19 +658,23 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         std::vector<uint32_t> list(Q);
         for (uint32_t i = 0; i < Q; i++) list[i] = p->ix_hpiece + (Q - 1 - i);
         uint32_t* dl = p->d_idx + (size_t)4 * (p->advice_queries.size() + p->fixed_queries.size() + P + 3 * S + 5 * NL + 4);
-        ZG_HIP(hipMemcpyAsync(dl, list.data(), Q * 4, hipMemcpyHostToDevice, st));
+        ZG_TRY(h2d(p, dl, list.data(), Q * 4));
         ZG_TRY(poly_horner_combine(ctx, polys, n, dl, Q, xn, fe_zero(), poly_at(p->ix_hpoly), n));
     }
-    ZG_TRY(poly_powers(ctx, points.data(), (uint32_t)points.size(), n, p->pw));
+    {
+        const Fe* pts_pinned = (const Fe*)stage(p, points.data(), points.size() * sizeof(Fe));
+        ZG_TRY(poly_powers(ctx, pts_pinned ? pts_pinned : points.data(), (uint32_t)points.size(), n, p->pw));
+    }
     std::vector<uint32_t> idx(2 * evq.size());
     for (size_t i = 0; i < evq.size(); i++) {
         idx[i] = evq[i].poly;
         idx[evq.size() + i] = evq[i].slot;
     }
-    ZG_HIP(hipMemcpyAsync(p->d_idx, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, st));
+    ZG_TRY(h2d(p, p->d_idx, idx.data(), idx.size() * 4));
     ZG_TRY(poly_dot(ctx, polys, n, n, p->d_idx, p->d_idx + evq.size(), p->pw, (uint32_t)evq.size(), p->evals));
-    std::vector<Fe> ev(evq.size());
-    ZG_HIP(hipMemcpyAsync(ev.data(), p->evals, ev.size() * sizeof(Fe), hipMemcpyDeviceToHost, st));
+    ZG_REQUIRE(evq.size() * sizeof(Fe) <= PIN_STAGE - PIN_EVALS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: too many evaluations");
+    const Fe* ev = reinterpret_cast<const Fe*>((char*)p->pinned + PIN_EVALS);
+    ZG_HIP(hipMemcpyAsync((void*)ev, p->evals, evq.size() * sizeof(Fe), hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
     for (size_t i = 0; i < e_written; i++) tr.write_scalar(ev[i]);
 
@@ -705,18 +731,18 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
                 list.push_back(oq[j].poly);
                 eval_batch = Fr::add(Fr::mul(eval_batch, v), oq[j].eval);
             }
-            // (hipMemcpyAsync from pageable memory stages the bytes before it returns, so `list` can be rebuilt)
             ZG_REQUIRE(list.size() <= 512, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %zu polynomials opened at one point", list.size());
             uint32_t* dl = p->d_idx + (size_t)npts * 512;
-            ZG_HIP(hipMemcpyAsync(dl, list.data(), list.size() * 4, hipMemcpyHostToDevice, st));
+            ZG_TRY(h2d(p, dl, list.data(), list.size() * 4));
             Fe* batch = p->wpoly + (size_t)(2 * npts) * n;
             ZG_TRY(poly_horner_combine(ctx, polys, n, dl, (uint32_t)list.size(), v, eval_batch, batch, n));
             open_points.push_back(points[slot]);
             npts++;
         }
         // one batched kate_division: poly j at wpoly[2j], quotient at wpoly[2j+1]
-        ZG_TRY(poly_kate_division(ctx, p->wpoly, (size_t)2 * n, open_points.data(), p->wpoly + n, (size_t)2 * n, p->ktmp,
-                                  n, npts));
+        const Fe* op_pinned = (const Fe*)stage(p, open_points.data(), open_points.size() * sizeof(Fe));
+        ZG_TRY(poly_kate_division(ctx, p->wpoly, (size_t)2 * n, op_pinned ? op_pinned : open_points.data(), p->wpoly + n,
+                                  (size_t)2 * n, p->ktmp, n, npts));
         // the witness polynomials sit at odd slots: stride 2n
         ZG_TRY(msm_batch_dev(ctx, p->g, p->wpoly + n, (size_t)2 * n, npts, n, p->xyzz));
         ZG_TRY(fetch_points(p, npts, pts));
