@@ -25,6 +25,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
+# ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the
+# proof streams (main + side stream each) need their own queues or they serialise behind each other.
+# Must be set before the HIP runtime initialises (i.e. before torch touches the GPU).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -132,7 +136,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--k", type=int, default=14)
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="independent proofs in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
