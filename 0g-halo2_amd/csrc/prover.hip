@@ -85,6 +85,7 @@ struct zg_prover {
     DevCircuit dc{};
     std::vector<void*> owned;  // device allocations freed at destroy
     zg_bases *g = nullptr, *gl = nullptr;
+    bool own_bases = true;  // false: tables shared with other provers of the same device
     Fe vk_repr{};
     Fe omega{}, omega_inv{}, ifft_div{};
     // pk-derived, resident
@@ -197,8 +198,10 @@ void zg_prover_destroy(zg_prover* p) {
     (void)hipStreamSynchronize(p->ctx->stream);
     if (p->ctx->side) (void)hipStreamSynchronize(p->ctx->side->stream);
     for (void* q : p->owned) (void)hipFree(q);
-    if (p->g) zg_bases_free(p->g);
-    if (p->gl) zg_bases_free(p->gl);
+    if (p->own_bases) {
+        if (p->g) zg_bases_free(p->g);
+        if (p->gl) zg_bases_free(p->gl);
+    }
     if (p->ev) (void)hipEventDestroy(p->ev);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -206,9 +209,26 @@ void zg_prover_destroy(zg_prover* p) {
     delete p;
 }
 
+static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_values, const zg_fr* sigma_values,
+                              const zg_g1_affine* g, const zg_g1_affine* g_lagrange, const zg_bases* shared_g,
+                              const zg_bases* shared_gl, const zg_fr* vk_repr, zg_prover** out);
+
 int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_values, const zg_fr* sigma_values,
                      const zg_g1_affine* g, const zg_g1_affine* g_lagrange, const zg_fr* vk_repr, zg_prover** out) {
-    ZG_REQUIRE(ctx && cs && g && g_lagrange && vk_repr && out, ZG_ERR_INVALID_ARG, "zg_prover_create: null argument");
+    ZG_REQUIRE(g && g_lagrange, ZG_ERR_INVALID_ARG, "zg_prover_create: null SRS");
+    return prover_create_impl(ctx, cs, fixed_values, sigma_values, g, g_lagrange, nullptr, nullptr, vk_repr, out);
+}
+
+int zg_prover_create_shared(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_values, const zg_fr* sigma_values,
+                            const zg_bases* g, const zg_bases* g_lagrange, const zg_fr* vk_repr, zg_prover** out) {
+    ZG_REQUIRE(g && g_lagrange, ZG_ERR_INVALID_ARG, "zg_prover_create_shared: null bases");
+    return prover_create_impl(ctx, cs, fixed_values, sigma_values, nullptr, nullptr, g, g_lagrange, vk_repr, out);
+}
+
+static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_values, const zg_fr* sigma_values,
+                              const zg_g1_affine* g, const zg_g1_affine* g_lagrange, const zg_bases* shared_g,
+                              const zg_bases* shared_gl, const zg_fr* vk_repr, zg_prover** out) {
+    ZG_REQUIRE(ctx && cs && vk_repr && out, ZG_ERR_INVALID_ARG, "zg_prover_create: null argument");
     ZG_REQUIRE(cs->n_fixed == 0 || fixed_values, ZG_ERR_INVALID_ARG, "zg_prover_create: fixed_values is null");
     ZG_REQUIRE(cs->n_perm_columns == 0 || sigma_values, ZG_ERR_INVALID_ARG, "zg_prover_create: sigma_values is null");
     ZG_REQUIRE(cs->cs_degree >= 3 && cs->cs_degree <= 9, ZG_ERR_UNSUPPORTED, "zg_prover_create: cs_degree %u", cs->cs_degree);
@@ -302,8 +322,16 @@ int zg_prover_create(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_value
     p->dc.n_gates = cs->n_gates; p->dc.n_lookups = cs->n_lookups; p->dc.n_perm = p->P; p->dc.chunk = p->chunk;
     p->dc.n_sets = p->sets;
 
-    // ---- SRS
-    {
+    // ---- SRS: upload + window tables, or tables shared with other provers on this device (read-only)
+    if (shared_g) {
+        ZG_REQUIRE(shared_g->ctx->device == ctx->device && shared_gl->ctx->device == ctx->device, ZG_ERR_INVALID_ARG,
+                   "zg_prover_create_shared: bases live on another device");
+        ZG_REQUIRE(shared_g->n == n && shared_gl->n == n && shared_g->c == shared_gl->c, ZG_ERR_INVALID_ARG,
+                   "zg_prover_create_shared: bases do not match 2^k = %u points", n);
+        p->g = const_cast<zg_bases*>(shared_g);
+        p->gl = const_cast<zg_bases*>(shared_gl);
+        p->own_bases = false;
+    } else {
         WsScope ws(ctx);
         Affine* d = ws.get<Affine>(n);
         if (!d) return ZG_ERR_OOM;

@@ -68,6 +68,7 @@ ABI_SYMBOLS = [
     "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
     "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
     "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms",
+    "zg_prover_create_shared",
 ]
 
 
@@ -311,8 +312,9 @@ def keccak256(data: bytes) -> bytes:
 class Prover:
     """zg_prover: create_proof for one circuit (circuit.py CircuitImage) on one GPU."""
 
-    def __init__(self, ctx: Ctx, image, fixed_values: np.ndarray, sigma_values: np.ndarray, g: np.ndarray,
-                 g_lagrange: np.ndarray, vk_repr: np.ndarray):
+    def __init__(self, ctx: Ctx, image, fixed_values: np.ndarray, sigma_values: np.ndarray, g, g_lagrange,
+                 vk_repr: np.ndarray):
+        """g / g_lagrange: uint64[n, 8] host arrays, or two `Bases` handles shared between provers."""
         self.ctx = ctx
         self.image = image
         lib = ctx.lib
@@ -322,11 +324,16 @@ class Prover:
         lib.zg_prover_destroy.restype = None
         fixed_values = np.ascontiguousarray(fixed_values, dtype=np.uint64)
         sigma_values = np.ascontiguousarray(sigma_values, dtype=np.uint64)
-        g = np.ascontiguousarray(g, dtype=np.uint64)
-        g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64)
         h = c_void_p()
-        _check(lib.zg_prover_create(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), _ptr(g),
-                                    _ptr(g_lagrange), _ptr(_fr(vk_repr)), ctypes.byref(h)))
+        if isinstance(g, Bases):
+            self._bases = (g, g_lagrange)  # keep the shared tables alive
+            _check(lib.zg_prover_create_shared(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), g.h,
+                                               g_lagrange.h, _ptr(_fr(vk_repr)), ctypes.byref(h)))
+        else:
+            g = np.ascontiguousarray(g, dtype=np.uint64)
+            g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64)
+            _check(lib.zg_prover_create(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), _ptr(g),
+                                        _ptr(g_lagrange), _ptr(_fr(vk_repr)), ctypes.byref(h)))
         self.h = h
         self.n = 1 << image.c.k
         self.n_advice = image.c.n_advice

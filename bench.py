@@ -67,6 +67,9 @@ class Circuit:
         self.vk_repr = np.array(limbs(0xC0FFEE * MONT % R), dtype=np.uint64)
         self.s = np.array(limbs(0x5EED5EED5EED5EED * MONT % R), dtype=np.uint64)
         self.g, self.gl = ctx.params_new(k, self.s)  # ParamsKZG::new(k) on the GPU
+        # one read-only copy of the MSM window tables per device, shared by every proof stream
+        self.g_bases = ctx.register_bases(self.g)
+        self.gl_bases = ctx.register_bases(self.gl)
 
 
 class ProofJob:
@@ -75,7 +78,7 @@ class ProofJob:
 
     def __init__(self, ctx: zg.Ctx, dev: torch.device, c: Circuit, stream_id: int):
         self.ctx, self.c, self.k, self.cs = ctx, c, c.k, c.cs
-        self.prover = zg.Prover(ctx, c.img, c.fixed, c.sigma, c.g, c.gl, c.vk_repr)
+        self.prover = zg.Prover(ctx, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
         self.d_advice = torch.from_numpy(c.advice.view(np.int64)).to(dev)
         torch.cuda.synchronize(dev)
         self.instance = c.instance
@@ -233,9 +236,16 @@ def main():
         name, (launches, total_ms, abytes) = max(stats.items(), key=lambda kv: kv[1][1])
         avg_ms = total_ms / max(launches, 1)
         achieved = (abytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = None
+        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/, separate runs)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["kernels"]
+            if args.k == 14 and name in pmc:
+                traffic = pmc[name]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roofline = {
             "bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": None, "avg_launch_ms": avg_ms,
+            "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_ms": avg_ms,
             "launches_per_step": launches / args.steps,
             "note": "BASELINE asks for the HBM roofline; the kernels are integer-ALU bound "
                     "(254-bit Montgomery products), see DESIGN.md",

@@ -222,6 +222,13 @@ typedef struct zg_prover zg_prover;
 int zg_prover_create(zg_ctx *ctx, const zg_circuit *circuit, const zg_fr *fixed_values,
                      const zg_fr *sigma_values, const zg_g1_affine *g, const zg_g1_affine *g_lagrange,
                      const zg_fr *vk_repr, zg_prover **out);
+/* Same, with base tables registered once per device (zg_bases_register on any context of that device)
+ * and shared read-only by several provers / proof streams: the window tables are the largest resident
+ * object (2 * W * 2^k * 64 B) and sharing them keeps them in the Infinity Cache.  The bases must outlive
+ * the prover and use the same window size. */
+int zg_prover_create_shared(zg_ctx *ctx, const zg_circuit *circuit, const zg_fr *fixed_values,
+                            const zg_fr *sigma_values, const zg_bases *g, const zg_bases *g_lagrange,
+                            const zg_fr *vk_repr, zg_prover **out);
 void zg_prover_destroy(zg_prover *p);
 /* advice: [n_advice][2^k] column values (host); the last blinding_factors+1 rows are overwritten with
  * blinding scalars as create_proof does.  instance: [n_instance][instance_len] public inputs.

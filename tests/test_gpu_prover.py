@@ -132,3 +132,29 @@ def test_wnn_shaped_circuit_parity_k12_and_verify_k14(ctx, zg, orc):
         bad[100] ^= 4
         assert orc.verify_proof(pk, inst, bytes(bad)) != 1
         prover.close()
+
+
+def test_wnn_shaped_circuit_k15_verifies(ctx, zg, orc):
+    """BASELINE configs[2] size (model_28input_1024entry_2hash_2bpi shape: k = 15, extended domain 2^18):
+    the GPU proof is accepted by the oracle's verifier; shared base tables give the same bytes."""
+    import wnn_shape
+
+    k = 15
+    vk_repr = orc.fr_from_int(0xC0FFEE)
+    cs, asg, ilen = wnn_shape.build("small", k=k, seed=5)
+    img = cs.to_c()
+    params = orc.params_new(k, 0x5EED)
+    fixed, sigma = asg.fixed_values(), asg.sigma_values()
+    pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
+    g, gl = params.g_np(), params.g_lagrange_np()
+    prover = zg.Prover(ctx, img, fixed, sigma, g, gl, vk_repr)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    got = prover.prove(adv, inst, 11)
+    assert orc.verify_proof(pk, inst, got) == 1
+    prover.close()
+    gb, glb = ctx.register_bases(g), ctx.register_bases(gl)
+    shared = zg.Prover(ctx, img, fixed, sigma, gb, glb, vk_repr)
+    assert shared.prove(adv, inst, 11) == got
+    shared.close()
+    gb.free()
+    glb.free()
