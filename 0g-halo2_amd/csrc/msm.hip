@@ -182,28 +182,36 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t* __restri
     for (uint32_t k = tid; k <= nb; k += 1024) cb[k] = hist[k];
 }
 
-// Per vector: bucket totals over the windows, exclusive scans (entry offsets and ceil(total/K) task
-// offsets), the absolute offset of every (window, bucket) cell and the list of hot buckets.  One
-// 1024-lane workgroup; the two passes over the count table are coalesced (lane <-> bucket).
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t c, uint32_t windows,
-                                                        uint32_t* __restrict__ off, uint32_t* __restrict__ toff,
-                                                        uint32_t* __restrict__ tot, uint32_t* __restrict__ ttotal,
-                                                        uint32_t* __restrict__ hmap, uint32_t* __restrict__ hlist,
-                                                        uint32_t* __restrict__ nheavy, uint32_t max_heavy) {
+// Bucket totals over the windows: tot[b][k] = sum_w cnt[b][w][k]   (grid-parallel, coalesced)
+__global__ __launch_bounds__(256) void msm_totals_kernel(const uint32_t* __restrict__ cnt, uint32_t c, uint32_t windows,
+                                                         uint32_t* __restrict__ tot) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (k > nb) return;
+    const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
+    uint32_t v = 0;
+#pragma unroll 8
+    for (uint32_t w = 0; w < windows; w++) v += cb[(size_t)w * (nb + 1) + k];  // independent loads
+    tot[(size_t)b * (nb + 2) + k] = v;
+}
+
+// Per vector: exclusive scans of the bucket totals (entry offsets, in place) and of ceil(total/K)
+// (task offsets), and the list of hot buckets.  One 1024-lane workgroup per vector; the totals are
+// staged in LDS (coalesced in, coalesced out) so that the per-lane strips do not walk HBM.
+__global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t c, uint32_t* __restrict__ toff, uint32_t* __restrict__ tot,
+                                                        uint32_t* __restrict__ ttotal, uint32_t* __restrict__ hmap,
+                                                        uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
+                                                        uint32_t max_heavy) {
+    extern __shared__ uint32_t scan_smem[];  // [nb+2] bucket totals -> entry offsets
     __shared__ uint32_t se[1024], st[1024];
     __shared__ uint32_t hcount;
     const uint32_t nb = 1u << (c - 1);
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
-    uint32_t* ob = off + (size_t)b * windows * (nb + 1);
     uint32_t* to = toff + (size_t)b * (nb + 2);
-    uint32_t* tt = tot + (size_t)b * (nb + 2);  // bucket totals, then exclusive entry offsets
+    uint32_t* tt = tot + (size_t)b * (nb + 2);
+    uint32_t* le = scan_smem;
     if (tid == 0) hcount = 0;
-    for (uint32_t k = tid; k <= nb; k += 1024) {
-        uint32_t v = 0;
-        for (uint32_t w = 0; w < windows; w++) v += cb[(size_t)w * (nb + 1) + k];
-        tt[k] = v;
-    }
+    for (uint32_t k = tid; k <= nb; k += 1024) le[k] = tt[k];
     __syncthreads();
     const uint32_t per = (nb + 1 + 1023) / 1024;
     uint32_t lo = tid * per, hi = lo + per;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     if (hi > nb + 1) hi = nb + 1;
     uint32_t es = 0, ts = 0;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t v = tt[k];
+        uint32_t v = le[k];
         es += v;
         ts += (v + MSM_K - 1) / MSM_K;
     }
@@ -231,9 +239,9 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     uint32_t eb = se[tid] - es, tb = st[tid] - ts;
     for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t v = tt[k];
-        tt[k] = eb;
-        to[k] = tb;
+        const uint32_t v = le[k];
+        le[k] = eb;
+        to[k] = tb;  // write-only: no dependent HBM reads in this strip loop
         eb += v;
         const uint32_t nt = (v + MSM_K - 1) / MSM_K;
         tb += nt;
@@ -247,17 +255,29 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     __syncthreads();
     if (tid == 1023) {
+        le[nb + 1] = se[1023];
         to[nb + 1] = st[1023];
-        tt[nb + 1] = se[1023];
         ttotal[b] = st[1023];
         nheavy[b] = hcount;
     }
-    for (uint32_t k = tid; k <= nb; k += 1024) {
-        uint32_t run = tt[k];
-        for (uint32_t w = 0; w < windows; w++) {
-            ob[(size_t)w * (nb + 1) + k] = run;
-            run += cb[(size_t)w * (nb + 1) + k];
-        }
+    __syncthreads();
+    for (uint32_t k = tid; k <= nb + 1; k += 1024) tt[k] = le[k];
+}
+
+// Absolute offset of every (window, bucket) cell: off[b][w][k] = tot[b][k] + sum_{w' < w} cnt[b][w'][k]
+__global__ __launch_bounds__(256) void msm_offsets_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tot,
+                                                          uint32_t c, uint32_t windows, uint32_t* __restrict__ off) {
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (k > nb) return;
+    const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
+    uint32_t* ob = off + (size_t)b * windows * (nb + 1);
+    uint32_t run = tot[(size_t)b * (nb + 2) + k];
+#pragma unroll 8
+    for (uint32_t w = 0; w < windows; w++) {
+        const uint32_t v = cb[(size_t)w * (nb + 1) + k];
+        ob[(size_t)w * (nb + 1) + k] = run;
+        run += v;
     }
 }
 
@@ -544,6 +564,7 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     static bool lds_attr = false;
     if (!lds_attr) {
         ZG_HIP(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ZG_HIP(hipFuncSetAttribute((const void*)msm_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         lds_attr = true;
     }
     // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out.  Every
@@ -561,8 +582,11 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               W, tbits, dig);
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
-    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), 0, cnt, c, W, off, toff, tot, ttotal, hmap,
-              hlist, nheavy, max_heavy);
+    ZG_LAUNCH(ctx, "msm_totals", msm_bytes, msm_totals_kernel, dim3((nb + 1 + 255) / 256, B), dim3(256), 0, cnt, c, W, tot);
+    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, c, toff, tot, ttotal,
+              hmap, hlist, nheavy, max_heavy);
+    ZG_LAUNCH(ctx, "msm_offsets", msm_bytes, msm_offsets_kernel, dim3((nb + 1 + 255) / 256, B), dim3(256), 0, cnt, tot, c, W,
+              off);
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted);
     ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
