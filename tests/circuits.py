@@ -70,3 +70,78 @@ def toy_circuit(k=5, seed=1, table_bits=4, two_lookups=False, force_degree=None)
         # q_t rows: (a1[r], a1[r-1]) must be (v, 3v): use dedicated rows at the end of the region
         pass
     return cs, asg, 1  # instance_len = 1
+
+
+def variant_circuit(kind: str, k: int = 5, seed: int = 3):
+    """Small circuits that take the prover through its less common paths.
+
+    "no_lookup"      gates + permutation only (the vanishing random polynomial is committed with the
+                     permutation products)
+    "gates_only"     no lookup, no permutation, no instance column
+    "wide_lookup"    one width-2 lookup ((a, b) in {(v, 3v+1)}), two instance columns, no gates
+    """
+    rng = random.Random(seed)
+    cs = ConstraintSystem(k)
+    n = 1 << k
+    if kind == "no_lookup":
+        q = cs.fixed_column()
+        a0, a1 = cs.advice_column(), cs.advice_column()
+        inst = cs.instance_column()
+        for kc in ((ADVICE, a0), (ADVICE, a1), (INSTANCE, inst)):
+            cs.enable_equality(*kc)
+        cs.create_gate([cs.fixed(q) * (cs.advice(a0) * cs.advice(a0) - cs.advice(a1))])
+        asg = Assignment(cs)
+        usable = cs.usable_rows()
+        for r in range(usable - 1):
+            v = rng.randrange(1 << 20)
+            asg.set(FIXED, q, r, 1)
+            asg.set(ADVICE, a0, r, v)
+            asg.set(ADVICE, a1, r, v * v)
+        asg.set(INSTANCE, inst, 0, asg.get(ADVICE, a1, 0))
+        asg.copy((ADVICE, a1, 0), (INSTANCE, inst, 0))
+        asg.set(ADVICE, a0, usable - 1, asg.get(ADVICE, a1, 3))
+        asg.copy((ADVICE, a0, usable - 1), (ADVICE, a1, 3))
+        return cs, asg, 1
+    if kind == "gates_only":
+        q = cs.fixed_column()
+        a0, a1 = cs.advice_column(), cs.advice_column()
+        # q * (a0 + a1(w) - 7): expands to monomials with the bare selector as a term (constant inside the
+        # bracket); q * a0*(a0-1)*(a0-2) = 0.  (Gates must vanish on the blinding rows too, hence q.)
+        cs.create_gate([cs.fixed(q) * (cs.advice(a0) + cs.advice(a1, 1) - 7),
+                        cs.fixed(q) * cs.advice(a0) * (cs.advice(a0) - 1) * (cs.advice(a0) - 2)])
+        asg = Assignment(cs)
+        usable = cs.usable_rows()
+        for r in range(usable - 1):
+            v = rng.randrange(3)
+            asg.set(FIXED, q, r, 1)
+            asg.set(ADVICE, a0, r, v)
+            asg.set(ADVICE, a1, r + 1, 7 - v)
+        return cs, asg, 0
+    if kind == "wide_lookup":
+        t0, t1, q = cs.fixed_column(), cs.fixed_column(), cs.fixed_column()
+        a0, a1 = cs.advice_column(), cs.advice_column()
+        i0, i1 = cs.instance_column(), cs.instance_column()
+        for kc in ((ADVICE, a0), (INSTANCE, i0), (INSTANCE, i1)):
+            cs.enable_equality(*kc)
+        qe = cs.fixed(q)
+        # off rows look up the (0, 1) entry: (q*a0, q*a1 + (1-q))
+        cs.lookup([qe * cs.advice(a0), qe * cs.advice(a1) + (1 - qe)], [cs.fixed(t0), cs.fixed(t1)])
+        asg = Assignment(cs)
+        usable = cs.usable_rows()
+        for r in range(usable):
+            v = r % 9
+            asg.set(FIXED, t0, r, v)
+            asg.set(FIXED, t1, r, 3 * v + 1)
+        for r in range(usable - 3):
+            v = rng.randrange(9)
+            asg.set(FIXED, q, r, 1)
+            asg.set(ADVICE, a0, r, v)
+            asg.set(ADVICE, a1, r, 3 * v + 1)
+        asg.set(INSTANCE, i0, 0, asg.get(ADVICE, a0, 0))
+        asg.set(INSTANCE, i0, 1, asg.get(ADVICE, a0, 1))
+        asg.set(INSTANCE, i1, 1, asg.get(ADVICE, a0, 2))
+        asg.copy((ADVICE, a0, 0), (INSTANCE, i0, 0))
+        asg.copy((ADVICE, a0, 1), (INSTANCE, i0, 1))
+        asg.copy((ADVICE, a0, 2), (INSTANCE, i1, 1))
+        return cs, asg, 2
+    raise ValueError(kind)

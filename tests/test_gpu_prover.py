@@ -158,3 +158,26 @@ def test_wnn_shaped_circuit_k15_verifies(ctx, zg, orc):
     shared.close()
     gb.free()
     glb.free()
+
+
+@pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup"])
+def test_circuit_variants_match_oracle(ctx, zg, orc, kind):
+    """No-lookup / no-permutation / several-instance-column / width-2-lookup paths of the prover."""
+    from circuits import variant_circuit
+
+    k = 6
+    cs, asg, ilen = variant_circuit(kind, k=k)
+    img = cs.to_c()
+    params = orc.params_new(k, 0xABCDEF)
+    vk_repr = orc.fr_from_int(99)
+    fixed, sigma = asg.fixed_values(), asg.sigma_values()
+    pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
+    prover = zg.Prover(ctx, img, fixed, sigma, params.g_np(), params.g_lagrange_np(), vk_repr)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    for seed in (1, 2):
+        st, want, _ = orc.create_proof(pk, adv, inst, seed)
+        assert st == 0
+        got = prover.prove(adv, inst, seed)
+        assert got == want
+        assert orc.verify_proof(pk, inst, got) == 1
+    prover.close()

@@ -99,3 +99,23 @@ def test_wnn_shaped_circuit_proof_verifies(orc):
     n_scalars = 10 + len(cs.fixed_queries) + 1 + 8 + 5 + 20
     assert len(proof) == 64 * 30 + 32 * n_scalars
     assert orc.verify_proof(pk, inst, proof) == 1
+
+
+@pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup"])
+def test_circuit_variants_verify(orc, params5, kind):
+    from circuits import variant_circuit
+
+    cs, asg, ilen = variant_circuit(kind)
+    asg.check()
+    pk = make_pk(orc, cs, asg, params5)
+    inst = asg.instance_values(ilen)
+    st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=2)
+    assert st == 0
+    assert orc.verify_proof(pk, inst, proof) == 1
+    if ilen:
+        wrong = inst.copy()
+        wrong[0, 0] = orc.fr_from_int(424242)
+        assert orc.verify_proof(pk, wrong, proof) != 1
+    bad = bytearray(proof)
+    bad[len(proof) // 2] ^= 0x10
+    assert orc.verify_proof(pk, inst, bytes(bad)) != 1
