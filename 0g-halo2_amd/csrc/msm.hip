@@ -75,27 +75,6 @@ __global__ void msm_table_kernel(const Affine* __restrict__ bases, Affine* __res
 }
 
 // ---------------------------------------------------------------- digits
-// bits [lo, lo+c) of the canonical scalar (zero beyond bit 255)
-__device__ __forceinline__ uint32_t window_bits(const uint32_t raw[8], uint32_t lo, uint32_t c) {
-    uint32_t limb = lo >> 5, sh = lo & 31;
-    if (limb >= 8) return 0;
-    uint64_t v = raw[limb];
-    if (limb + 1 < 8) v |= (uint64_t)raw[limb + 1] << 32;
-    return (uint32_t)(v >> sh) & ((1u << c) - 1);
-}
-
-// signed digit of window w: value in [-(nb-1), nb], returned as bucket index k (0 = none) and sign
-__device__ __forceinline__ void digit_at(const uint32_t raw[8], uint32_t w, uint32_t c, uint32_t nb, uint32_t& k,
-                                         uint32_t& neg) {
-    uint32_t carry = 0, d = 0;
-    for (uint32_t ww = 0; ww <= w; ww++) {
-        d = window_bits(raw, ww * c, c) + carry;
-        carry = d > nb ? 1u : 0u;
-    }
-    neg = carry;
-    k = carry ? (1u << c) - d : d;
-}
-
 // All signed digits of a scalar, once: dig[b][w][i] = bucket index k (0 = no entry) | sign << 31.
 //
 // Balancing: W*c exceeds 254, so the top window of a 254-bit scalar only reaches its lowest few
