@@ -452,7 +452,8 @@ static uint32_t default_window_bits(size_t n) {
     }
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = (int)lg - 1;
+    // measured inside the full proof (tools/sweep_c.sh): k=14 -> 13, k=15 -> 13, k=17 -> 15
+    int c = lg >= 15 ? (int)lg - 2 : (int)lg - 1;
     if (c < 4) c = 4;
     if (c > (int)MSM_MAX_C) c = MSM_MAX_C;
     return (uint32_t)c;
@@ -571,7 +572,7 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
               bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot, toff,
               ttotal, sorted, max_tasks, partial);
-    ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel, dim3(max_heavy < 64 ? max_heavy : 64, B), dim3(256), 0, partial,
+    ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel, dim3(max_heavy < 2048 ? max_heavy : 2048, B), dim3(256), 0, partial,
               toff, hlist, nheavy, max_tasks, max_heavy, c, hsum);
     ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_bucket_scan_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff, hmap,
               hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
