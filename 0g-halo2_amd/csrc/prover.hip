@@ -10,6 +10,7 @@
 // stream while the main stream works through the commitment MSM and the host hashes.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <memory>
 
 #include "poly.h"
@@ -85,6 +86,7 @@ struct zg_prover {
     DevCircuit dc{};
     std::vector<void*> owned;  // device allocations freed at destroy
     zg_bases *g = nullptr, *gl = nullptr;
+    bool use_side = true;   // coefficient / coset forms on a side stream (latency) or inline (throughput)
     bool own_bases = true;  // false: tables shared with other provers of the same device
     Fe vk_repr{};
     Fe omega{}, omega_inv{}, ifft_div{};
@@ -262,7 +264,8 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    if (!ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
+    if (const char* e = getenv("ZG_SIDE_STREAM")) p->use_side = atoi(e) != 0;
+    if (p->use_side && !ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
 
     // ---- validate and upload the circuit tables
     for (uint32_t q = 0; q < cs->n_queries; q++) {
@@ -467,14 +470,18 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
 
     // side stream: coefficient / coset forms of committed columns are computed there while the main
     // stream runs the commitment MSM (whose tail is a chain of dependent EC additions on a few CUs)
-    zg_ctx* sx = ctx->side;
+    // (p->use_side == false: everything stays on the main stream -- the throughput configuration, where
+    // other proofs in flight fill the gaps and every extra HIP stream costs a hardware queue)
+    zg_ctx* sx = p->use_side ? ctx->side : ctx;
     hipStream_t ss = sx->stream;
     auto fork = [&]() -> int {  // side stream continues after everything queued on the main stream so far
+        if (!p->use_side) return ZG_OK;
         ZG_HIP(hipEventRecord(p->ev_fork, st));
         ZG_HIP(hipStreamWaitEvent(ss, p->ev_fork, 0));
         return ZG_OK;
     };
     auto join = [&]() -> int {  // main stream continues after everything queued on the side stream so far
+        if (!p->use_side) return ZG_OK;
         ZG_HIP(hipEventRecord(p->ev_join, ss));
         ZG_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
         return ZG_OK;
