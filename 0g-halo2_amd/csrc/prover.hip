@@ -264,7 +264,6 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    if (const char* e = getenv("ZG_SIDE_STREAM")) p->use_side = atoi(e) != 0;
     if (p->use_side && !ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
 
     // ---- validate and upload the circuit tables
@@ -802,6 +801,18 @@ int zg_prover_prove(zg_prover* p, const zg_fr* advice, const zg_fr* instance, si
     if (p->A)
         ZG_HIP(hipMemcpyAsync(p->adv_val, advice, (size_t)p->A * p->n * 32, hipMemcpyHostToDevice, p->ctx->stream));
     return zg_prover_prove_dev(p, p->adv_val, instance, instance_len, seed, proof, proof_cap, proof_len);
+}
+
+int zg_prover_set_overlap(zg_prover* p, int enable) {
+    ZG_REQUIRE(p, ZG_ERR_INVALID_ARG, "zg_prover_set_overlap: null prover");
+    if (enable && !p->ctx->side) {
+        ZG_HIP(hipSetDevice(p->ctx->device));
+        ZG_TRY(zg_ctx_create(p->ctx->device, &p->ctx->side));
+        p->ctx->side->profiling = p->ctx->profiling;
+        p->ctx->side->prof_filter = p->ctx->prof_filter;
+    }
+    p->use_side = enable != 0;
+    return ZG_OK;
 }
 
 int zg_prover_phase_ms(const zg_prover* p, double* out, size_t cap) {

@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "zg_domain_omega", "zg_ctx_profile_enable", "zg_ctx_profile_collect", "zg_params_new",
     "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
     "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
-    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms",
+    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_set_overlap",
     "zg_prover_create_shared",
 ]
 
@@ -358,6 +358,10 @@ class Prover:
                                                 ctypes.c_uint64(seed), buf, c_size_t(self.proof_cap),
                                                 ctypes.byref(plen)))
         return bytes(buf[: plen.value])
+
+    def set_overlap(self, enable: bool):
+        """True (default): transforms on a side stream (latency); False: one stream per proof (throughput)."""
+        _check(self.ctx.lib.zg_prover_set_overlap(self.h, ctypes.c_int(1 if enable else 0)))
 
     def phase_ms(self) -> list:
         out = (ctypes.c_double * 8)()

@@ -252,6 +252,12 @@ int zg_prover_fetch(zg_prover *p, uint32_t what, uint32_t index, zg_fr *out, siz
  * 5 GWC openings, 6 total. */
 int zg_prover_phase_ms(const zg_prover *p, double *out, size_t cap);
 
+/* Scheduling of one proof on its GPU.  enable = 1 (default): the coefficient / coset transforms run on a
+ * second HIP stream beside the commitment MSMs -- lowest latency for a lone proof.  enable = 0: one
+ * stream per proof -- the throughput configuration when many provers share the GPU (other proofs fill
+ * the gaps, and every extra stream costs a hardware queue).  Proof bytes do not depend on it. */
+int zg_prover_set_overlap(zg_prover *p, int enable);
+
 /* Stand-alone building blocks of the above (device pointers, context stream), exposed for tests. */
 /* z[0] = z0, z[i+1] = z[i] * num[i] / den[i]  (lookup::prover::commit_product / permutation commit). */
 int zg_grand_product_dev(zg_ctx *ctx, const void *d_num, const void *d_den, const zg_fr *z0, size_t n,

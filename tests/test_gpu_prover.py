@@ -55,6 +55,18 @@ def test_proof_bytes_match_oracle_and_verify(ctx, zg, orc, k, force_degree):
     prover.close()
 
 
+def test_single_stream_schedule_gives_the_same_bytes(ctx, zg, orc):
+    """zg_prover_set_overlap only changes which HIP stream the transforms run on."""
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 9)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    st, want, _ = orc.create_proof(pk, adv, inst, 5)
+    assert st == 0
+    for overlap in (False, True, False):
+        prover.set_overlap(overlap)
+        assert prover.prove(adv, inst, 5) == want
+    prover.close()
+
+
 def test_lookup_failure_is_constraint_system_failure(ctx, zg, orc):
     cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 5)
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
