@@ -63,7 +63,7 @@ def domain(j: int, k: int) -> Domain:
 
 class Params(ctypes.Structure):
     _fields_ = [("k", c_uint32), ("n", c_uint64), ("g", c_void_p), ("g_lagrange", c_void_p),
-                ("s", c_uint64 * 4)]
+                ("s", c_uint64 * 4), ("g2", c_uint64 * 16), ("s_g2", c_uint64 * 16)]
 
     def g_np(self) -> np.ndarray:
         n = int(self.n)
@@ -264,6 +264,15 @@ def verify_proof(pk: ProvingKey, instance: np.ndarray, proof: bytes) -> int:
     buf = (ctypes.c_uint8 * len(proof)).from_buffer_copy(proof)
     return int(load().orc_verify_proof(ctypes.byref(pk.c), _p(instance), c_size_t(inst_len), buf,
                                        c_size_t(len(proof))))
+
+
+def verify_proof_pairing(pk: ProvingKey, instance: np.ndarray, proof: bytes) -> int:
+    """KZG/GWC verification with the BN254 pairing (uses g2 / s_g2 only, never the toxic scalar)."""
+    instance = np.ascontiguousarray(instance, dtype=np.uint64)
+    inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0
+    buf = (ctypes.c_uint8 * len(proof)).from_buffer_copy(proof)
+    return int(load().orc_verify_proof_pairing(ctypes.byref(pk.c), _p(instance), c_size_t(inst_len), buf,
+                                               c_size_t(len(proof))))
 
 
 def trace_free(tr: Trace):

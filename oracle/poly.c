@@ -326,6 +326,8 @@ void orc_params_new(orc_params *p, uint32_t k, const orc_fr *s) {
     p->k = k;
     p->n = (uint64_t)1 << k;
     p->s = *s;
+    orc_g2_generator(&p->g2);
+    orc_g2a_mul(&p->s_g2, &p->g2, s);
     size_t n = (size_t)p->n;
     p->g = (orc_g1a *)malloc(n * sizeof(orc_g1a));
     p->g_lagrange = (orc_g1a *)malloc(n * sizeof(orc_g1a));

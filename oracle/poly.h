@@ -15,6 +15,7 @@
 #define ZG_ORACLE_POLY_H
 
 #include "bn254.h"
+#include "pairing.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -73,6 +74,7 @@ typedef struct {
     orc_g1a *g;          /* s^i * G                */
     orc_g1a *g_lagrange; /* L_i(s) * G             */
     orc_fr s;            /* kept for the test-only pairing-free verifier */
+    orc_g2a g2, s_g2;    /* [1]_2, [s]_2: all the pairing verifier may use of s */
 } orc_params;
 
 void orc_params_new(orc_params *p, uint32_t k, const orc_fr *s);

@@ -813,8 +813,25 @@ static void scalar_mul_g(orc_g1 *out, const orc_fr *k) {
     orc_g1_mul(out, &g, k);
 }
 
+static int verify_impl(const orc_pk *pk, const orc_fr *instance_in, size_t instance_len, const uint8_t *proof,
+                       size_t proof_len, int use_pairing);
+
+/* Test-only shortcut: the opening equations are checked in G1 with the known toxic scalar. */
 int orc_verify_proof(const orc_pk *pk, const orc_fr *instance_in, size_t instance_len, const uint8_t *proof,
                      size_t proof_len) {
+    return verify_impl(pk, instance_in, instance_len, proof, proof_len, 0);
+}
+
+/* The public verification equation (gwc/verifier.rs + strategy.rs `SingleStrategy`): after all W_i are
+ * read, u is squeezed and  e(sum u^i W_i, [s]_2) == e(sum u^i (z_i W_i + C_i - e_i G), [1]_2)  is decided
+ * with the pairing; only g2 / s_g2 of the parameters are used. */
+int orc_verify_proof_pairing(const orc_pk *pk, const orc_fr *instance_in, size_t instance_len, const uint8_t *proof,
+                             size_t proof_len) {
+    return verify_impl(pk, instance_in, instance_len, proof, proof_len, 1);
+}
+
+static int verify_impl(const orc_pk *pk, const orc_fr *instance_in, size_t instance_len, const uint8_t *proof,
+                       size_t proof_len, int use_pairing) {
     const zg_circuit *cs = pk->cs;
     const size_t n = (size_t)1 << cs->k;
     const size_t bf = cs->blinding_factors;
@@ -1108,6 +1125,9 @@ int orc_verify_proof(const orc_pk *pk, const orc_fr *instance_in, size_t instanc
     tr_squeeze(&tr, &v);
     {
         int *done = (int *)calloc(nq, sizeof(int));
+        /* pairing mode: the per-point terms wait for u */
+        orc_g1 *pw = (orc_g1 *)malloc(nq * sizeof(orc_g1)), *pr = (orc_g1 *)malloc(nq * sizeof(orc_g1));
+        size_t nsets = 0;
         for (size_t first = 0; first < nq && ok == 1; first++) {
             if (done[first]) continue;
             orc_fr z = qs[first].point, eval_batch = ORC_FR_ZERO;
@@ -1126,15 +1146,41 @@ int orc_verify_proof(const orc_pk *pk, const orc_fr *instance_in, size_t instanc
             if (tr_read_point(&tr, &w)) { ok = -1; break; }
             /* e(W, [s - z]_2) == e(C - eval*G, [1]_2)  <=>  (s - z) W == C - eval G */
             orc_g1 lhs, rhs, wj, eg;
-            orc_fr smz;
-            orc_fr_sub(&smz, &pk->params->s, &z);
             orc_g1_from_affine(&wj, &w);
-            orc_g1_mul(&lhs, &wj, &smz);
             scalar_mul_g(&eg, &eval_batch);
             orc_g1_neg(&eg, &eg);
             orc_g1_add(&rhs, &cb, &eg);
+            if (use_pairing) {
+                orc_g1_mul(&lhs, &wj, &z);      /* z W + C - e G */
+                orc_g1_add(&pr[nsets], &lhs, &rhs);
+                pw[nsets++] = wj;
+                continue;
+            }
+            orc_fr smz;
+            orc_fr_sub(&smz, &pk->params->s, &z);
+            orc_g1_mul(&lhs, &wj, &smz);
             if (!orc_g1_eq(&lhs, &rhs)) ok = 0;
         }
+        if (use_pairing && ok == 1) {
+            orc_fr u;
+            tr_squeeze(&tr, &u);
+            orc_g1 wsum, rsum, t;
+            orc_g1_identity(&wsum);
+            orc_g1_identity(&rsum);
+            for (size_t i = nsets; i-- > 0;) { /* Horner in u */
+                orc_g1_mul(&t, &wsum, &u);
+                orc_g1_add(&wsum, &t, &pw[i]);
+                orc_g1_mul(&t, &rsum, &u);
+                orc_g1_add(&rsum, &t, &pr[i]);
+            }
+            orc_g1_neg(&rsum, &rsum);
+            orc_g1a ps[2];
+            orc_g2a qs2[2] = {pk->params->s_g2, pk->params->g2};
+            orc_g1_to_affine(&ps[0], &wsum);
+            orc_g1_to_affine(&ps[1], &rsum);
+            if (!orc_pairing_check(ps, qs2, 2)) ok = 0;
+        }
+        free(pw); free(pr);
         free(done);
     }
     if (ok == 1 && tr.ipos != proof_len) ok = 0; /* trailing bytes */

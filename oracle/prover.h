@@ -75,6 +75,10 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice, const orc_fr *insta
  * proof verifies, 0 if it does not, negative on malformed input. */
 int orc_verify_proof(const orc_pk *pk, const orc_fr *instance, size_t instance_len, const uint8_t *proof,
                      size_t proof_len);
+/* Same checks, with the opening equation decided by the BN254 pairing from g2 / s_g2 only (the public
+ * verification equation of Wnn::verify_proof, /root/reference/src/wnn.rs:265-280). */
+int orc_verify_proof_pairing(const orc_pk *pk, const orc_fr *instance, size_t instance_len, const uint8_t *proof,
+                             size_t proof_len);
 
 /* Stand-alone pieces, used by the piecewise GPU parity tests. */
 void orc_grand_product(orc_fr *z, const orc_fr *num, const orc_fr *den, const orc_fr *z0, size_t n);

@@ -95,7 +95,7 @@ def test_oracle_reproduces_frozen_proofs(orc, golden):
         st, proof, _ = orc.create_proof(pk, asg.advice_values(), asg.instance_values(ilen), v["blinding_seed"])
         assert st == 0 and proof.hex() == v["proof_hex"], v["name"]
         assert hashlib.sha256(proof).hexdigest() == v["proof_sha256"]
-        assert orc.verify_proof(pk, asg.instance_values(ilen), bytes.fromhex(v["proof_hex"])) == 1
+        assert orc.verify_proof_pairing(pk, asg.instance_values(ilen), bytes.fromhex(v["proof_hex"])) == 1
 
 
 # ------------------------------------------------------------------ GPU: the HIP path against the vectors

@@ -50,7 +50,7 @@ def test_proof_bytes_match_oracle_and_verify(ctx, zg, orc, k, force_degree):
         qpd = cs.degree() - 1
         assert np.array_equal(prover.fetch(5, 0, qpd * n), tr.array("h_pieces", qpd * n)), "h pieces"
         assert got == want, "proof bytes"
-        assert orc.verify_proof(pk, inst, got) == 1
+        assert orc.verify_proof_pairing(pk, inst, got) == 1
         orc.trace_free(tr)
     prover.close()
 
@@ -139,7 +139,7 @@ def test_wnn_shaped_circuit_parity_k12_and_verify_k14(ctx, zg, orc):
         if full_parity:
             st, want, _ = orc.create_proof(pk, adv, inst, 9)
             assert st == 0 and got == want
-        assert orc.verify_proof(pk, inst, got) == 1
+        assert orc.verify_proof_pairing(pk, inst, got) == 1
         bad = bytearray(got)
         bad[100] ^= 4
         assert orc.verify_proof(pk, inst, bytes(bad)) != 1
@@ -162,7 +162,7 @@ def test_wnn_shaped_circuit_k15_verifies(ctx, zg, orc):
     prover = zg.Prover(ctx, img, fixed, sigma, g, gl, vk_repr)
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
     got = prover.prove(adv, inst, 11)
-    assert orc.verify_proof(pk, inst, got) == 1
+    assert orc.verify_proof_pairing(pk, inst, got) == 1
     prover.close()
     gb, glb = ctx.register_bases(g), ctx.register_bases(gl)
     shared = zg.Prover(ctx, img, fixed, sigma, gb, glb, vk_repr)
@@ -191,5 +191,5 @@ def test_circuit_variants_match_oracle(ctx, zg, orc, kind):
         assert st == 0
         got = prover.prove(adv, inst, seed)
         assert got == want
-        assert orc.verify_proof(pk, inst, got) == 1
+        assert orc.verify_proof_pairing(pk, inst, got) == 1
     prover.close()

@@ -35,7 +35,7 @@ def test_toy_proof_verifies(orc, params5, force_degree):
     inst = asg.instance_values(ilen)
     st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=7)
     assert st == 0 and len(proof) > 0
-    assert orc.verify_proof(pk, inst, proof) == 1
+    assert orc.verify_proof(pk, inst, proof) == 1 and orc.verify_proof_pairing(pk, inst, proof) == 1
     # deterministic in the seed, different for another seed
     st2, proof2, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=7)
     assert proof2 == proof
@@ -48,7 +48,7 @@ def test_tampered_proofs_and_wrong_instance_fail(orc, params5):
     pk = make_pk(orc, cs, asg, params5)
     inst = asg.instance_values(ilen)
     st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=1)
-    assert orc.verify_proof(pk, inst, proof) == 1
+    assert orc.verify_proof(pk, inst, proof) == 1 and orc.verify_proof_pairing(pk, inst, proof) == 1
     # flip one bit in an evaluation (scalars start after the commitments) and in a commitment
     for pos in (len(proof) - 64 * 4 - 5, len(proof) - 10, 40):
         bad = bytearray(proof)
@@ -98,7 +98,7 @@ def test_wnn_shaped_circuit_proof_verifies(orc):
     # 6 advice + 8 permuted + 2 perm z + 4 lookup z + 1 random + 5 h + 4 W = 30 points
     n_scalars = 10 + len(cs.fixed_queries) + 1 + 8 + 5 + 20
     assert len(proof) == 64 * 30 + 32 * n_scalars
-    assert orc.verify_proof(pk, inst, proof) == 1
+    assert orc.verify_proof(pk, inst, proof) == 1 and orc.verify_proof_pairing(pk, inst, proof) == 1
 
 
 @pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup"])
@@ -111,7 +111,7 @@ def test_circuit_variants_verify(orc, params5, kind):
     inst = asg.instance_values(ilen)
     st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=2)
     assert st == 0
-    assert orc.verify_proof(pk, inst, proof) == 1
+    assert orc.verify_proof(pk, inst, proof) == 1 and orc.verify_proof_pairing(pk, inst, proof) == 1
     if ilen:
         wrong = inst.copy()
         wrong[0, 0] = orc.fr_from_int(424242)
