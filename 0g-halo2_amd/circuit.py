@@ -3,9 +3,8 @@
 A small mirror of halo2's `ConstraintSystem` (halo2_proofs v2023_04_20 src/plonk/circuit.rs) and of the
 permutation assembly done by keygen (src/plonk/permutation/keygen.rs): columns, cell queries, gate
 polynomials, lookup arguments, equality constraints -> the flat arrays `zg_prover_create` takes.
-It exists to feed tests and bench.py with circuits of the reference's shape; zero_g's real circuit is
-built by the Rust `WnnChip::configure` (/root/reference/src/gadgets/wnn.rs:125-172), which this run
-does not re-implement (out of scope).
+It feeds tests and bench.py: toy circuits (tests/circuits.py), the WNN-shaped circuit (wnn_shape.py)
+and the restatement of zero_g's own `WnnChip::configure` / `predict` (wnn_circuit.py over layouter.py).
 
 Polynomials are kept expanded: {tuple(sorted query indices): coefficient mod r}.
 """
@@ -23,6 +22,7 @@ ROOT_OF_UNITY = pow(7, (R - 1) >> 28, R)
 
 FIXED, ADVICE, INSTANCE = 0, 1, 2
 MAX_FACTORS, MAX_LOOKUP_WIDTH = 8, 4
+SELECTOR_BASE = 1 << 20   # provisional column ids / query indices of selectors before finalize_selectors()
 
 
 def omega_for(k: int) -> int:
@@ -147,6 +147,40 @@ class ConstraintSystem:
     advice_queries: list = field(default_factory=list)   # (column, rotation) in first-query order
     fixed_queries: list = field(default_factory=list)
     instance_queries: list = field(default_factory=list)
+    n_selectors: int = 0
+    selector_columns: list = field(default_factory=list)  # selector id -> fixed column (after finalize_selectors)
+
+    # ---- selectors (circuit.rs `selector` / `complex_selector`).  halo2 keeps selectors virtual until keygen,
+    # where `compress_selectors` turns them into fixed columns appended AFTER the circuit's own fixed
+    # columns, with their cell queries appended after every other query.  finalize_selectors() does the
+    # same, one fixed column per selector (i.e. without halo2's optional merging of simple selectors).
+    def selector(self) -> int:
+        self.n_selectors += 1
+        return self.n_selectors - 1
+
+    complex_selector = selector
+
+    def query_selector(self, s: int) -> "Expr":
+        assert not self.selector_columns, "selectors already finalized"
+        return Expr({(SELECTOR_BASE + s,): 1})
+
+    def finalize_selectors(self):
+        assert not self.selector_columns
+        self.selector_columns = [self.fixed_column() for _ in range(self.n_selectors)]
+        used = set()
+        for e in self.gates + [x for ins, tabs in self.lookups for x in ins + tabs]:
+            for key in e.terms:
+                used.update(qi - SELECTOR_BASE for qi in key if qi >= SELECTOR_BASE)
+        remap = {}
+        for s in sorted(used):
+            self.q(FIXED, self.selector_columns[s], 0)
+            remap[SELECTOR_BASE + s] = self.queries.index((FIXED, self.selector_columns[s], 0))
+
+        def fix(e: "Expr") -> "Expr":
+            return Expr({tuple(sorted(remap.get(qi, qi) for qi in key)): v for key, v in e.terms.items()})
+
+        self.gates = [fix(g) for g in self.gates]
+        self.lookups = [([fix(e) for e in ins], [fix(e) for e in tabs]) for ins, tabs in self.lookups]
 
     # ---- columns
     def fixed_column(self) -> int:

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- create_proof of zero_g's WNN circuit shape on MI355X (BASELINE.json metric).
+"""bench.py -- create_proof of zero_g's WNN circuit on MI355X (BASELINE.json metric).
 
 A "step" is one batch of `--streams` (default 16) full create_proofs, one per proof stream of the GPU,
 all in flight together; K steps = K x streams proofs, and value = proofs / hour.  One create_proof
-(zg_prover_prove_dev) goes from the assigned advice columns, resident in HBM, to the proof bytes -- 30 commitment MSMs, 21 iNTT + 21 coset NTT + 1 extended iNTT, the 4
-lookup arguments (compression, permutation, grand products), the 2-set permutation argument,
-evaluate_h over the 2^17-point extended coset, ~60 polynomial evaluations, the 4 GWC openings and the
-Keccak-256 EvmTranscript, for a circuit of the shape of model_28input_256entry_1hash_1bpi
-(k = 14; 0g-halo2_amd/wnn_shape.py).  The SRS tables, the proving key (fixed /
-sigma polynomials and cosets) and the witness are in HBM before the timed region, as in the
-reference's own bench (benches/bench.rs:30-36 times only `wnn.proof`).
+(zg_prover_prove_dev) goes from the assigned advice columns, resident in HBM, to the proof bytes -- 30
+commitment MSMs, 21 iNTT + 21 coset NTT + 1 extended iNTT, the 4 lookup arguments (compression,
+permutation, grand products), the 2-set permutation argument, evaluate_h over the 2^17-point extended
+coset, 67 polynomial evaluations, the 4 GWC openings and the Keccak-256 EvmTranscript -- for zero_g's
+WnnCircuit of model_28input_256entry_1hash_1bpi (k = 14) on benches/example_image_7.png: the real
+constraint system and the real inference witness (0g-halo2_amd/wnn_circuit.py restates WnnChip; the
+class scores it proves are the reference's snapshot, tests/test_wnn_circuit.py).  The SRS tables, the
+proving key (fixed / sigma polynomials and cosets) and the witness are in HBM before the timed region,
+as in the reference's own bench (benches/bench.rs:30-36 times only `wnn.proof`).
 
     python bench.py --gpus N --steps K --warmup W          (N > 1 via torch.distributed.run)
 
@@ -34,12 +36,16 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
 import torch
 
-import wnn_shape
+import wnn_circuit
+import wnn_model
 import zg_halo2 as zg
 
 R = zg.FR_MODULUS
 MONT = (1 << 256) % R
-MODEL = {14: "tiny", 15: "small", 17: "large"}
+# the four configurations of BASELINE.json: (k, model); "large" is a seeded stand-in of the same shape
+# because model_49input_8192entry_4hash_6bpi.hdf5 is not in the reference checkout (.MISSING_LARGE_BLOBS)
+MODELS = {"tiny": wnn_model.MNIST_TINY, "small": wnn_model.MNIST_SMALL, "medium": wnn_model.MNIST_MEDIUM,
+          "large": wnn_model.MNIST_LARGE}
 
 
 def limbs(x):
@@ -58,9 +64,13 @@ def host_cores() -> int:
 class Circuit:
     """Host-side material shared by every proof stream: circuit image, pk values, witness, SRS."""
 
-    def __init__(self, ctx: zg.Ctx, k: int, seed: int):
-        self.k = k
-        self.cs, self.asg, self.ilen = wnn_shape.build(MODEL.get(k, "tiny"), k=k, seed=seed)
+    def __init__(self, ctx: zg.Ctx, model: str):
+        self.k, self.model_name = MODELS[model]
+        wnn = wnn_model.synthetic_wnn() if model == "large" else wnn_model.load_checked_in(self.model_name)
+        # zero_g's WnnCircuit for this model, synthesised on benches/example_image_7.png: the real
+        # constraint system, fixed / sigma columns and witness (wnn_circuit.py restates WnnChip)
+        self.cs, self.asg, self.ilen, self.scores = wnn_circuit.build(wnn, wnn_model.load_test_image(), self.k)
+        k = self.k
         self.img = self.cs.to_c()
         self.fixed, self.sigma = self.asg.fixed_values(), self.asg.sigma_values()
         self.advice = self.asg.advice_values()
@@ -158,7 +168,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--k", type=int, default=14)
+    ap.add_argument("--model", choices=sorted(MODELS), default="tiny",
+                    help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
     ap.add_argument("--streams", type=int, default=16,
                     help="proofs per step = independent proofs in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,7 +195,7 @@ def main():
 
     nstreams = max(1, args.streams)
     ctxs = [zg.Ctx(local_rank) for _ in range(nstreams)]
-    circuit = Circuit(ctxs[0], args.k, seed=rank)
+    circuit = Circuit(ctxs[0], args.model)
     jobs = [ProofJob(ctxs[i], dev, circuit, rank * 64 + i) for i in range(nstreams)]
     job = jobs[0]
 
@@ -271,7 +282,7 @@ def main():
         traffic = None
         try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/, separate runs)
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["kernels"]
-            if args.k == 14 and name in pmc:
+            if args.model == "tiny" and name in pmc:
                 traffic = pmc[name]["hbm_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -284,14 +295,17 @@ def main():
         }
         kernel_ms = sum(v[1] for v in split.values()) / 2
         out = {
-            "metric": "create_proof proofs/hour, model_28input_256entry_1hash_1bpi shape",
+            "metric": f"create_proof proofs/hour, {circuit.model_name}",
             "value": proofs_per_hour, "unit": "proofs/hour", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)",
             "data": "synthetic",
-            "config": {"workload": f"full create_proof, WNN-shaped circuit (6 advice, 23 fixed, 12 gates, 4 lookups, "
-                                   f"8 equality columns, degree 6) k={args.k}, extended domain 2^{job.cs.extended_k()}, "
-                                   f"proof {len(job.last)} B",
+            "config": {"workload": f"full create_proof of zero_g's WnnCircuit for {circuit.model_name} on "
+                                   f"example_image_7.png (6 advice, 23 fixed, 12 gates, 4 lookups, 8 equality columns, "
+                                   f"degree 6), k={circuit.k}, extended domain 2^{job.cs.extended_k()}, proof {len(job.last)} B"
+                                   + (" [seeded stand-in model: the file is absent from the reference]"
+                                      if args.model == "large" else ""),
+                       "class_scores": circuit.scores,
                        "proofs_per_step": nstreams,
                        "parallelism": f"{world} GPU(s) x {nstreams} independent proof stream(s) per GPU"},
             "proofs_per_step": nstreams, "ms_per_proof": ms_per_proof,

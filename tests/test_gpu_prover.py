@@ -193,3 +193,50 @@ def test_circuit_variants_match_oracle(ctx, zg, orc, kind):
         assert got == want
         assert orc.verify_proof_pairing(pk, inst, got) == 1
     prover.close()
+
+
+def _real_model(orc, zg, ctx, which):
+    import wnn_circuit
+    import wnn_model
+
+    k, name = which
+    cs, asg, ilen, scores = wnn_circuit.build(wnn_model.load_checked_in(name), wnn_model.load_test_image(), k)
+    img = cs.to_c()
+    params = orc.params_new(k, 0x5EED)
+    vk_repr = orc.fr_from_int(0xC0FFEE)
+    pk = orc.ProvingKey(img, asg.fixed_values(), asg.sigma_values(), params, vk_repr)
+    prover = zg.Prover(ctx, img, asg.fixed_values(), asg.sigma_values(), params.g_np(), params.g_lagrange_np(), vk_repr)
+    return cs, asg, ilen, scores, pk, prover
+
+
+def test_real_wnn_circuit_tiny_proof_bytes_match_oracle(ctx, zg, orc):
+    """zero_g's WnnCircuit for model_28input_256entry_1hash_1bpi on example_image_7 (BASELINE configs[1]):
+    the GPU proof is byte-identical to the oracle's and satisfies the public pairing equation."""
+    import wnn_model
+
+    orc.load().orc_set_threads(16)
+    cs, asg, ilen, scores, pk, prover = _real_model(orc, zg, ctx, wnn_model.MNIST_TINY)
+    assert scores == [9, 6, 13, 10, 17, 10, 9, 26, 11, 16]
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    for seed in (1, 99):
+        got = prover.prove(adv, inst, seed)
+        st, want, _ = orc.create_proof(pk, adv, inst, seed)
+        assert st == 0 and got == want
+    assert orc.verify_proof_pairing(pk, inst, got) == 1
+    wrong = inst.copy()
+    wrong[0, 0] = orc.fr_from_int(scores[0] + 1)
+    assert orc.verify_proof_pairing(pk, wrong, got) != 1
+    prover.close()
+
+
+def test_real_wnn_circuit_small_k15_verifies(ctx, zg, orc):
+    """model_28input_1024entry_2hash_2bpi (BASELINE configs[2], k = 15): GPU proof, pairing verifier."""
+    import wnn_model
+
+    orc.load().orc_set_threads(16)
+    cs, asg, ilen, scores, pk, prover = _real_model(orc, zg, ctx, wnn_model.MNIST_SMALL)
+    assert scores == [17, 13, 25, 27, 29, 21, 15, 55, 27, 32]
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    got = prover.prove(adv, inst, 5)
+    assert orc.verify_proof_pairing(pk, inst, got) == 1
+    prover.close()

@@ -1,0 +1,111 @@
+"""zero_g's WnnCircuit restated (0g-halo2_amd/wnn_circuit.py over layouter.py) on the checked-in models.
+
+What the reference's own tests pin on this side of the path, reproduced here:
+  * `mock_proof_mnist_{tiny,small,medium}` (tests/integration_test.rs:6,24,42): the circuit is satisfied for
+    benches/example_image_7.png at k = 14 / 15 / 15 with the class scores as public inputs;
+  * `snapshot_mnist_*_predictions`: those scores;
+  * constraint-system shape of SURVEY.md appendix A (12 gates, 4 lookups, degree 6, 8 equality columns,
+    advice rotations), and the row budget: each model needs exactly the k the reference uses.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import wnn_circuit as wc
+import wnn_model as wm
+from circuit import ADVICE
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def snapshots():
+    with open(os.path.join(HERE, "golden", "vectors.json")) as f:
+        return json.load(f)["reference"]["predictions"]
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    k, name = wm.MNIST_TINY
+    wnn = wm.load_checked_in(name)
+    circuit = wc.WnnCircuit(wnn, k)
+    asg, scores = circuit.synthesize(wm.load_test_image())
+    return wnn, circuit, asg, scores
+
+
+def test_constraint_system_shape_is_appendix_a(tiny):
+    _, circuit, _, _ = tiny
+    cs = circuit.cs
+    assert (cs.n_advice, cs.n_instance, len(cs.gates), len(cs.lookups)) == (6, 1, 12, 4)
+    assert cs.n_fixed == 1 + 6 + 16  # constants, 6 table columns, 16 selectors (uncompressed)
+    assert cs.degree() == 6 and cs.extended_k() == cs.k + 3 and cs.blinding_factors() == 5
+    assert len(cs.perm_columns) == 8
+    assert [len(t) for _, t in cs.lookups] == [3, 3, 1, 1]
+    # rotations queried: a0 {0,+1}; a1..a3 {0}; a4 {0,+1}; a5 {-1,0,+1}
+    assert sorted(cs.advice_queries) == sorted([(0, 0), (0, 1), (1, 0), (2, 0), (3, 0), (4, 0), (4, 1),
+                                                (5, -1), (5, 0), (5, 1)])
+    assert [g.degree() for g in cs.gates] == [3, 2, 3, 3, 3, 3, 2, 2, 4, 2, 2, 2]
+
+
+def test_mock_proof_mnist_tiny(tiny, snapshots):
+    wnn, circuit, asg, scores = tiny
+    assert scores == snapshots[wm.MNIST_TINY[1]] == wnn.predict(wm.load_test_image())
+    asg.check()  # MockProver::assert_satisfied
+    assert asg.instance[0][:10] == scores
+    # the reference proves this model at k = 14: the layout must need more than 2^13 rows and fit 2^14
+    assert (1 << 13) - 6 < circuit.rows_used <= (1 << 14) - 6
+
+
+@pytest.mark.parametrize("k,name", [wm.MNIST_SMALL, wm.MNIST_MEDIUM])
+def test_mock_proof_mnist_small_medium(snapshots, k, name):
+    wnn = wm.load_checked_in(name)
+    circuit = wc.WnnCircuit(wnn, k)
+    asg, scores = circuit.synthesize(wm.load_test_image())
+    assert scores == snapshots[name]
+    asg.check()
+    assert (1 << (k - 1)) - 6 < circuit.rows_used <= (1 << k) - 6  # needs exactly the reference's k
+
+
+def test_large_shape_needs_k17():
+    wnn = wm.synthetic_wnn()  # stand-in for the absent model_49input_8192entry_4hash_6bpi
+    circuit = wc.WnnCircuit(wnn, wm.MNIST_LARGE[0])
+    _, scores = circuit.synthesize(wm.load_test_image())
+    assert scores == wnn.predict(wm.load_test_image())
+    assert (1 << 16) - 6 < circuit.rows_used <= (1 << 17) - 6
+
+
+def test_keygen_does_not_depend_on_the_image(tiny):
+    """Wnn::generate_proving_key synthesises a zero image (wnn.rs:222-229): fixed columns and the
+    permutation must come out the same as for a real image."""
+    wnn, circuit, asg, _ = tiny
+    asg0, _ = circuit.synthesize(np.zeros((28, 28), np.uint8))
+    assert asg0.fixed == asg.fixed
+    assert asg0.mapping == asg.mapping
+    assert asg0.advice != asg.advice
+
+
+def test_a_wrong_witness_is_caught(tiny):
+    _, circuit, _, _ = tiny
+    asg, scores = circuit.synthesize(wm.load_test_image())
+    row = next(r for r in range(asg.n) if asg.fixed[circuit.cs.selector_columns[-1]][r])  # a bits2num row
+    asg.advice[4][row + 1] = (asg.advice[4][row + 1] + 1) % wc.R
+    with pytest.raises(AssertionError):
+        asg.check()
+
+
+def test_oracle_proves_and_pairing_verifies_the_real_tiny_circuit(orc, tiny):
+    _, circuit, asg, scores = tiny
+    cs = circuit.cs
+    orc.load().orc_set_threads(8)
+    params = orc.params_new(cs.k, 0x5EED)
+    pk = orc.ProvingKey(cs.to_c(), asg.fixed_values(), asg.sigma_values(), params, orc.fr_from_int(0xC0FFEE))
+    inst = asg.instance_values(len(scores))
+    st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, 1)
+    # 30 points (6 advice, 8 permuted, 2+4 products, 1 random, 5 h pieces, 4 openings) + 67 evaluations
+    assert st == 0 and len(proof) == 30 * 64 + (10 + 23 + 1 + 8 + 5 + 20) * 32 <= orc.proof_size(cs.to_c())
+    assert orc.verify_proof_pairing(pk, inst, proof) == 1
+    wrong = inst.copy()
+    wrong[0, 7] = orc.fr_from_int(scores[7] + 1)
+    assert orc.verify_proof_pairing(pk, wrong, proof) != 1

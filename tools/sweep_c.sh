@@ -1,8 +1,8 @@
 #!/bin/bash
-# window-size sensitivity of the MSM inside the full proof (tuning aid): ./tools/sweep_c.sh K C...
-K=${1:-14}; shift
+# window-size sensitivity of the MSM inside the full proof (tuning aid): ./tools/sweep_c.sh MODEL C...
+M=${1:-tiny}; shift
 for c in "$@"; do
-  ZG_MSM_C=$c python bench.py --k $K --steps 6 --warmup 1 --no-cpu-baseline 2>/dev/null > /tmp/b.json
+  ZG_MSM_C=$c python bench.py --model $M --steps 6 --warmup 1 --no-cpu-baseline 2>/dev/null > /tmp/b.json
   python - "$c" <<'PY'
 import json,sys
 d=json.load(open('/tmp/b.json')); k=d["single_proof_kernels_ms"]
