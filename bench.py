@@ -299,7 +299,8 @@ def main():
             "value": proofs_per_hour, "unit": "proofs/hour", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)",
-            "data": "synthetic",
+            "data": ("checked-in model + benches/example_image_7.png (fixtures from the reference checkout), "
+                     "seeded SRS" if args.model != "large" else "synthetic (seeded stand-in model), seeded SRS"),
             "config": {"workload": f"full create_proof of zero_g's WnnCircuit for {circuit.model_name} on "
                                    f"example_image_7.png (6 advice, 23 fixed, 12 gates, 4 lookups, 8 equality columns, "
                                    f"degree 6), k={circuit.k}, extended domain 2^{job.cs.extended_k()}, proof {len(job.last)} B"
