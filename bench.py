@@ -31,7 +31,10 @@ sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
 # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the
 # proof streams (main + side stream each) need their own queues or they serialise behind each other.
 # Must be set before the HIP runtime initialises (i.e. before torch touches the GPU).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# 16 proof streams -> 16 queues; RCCL (N > 1: barrier + max over ranks) brings streams of its own, and
+# with them 20 queues measure best (tools/sweep_dist.sh: 16 -> 2.06, 20 -> 1.77, 24 -> 1.90 ms/proof).
+_dist = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ZG_BENCH_FORCE_DIST") == "1"
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20" if _dist else "16")
 
 import numpy as np
 import torch
@@ -185,7 +188,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("ZG_BENCH_FORCE_DIST") == "1":  # (the env knob rehearses the RCCL path on one GPU)
         import torch.distributed as dist_mod
 
         dist = dist_mod
