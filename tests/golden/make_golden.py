@@ -140,6 +140,17 @@ def oracle_vectors():
     out.append(proof_case("toy_k8_degree6", cs, asg, ilen, 8, 0xABCDEF, 0x1234567, 2))
     cs, asg, ilen = wnn_shape.build("tiny", k=12, seed=1)
     out.append(proof_case("wnn_shape_k12", cs, asg, ilen, 12, 0x5EED, 0xC0FFEE, 7))
+    # zero_g's real WnnCircuit for model_28input_256entry_1hash_1bpi on example_image_7 (k = 14): digest only
+    import wnn_circuit
+    import wnn_model
+
+    k, name = wnn_model.MNIST_TINY
+    cs, asg, ilen, scores = wnn_circuit.build(wnn_model.load_checked_in(name), wnn_model.load_test_image(), k)
+    orc.load().orc_set_threads(8)
+    case = proof_case("wnn_real_tiny_k14", cs, asg, ilen, k, 0x5EED, 0xC0FFEE, 7)
+    del case["proof_hex"]
+    case["class_scores"] = scores
+    out.append(case)
     # large-size digests: MSM 2^14 over the seeded SRS, iNTT 2^14, coset NTT 2^14 -> 2^17
     k = 14
     prm = orc.params_new(k)
