@@ -1,0 +1,260 @@
+// Nine 29-bit limbs: the register form of Fq used inside the MSM bucket accumulation (device only).
+//
+// Why: with 32-bit limbs a column of partial products overflows a 64-bit accumulator after one
+// product, so every v_mad_u64_u32 drags a v_addc_co_u32 behind it (128 + 128 per Montgomery product).
+// With 29-bit limbs a whole column (9 data products + 9 reduction products < 2^62.2) fits the 64-bit
+// accumulator: every partial product is ONE v_mad_i64_i32 and there is no carry word -- 162 mads and
+// ~70 other instructions per product instead of ~340 (measured: 167 vs 134 G products/s,
+// tools/mont29_probe.hip).
+//
+// Representation: value = sum l[i] * 2^(29 i), limbs SIGNED.  "Normalised": l[0..7] in [0, 2^29),
+// l[8] a small signed remainder.  Elements are residues mod p, NOT kept canonical: the Montgomery
+// radix is 2^261 >> p, so a product of values of magnitude < 2^258 lands in (-2^256, 2^256 + p) with
+// no final subtraction; additions and subtractions are plain limb-wise (no carries, no bias), and the
+// only rule is that an operand of mul9 has limb magnitudes < 2^29 -- true for normalised values and
+// for the difference of two normalised values (sums need norm9 first).
+// Montgomery form here is x * 2^261; conversion from / to the library's x * 2^256 form is one product
+// by a constant (k266 / k256).  Memory keeps the packed 8 x 32-bit canonical form.
+#pragma once
+
+#include "field.h"
+
+namespace zg {
+
+struct F9 {
+    int32_t l[9];
+};
+
+constexpr int32_t MASK29 = (1 << 29) - 1;
+
+struct Fq9Params {
+    static __device__ __forceinline__ int32_t p(int i) {
+        constexpr int32_t P[9] = {0x187cfd47, 0x010460b6, 0x1c72a34f, 0x02d522d0, 0x1585d978,
+                                  0x02db40c0, 0x00a6e141, 0x0e5c2634, 0x0030644e};
+        return P[i];
+    }
+    static constexpr uint32_t INV29 = 0x04866389u;  // -p^-1 mod 2^29
+    static __device__ __forceinline__ F9 one() {    // 2^261 mod p
+        return F9{{0x157ccc21, 0x141c2758, 0x185230d3, 0x014c0419, 0x0aa36fb9, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836}};
+    }
+    static __device__ __forceinline__ F9 k256() {   // 2^256 mod p: mul9(x * 2^261, k256) = x * 2^256
+        return F9{{0x058f0d9d, 0x1aea1c6e, 0x11c2cf74, 0x11d651eb, 0x1462c0a7, 0x11b7bc3c, 0x1cbd99ba, 0x183340fb, 0x000e0a77}};
+    }
+    // 2^261 mod p as an 8 x 32-bit integer: Fq::mul(X, c261) = X * 2^5, i.e. x*2^256 -> x*2^261
+    static ZG_HD Fe c261_fe() {
+        return Fe{{0x157ccc21u, 0x4e8384ebu, 0x0ce148c3u, 0xfb90a602u, 0x819caa36u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u}};
+    }
+};
+
+// 8 x 32-bit packed (canonical, < 2^256) -> normalised limbs
+__device__ __forceinline__ F9 f9_unpack(const Fe& a) {
+    F9 o;
+    o.l[0] = (int32_t)(a.l[0] & (uint32_t)MASK29);
+#pragma unroll
+    for (int i = 1; i < 8; i++) {
+        const int bit = 29 * i, w = bit / 32, s = bit % 32;
+        const uint64_t two = ((uint64_t)a.l[w + 1] << 32) | a.l[w];  // (selects to v_alignbit_b32)
+        o.l[i] = (int32_t)((uint32_t)(two >> s) & (uint32_t)MASK29);
+    }
+    o.l[8] = (int32_t)(a.l[7] >> 8);
+    return o;
+}
+
+// canonical normalised limbs (all in [0, 2^29), value < 2^256) -> packed
+__device__ __forceinline__ Fe f9_pack(const F9& a) {
+    Fe o;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+        const int bit = 32 * w, i = bit / 29, s = bit % 29;  // word w starts inside limb i at bit s
+        uint32_t v = (uint32_t)a.l[i] >> s;
+        v |= (uint32_t)a.l[i + 1] << (29 - s);
+        if (29 - s + 29 < 32 && i + 2 < 9) v |= (uint32_t)a.l[i + 2] << (58 - s);
+        o.l[w] = v;
+    }
+    return o;
+}
+
+// carry propagation: l[0..7] into [0, 2^29), l[8] takes the signed remainder (value unchanged)
+__device__ __forceinline__ F9 f9_norm(const F9& a) {
+    F9 o;
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int32_t v = a.l[i] + c;
+        o.l[i] = v & MASK29;
+        c = v >> 29;
+    }
+    o.l[8] = a.l[8] + c;
+    return o;
+}
+
+__device__ __forceinline__ F9 f9_add(const F9& a, const F9& b) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + b.l[i];
+    return o;
+}
+__device__ __forceinline__ F9 f9_sub(const F9& a, const F9& b) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = a.l[i] - b.l[i];
+    return o;
+}
+__device__ __forceinline__ F9 f9_neg(const F9& a) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = -a.l[i];
+    return o;
+}
+__device__ __forceinline__ bool f9_limbs_zero(const F9& a) {
+    int32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= a.l[i];
+    return o == 0;
+}
+
+template <class P>
+struct Field9 {
+    // a * b * 2^-261 mod p.  Operand limb magnitudes < 2^29 (one of them may reach 2^30); operand
+    // values of magnitude < 2^258.  Result normalised, value in (-2^256, 2^256 + p).
+    static __device__ __forceinline__ F9 mul(const F9& a, const F9& b) {
+        int64_t acc = 0;
+        int32_t m[9];
+        F9 r;
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < 9) acc += (int64_t)a.l[i] * (int64_t)b.l[j];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (i < k && j >= 0 && j < 9) acc += (int64_t)m[i] * (int64_t)P::p(j);
+            }
+            if (k < 9) {
+                m[k] = (int32_t)(((uint32_t)acc * P::INV29) & (uint32_t)MASK29);
+                acc += (int64_t)m[k] * (int64_t)P::p(0);
+                acc >>= 29;
+            } else {
+                r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK29);
+                acc >>= 29;
+            }
+        }
+        r.l[8] = (int32_t)acc;
+        return r;
+    }
+    static __device__ __forceinline__ F9 sqr(const F9& a) { return mul(a, a); }
+
+    // value in (-2p, 3p), any limbs -> the canonical representative in [0, p), normalised
+    static __device__ F9 canon(const F9& x) {
+        F9 a = f9_norm(x);
+        F9 pp;
+#pragma unroll
+        for (int i = 0; i < 9; i++) pp.l[i] = P::p(i);
+#pragma unroll 1
+        for (int it = 0; it < 2; it++)
+            if (a.l[8] < 0) a = f9_norm(f9_add(a, pp));
+#pragma unroll 1
+        for (int it = 0; it < 2; it++) {
+            F9 t = f9_norm(f9_sub(a, pp));
+            if (t.l[8] >= 0) a = t;
+        }
+        return a;
+    }
+
+    // exact test x == 0 (mod p) for a NORMALISED value in [0, 8p): the low limb filters, the rare hit is
+    // settled by subtraction
+    static __device__ bool is_zero_mod_p(const F9& a) {
+        bool cand = false;
+        uint32_t lo = 0;  // low limb of j*p
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            cand |= (uint32_t)a.l[0] == lo;
+            lo = (lo + (uint32_t)P::p(0)) & (uint32_t)MASK29;
+        }
+        if (!cand) return false;
+        F9 t = a;
+        F9 pp;
+#pragma unroll
+        for (int i = 0; i < 9; i++) pp.l[i] = P::p(i);
+#pragma unroll 1
+        for (int j = 0; j < 8; j++) {
+            if (f9_limbs_zero(t)) return true;
+            t = f9_norm(f9_sub(t, pp));
+            if (t.l[8] < 0) return false;
+        }
+        return false;
+    }
+};
+
+using Fq9 = Field9<Fq9Params>;
+
+// XYZZ accumulator in the nine-limb form (coordinates x * 2^261, normalised)
+struct XYZZ9 {
+    F9 x, y, zz, zzz;
+};
+
+// acc + q, q affine in the nine-limb 2^261 form (madd-2008-s, same case analysis as xyzz_madd).
+// `inf` is the accumulator's identity flag.  All coordinates in and out are normalised.
+__device__ __forceinline__ void xyzz9_madd(XYZZ9& a, bool& inf, const F9& qx, const F9& qy) {
+    if (inf) {
+        a.x = qx;
+        a.y = f9_norm(qy);  // (a negated y arrives with negative limbs)
+        a.zz = Fq9Params::one();
+        a.zzz = Fq9Params::one();
+        inf = false;
+        return;
+    }
+    const F9 u2 = Fq9::mul(qx, a.zz);
+    const F9 s2 = Fq9::mul(qy, a.zzz);
+    const F9 p = f9_sub(u2, a.x);  // limb magnitudes < 2^29: both operands normalised
+    const F9 r = f9_sub(s2, a.y);
+    const F9 pp = Fq9::sqr(p);
+    // p == 0 (mod q)  <=>  pp == 0 (mod q); pp is normalised and lies in [0, 2^256 + q)
+    if (__builtin_expect(pp.l[8] >= 0 && Fq9::is_zero_mod_p(pp), 0)) {
+        const F9 rr = Fq9::sqr(r);
+        if (!Fq9::is_zero_mod_p(rr)) {  // q = -acc
+            inf = true;
+            return;
+        }
+        // q = acc: dbl-2008-s-1 on the affine point (rare: every operand normalised on the way)
+        const F9 u = f9_norm(f9_add(qy, qy));
+        const F9 v = Fq9::sqr(u);
+        const F9 w = Fq9::mul(u, v);
+        const F9 s = Fq9::mul(qx, v);
+        const F9 x2 = Fq9::sqr(qx);
+        const F9 m = f9_norm(f9_add(f9_add(x2, x2), x2));
+        a.x = f9_norm(f9_sub(f9_sub(Fq9::sqr(m), s), s));
+        a.y = f9_norm(f9_sub(Fq9::mul(m, f9_norm(f9_sub(s, a.x))), Fq9::mul(w, f9_norm(qy))));
+        a.zz = v;
+        a.zzz = w;
+        return;
+    }
+    const F9 ppp = Fq9::mul(p, pp);
+    const F9 qq = Fq9::mul(a.x, pp);
+    const F9 x3 = f9_norm(f9_sub(f9_sub(f9_sub(Fq9::sqr(r), ppp), qq), qq));
+    const F9 t = f9_sub(qq, x3);
+    a.y = f9_norm(f9_sub(Fq9::mul(r, t), Fq9::mul(a.y, ppp)));
+    a.x = x3;
+    a.zz = Fq9::mul(a.zz, pp);
+    a.zzz = Fq9::mul(a.zzz, ppp);
+}
+
+// nine-limb 2^261 form -> the library's packed XYZZ (coordinates x * 2^256, canonical)
+__device__ __forceinline__ XYZZ xyzz9_to_xyzz(const XYZZ9& a, bool inf) {
+    XYZZ o;
+    if (inf) {
+        o.x = fe_zero(); o.y = fe_zero(); o.zz = fe_zero(); o.zzz = fe_zero();
+        return o;
+    }
+    const F9 k = Fq9Params::k256();
+    o.x = f9_pack(Fq9::canon(Fq9::mul(a.x, k)));
+    o.y = f9_pack(Fq9::canon(Fq9::mul(a.y, k)));
+    o.zz = f9_pack(Fq9::canon(Fq9::mul(a.zz, k)));
+    o.zzz = f9_pack(Fq9::canon(Fq9::mul(a.zzz, k)));
+    return o;
+}
+
+}  // namespace zg

@@ -22,6 +22,7 @@
 #include <cstdlib>
 
 #include "common.h"
+#include "field9.h"
 
 namespace zg {
 
@@ -56,21 +57,25 @@ __device__ __forceinline__ void st_xyzz(XYZZ* p, const XYZZ& v) {
 
 // ---------------------------------------------------------------- base table
 // table[w][i] = 2^(c*w) * P_i in affine form.  One thread per base point, windows in sequence.
+// The table is private to msm_accumulate_kernel, which works on nine 29-bit limbs with Montgomery
+// radix 2^261 (field9.h): coordinates are stored as x * 2^261 mod q (packed, canonical), i.e. the
+// library form times 2^5; the identity stays (0, 0).
 __global__ void msm_table_kernel(const Affine* __restrict__ bases, Affine* __restrict__ table,
                                  uint32_t n, uint32_t c, uint32_t windows) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const Fe c261 = Fq9Params::c261_fe();
     Affine p;
     p.x = ld_fe_g(&bases[i].x);
     p.y = ld_fe_g(&bases[i].y);
-    st_fe_g(&table[i].x, p.x);
-    st_fe_g(&table[i].y, p.y);
+    st_fe_g(&table[i].x, Fq::mul(p.x, c261));
+    st_fe_g(&table[i].y, Fq::mul(p.y, c261));
     for (uint32_t w = 1; w < windows; w++) {
         XYZZ acc = xyzz_dbl_affine(p);
         for (uint32_t d = 1; d < c; d++) acc = xyzz_dbl(acc);
         p = xyzz_to_affine(acc);
-        st_fe_g(&table[(size_t)w * n + i].x, p.x);
-        st_fe_g(&table[(size_t)w * n + i].y, p.y);
+        st_fe_g(&table[(size_t)w * n + i].x, Fq::mul(p.x, c261));
+        st_fe_g(&table[(size_t)w * n + i].y, Fq::mul(p.y, c261));
     }
 }
 
@@ -277,7 +282,9 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __rest
     sorted[(size_t)b * windows * n + pos] = i | (w << 24) | (d & 0x80000000u);
 }
 
-// One lane per task: at most K points of one bucket, mixed adds in XYZZ.
+// One lane per task: at most K points of one bucket, mixed adds in XYZZ on nine 29-bit limbs (field9.h:
+// no carry word per partial product, no per-operation modular correction); the partial sum leaves in
+// the library's packed form.
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table,
     uint32_t c, uint32_t windows, uint32_t n,
@@ -305,18 +312,19 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     uint32_t len = total - j * MSM_K;
     if (len > MSM_K) len = MSM_K;
     const uint32_t* so = sorted + (size_t)b * windows * n + start;
-    XYZZ acc = xyzz_identity();
+    XYZZ9 acc;
+    bool inf = true;
     for (uint32_t e = 0; e < len; e++) {
         uint32_t ent = so[e];
         uint32_t i = ent & 0xffffffu, w = (ent >> 24) & 0x7fu;
         const Affine* src = table + (size_t)w * n_table + i;
-        Affine p;
-        p.x = ld_fe_g(&src->x);
-        p.y = ld_fe_g(&src->y);
-        if (ent >> 31) p.y = Fq::neg(p.y);
-        acc = xyzz_madd(acc, p);
+        const F9 qx = f9_unpack(ld_fe_g(&src->x));
+        F9 qy = f9_unpack(ld_fe_g(&src->y));
+        if (f9_limbs_zero(qx) && f9_limbs_zero(qy)) continue;  // identity base point
+        if (ent >> 31) qy = f9_neg(qy);
+        xyzz9_madd(acc, inf, qx, qy);
     }
-    st_xyzz(partial + (size_t)b * max_tasks + t, acc);
+    st_xyzz(partial + (size_t)b * max_tasks + t, inf ? xyzz_identity() : xyzz9_to_xyzz(acc, false));
 }
 
 // sum_k k*B_k = sum_k S_k with S_k = sum_{k' >= k} B_k' (the classic running sum of running sums), cut
