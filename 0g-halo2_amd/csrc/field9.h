@@ -191,10 +191,34 @@ struct Field9 {
 
 using Fq9 = Field9<Fq9Params>;
 
-// XYZZ accumulator in the nine-limb form (coordinates x * 2^261, normalised)
-struct XYZZ9 {
+// XYZZ point in the nine-limb form (coordinates x * 2^261, normalised); identity <=> zz limbs all zero
+struct alignas(16) XYZZ9 {
     F9 x, y, zz, zzz;
 };
+static_assert(sizeof(XYZZ9) == 144, "XYZZ9 layout");
+
+__device__ __forceinline__ XYZZ9 xyzz9_identity() {
+    XYZZ9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.x.l[i] = r.y.l[i] = r.zz.l[i] = r.zzz.l[i] = 0;
+    return r;
+}
+__device__ __forceinline__ bool xyzz9_is_identity(const XYZZ9& a) { return f9_limbs_zero(a.zz); }
+
+__device__ __forceinline__ XYZZ9 ld_xyzz9(const XYZZ9* p) {
+    XYZZ9 r;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = q[i];
+    return r;
+}
+__device__ __forceinline__ void st_xyzz9(XYZZ9* p, const XYZZ9& v) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    const uint4* s = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+    for (int i = 0; i < 9; i++) q[i] = s[i];
+}
 
 // acc + q, q affine in the nine-limb 2^261 form (madd-2008-s, same case analysis as xyzz_madd).
 // `inf` is the accumulator's identity flag.  All coordinates in and out are normalised.
@@ -242,13 +266,52 @@ __device__ __forceinline__ void xyzz9_madd(XYZZ9& a, bool& inf, const F9& qx, co
     a.zzz = Fq9::mul(a.zzz, ppp);
 }
 
+// dbl-2008-s-1 in the nine-limb form (only reached when an addition meets two equal points)
+__device__ __noinline__ XYZZ9 xyzz9_dbl(const XYZZ9& a) {
+    if (xyzz9_is_identity(a)) return a;
+    XYZZ9 o;
+    const F9 u = f9_norm(f9_add(a.y, a.y));
+    const F9 v = Fq9::sqr(u);
+    const F9 w = Fq9::mul(u, v);
+    const F9 s = Fq9::mul(a.x, v);
+    const F9 xx = Fq9::sqr(a.x);
+    const F9 m = f9_norm(f9_add(f9_add(xx, xx), xx));
+    o.x = f9_norm(f9_sub(f9_sub(Fq9::sqr(m), s), s));
+    o.y = f9_norm(f9_sub(Fq9::mul(m, f9_norm(f9_sub(s, o.x))), Fq9::mul(w, a.y)));
+    o.zz = Fq9::mul(v, a.zz);
+    o.zzz = Fq9::mul(w, a.zzz);
+    return o;
+}
+
+// add-2008-s in the nine-limb form, same case analysis as xyzz_add.  Inputs and output normalised.
+__device__ __forceinline__ XYZZ9 xyzz9_add(const XYZZ9& a, const XYZZ9& b) {
+    if (xyzz9_is_identity(a)) return b;
+    if (xyzz9_is_identity(b)) return a;
+    const F9 u1 = Fq9::mul(a.x, b.zz);
+    const F9 u2 = Fq9::mul(b.x, a.zz);
+    const F9 s1 = Fq9::mul(a.y, b.zzz);
+    const F9 s2 = Fq9::mul(b.y, a.zzz);
+    const F9 p = f9_sub(u2, u1);
+    const F9 r = f9_sub(s2, s1);
+    const F9 pp = Fq9::sqr(p);
+    if (__builtin_expect(pp.l[8] >= 0 && Fq9::is_zero_mod_p(pp), 0)) {
+        if (Fq9::is_zero_mod_p(Fq9::sqr(r))) return xyzz9_dbl(a);
+        return xyzz9_identity();
+    }
+    const F9 ppp = Fq9::mul(p, pp);
+    const F9 qq = Fq9::mul(u1, pp);
+    XYZZ9 o;
+    o.x = f9_norm(f9_sub(f9_sub(f9_sub(Fq9::sqr(r), ppp), qq), qq));
+    o.y = f9_norm(f9_sub(Fq9::mul(r, f9_sub(qq, o.x)), Fq9::mul(s1, ppp)));
+    o.zz = Fq9::mul(Fq9::mul(a.zz, b.zz), pp);
+    o.zzz = Fq9::mul(Fq9::mul(a.zzz, b.zzz), ppp);
+    return o;
+}
+
 // nine-limb 2^261 form -> the library's packed XYZZ (coordinates x * 2^256, canonical)
 __device__ __forceinline__ XYZZ xyzz9_to_xyzz(const XYZZ9& a, bool inf) {
+    if (inf || xyzz9_is_identity(a)) return xyzz_identity();
     XYZZ o;
-    if (inf) {
-        o.x = fe_zero(); o.y = fe_zero(); o.zz = fe_zero(); o.zzz = fe_zero();
-        return o;
-    }
     const F9 k = Fq9Params::k256();
     o.x = f9_pack(Fq9::canon(Fq9::mul(a.x, k)));
     o.y = f9_pack(Fq9::canon(Fq9::mul(a.y, k)));

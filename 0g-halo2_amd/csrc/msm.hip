@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table,
     uint32_t c, uint32_t windows, uint32_t n,
     const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
-    const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ* __restrict__ partial) {
+    const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ9* __restrict__ partial) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t b = blockIdx.y;
     if (t >= ttotal[b]) return;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
         if (ent >> 31) qy = f9_neg(qy);
         xyzz9_madd(acc, inf, qx, qy);
     }
-    st_xyzz(partial + (size_t)b * max_tasks + t, inf ? xyzz_identity() : xyzz9_to_xyzz(acc, false));
+    st_xyzz9(partial + (size_t)b * max_tasks + t, inf ? xyzz9_identity() : acc);
 }
 
 // sum_k k*B_k = sum_k S_k with S_k = sum_{k' >= k} B_k' (the classic running sum of running sums), cut
@@ -332,30 +332,30 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
 constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
 
 // One workgroup per hot bucket: lanes take a strided share of its task partials, tree through LDS.
-__global__ __launch_bounds__(256) void msm_heavy_kernel(const XYZZ* __restrict__ partial, const uint32_t* __restrict__ toff,
+__global__ __launch_bounds__(256) void msm_heavy_kernel(const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff,
                                                         const uint32_t* __restrict__ hlist,
                                                         const uint32_t* __restrict__ nheavy, uint32_t max_tasks,
-                                                        uint32_t max_heavy, uint32_t c, XYZZ* __restrict__ hsum) {
-    __shared__ XYZZ sh[256];
+                                                        uint32_t max_heavy, uint32_t c, XYZZ9* __restrict__ hsum) {
+    __shared__ XYZZ9 sh[256];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t tid = threadIdx.x, b = blockIdx.y;
     const uint32_t nh = nheavy[b];
     const uint32_t* to = toff + (size_t)b * (nb + 2);
-    const XYZZ* pp = partial + (size_t)b * max_tasks;
+    const XYZZ9* pp = partial + (size_t)b * max_tasks;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t k = hlist[(size_t)b * max_heavy + h];
         const uint32_t t0 = to[k], t1 = to[k + 1];
         {
-            XYZZ acc = xyzz_identity();
-            for (uint32_t t = t0 + tid; t < t1; t += 256) acc = xyzz_add(acc, ld_xyzz(pp + t));
+            XYZZ9 acc = xyzz9_identity();
+            for (uint32_t t = t0 + tid; t < t1; t += 256) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
             sh[tid] = acc;
         }
         __syncthreads();
         for (uint32_t o = 128; o > 0; o >>= 1) {
-            if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+            if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
             __syncthreads();
         }
-        if (tid == 0) st_xyzz(hsum + (size_t)b * max_heavy + h, sh[0]);
+        if (tid == 0) st_xyzz9(hsum + (size_t)b * max_heavy + h, sh[0]);
         __syncthreads();
     }
 }
@@ -364,93 +364,93 @@ __global__ __launch_bounds__(256) void msm_heavy_kernel(const XYZZ* __restrict__
 // lane j merges the task partials of bucket k0 + j + 1 (hot buckets arrive pre-merged from
 // msm_heavy_kernel), a Hillis-Steele suffix scan through LDS gives the block-local S_j, stored for
 // stage 2 together with the block total P = S_0.
-__global__ __launch_bounds__(MSM_RB) void msm_bucket_scan_kernel(const XYZZ* __restrict__ partial,
+__global__ __launch_bounds__(MSM_RB) void msm_bucket_scan_kernel(const XYZZ9* __restrict__ partial,
                                                                 const uint32_t* __restrict__ toff,
                                                                 const uint32_t* __restrict__ hmap,
-                                                                const XYZZ* __restrict__ hsum, uint32_t max_tasks,
+                                                                const XYZZ9* __restrict__ hsum, uint32_t max_tasks,
                                                                 uint32_t max_heavy, uint32_t c,
-                                                                XYZZ* __restrict__ sfx, XYZZ* __restrict__ blk_p,
+                                                                XYZZ9* __restrict__ sfx, XYZZ9* __restrict__ blk_p,
                                                                 uint32_t nblk) {
-    __shared__ XYZZ sh[MSM_RB];
+    __shared__ XYZZ9 sh[MSM_RB];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     const uint32_t k = blk * MSM_RB + tid + 1;
     const uint32_t* to = toff + (size_t)b * (nb + 2);
-    const XYZZ* pp = partial + (size_t)b * max_tasks;
+    const XYZZ9* pp = partial + (size_t)b * max_tasks;
     {
-        XYZZ acc = xyzz_identity();
+        XYZZ9 acc = xyzz9_identity();
         if (k <= nb) {
             const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
             if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
-                acc = ld_xyzz(hsum + (size_t)b * max_heavy + hs);
+                acc = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
             } else {
                 const uint32_t t0 = to[k], t1 = to[k + 1];
-                for (uint32_t t = t0; t < t1; t++) acc = xyzz_add(acc, ld_xyzz(pp + t));
+                for (uint32_t t = t0; t < t1; t++) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
             }
         }
         sh[tid] = acc;
     }
     __syncthreads();
     for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
-        XYZZ v = xyzz_identity();
+        XYZZ9 v = xyzz9_identity();
         const bool has = tid + o < MSM_RB;
         if (has) v = sh[tid + o];
         __syncthreads();
-        if (has) sh[tid] = xyzz_add(sh[tid], v);
+        if (has) sh[tid] = xyzz9_add(sh[tid], v);
         __syncthreads();
     }
-    st_xyzz(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid, sh[tid]);
-    if (tid == 0) st_xyzz(blk_p + (size_t)b * nblk + blk, sh[0]);
+    st_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid, sh[tid]);
+    if (tid == 0) st_xyzz9(blk_p + (size_t)b * nblk + blk, sh[0]);
 }
 
 // Stage 2: the global suffix sum at bucket (blk, j) is S_j + BS with BS = sum of the totals of the
 // blocks above.  Every lane adds BS once -- the factor 256 of "256 * BS" is supplied by the 256 lanes,
 // not by a doubling chain -- and a tree gives W' = sum_j (S_j + BS).
-__global__ __launch_bounds__(MSM_RB) void msm_bucket_sum_kernel(const XYZZ* __restrict__ sfx,
-                                                               const XYZZ* __restrict__ blk_p,
-                                                               XYZZ* __restrict__ blk_w, uint32_t nblk) {
-    __shared__ XYZZ sh[MSM_RB];
+__global__ __launch_bounds__(MSM_RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
+                                                               const XYZZ9* __restrict__ blk_p,
+                                                               XYZZ9* __restrict__ blk_w, uint32_t nblk) {
+    __shared__ XYZZ9 sh[MSM_RB];
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     // BS = sum_{blk' > blk} P_blk'   (nblk <= 256)
     {
-        XYZZ v = xyzz_identity();
-        if (blk + 1 + tid < nblk) v = ld_xyzz(blk_p + (size_t)b * nblk + blk + 1 + tid);
+        XYZZ9 v = xyzz9_identity();
+        if (blk + 1 + tid < nblk) v = ld_xyzz9(blk_p + (size_t)b * nblk + blk + 1 + tid);
         sh[tid] = v;
     }
     __syncthreads();
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
     for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+        if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
         __syncthreads();
     }
     {
-        XYZZ bs = sh[0];
+        XYZZ9 bs = sh[0];
         __syncthreads();
-        sh[tid] = xyzz_add(ld_xyzz(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid), bs);
+        sh[tid] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid), bs);
     }
     __syncthreads();
     for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+        if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
         __syncthreads();
     }
-    if (tid == 0) st_xyzz(blk_w + (size_t)b * nblk + blk, sh[0]);
+    if (tid == 0) st_xyzz9(blk_w + (size_t)b * nblk + blk, sh[0]);
 }
 
 // result = sum_blk W'_blk
-__global__ __launch_bounds__(256) void msm_finish_kernel(const XYZZ* __restrict__ blk_w, uint32_t nblk,
+__global__ __launch_bounds__(256) void msm_finish_kernel(const XYZZ9* __restrict__ blk_w, uint32_t nblk,
                                                          XYZZ* __restrict__ out) {
-    __shared__ XYZZ sh[256];
+    __shared__ XYZZ9 sh[256];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    sh[tid] = tid < nblk ? ld_xyzz(blk_w + (size_t)b * nblk + tid) : xyzz_identity();
+    sh[tid] = tid < nblk ? ld_xyzz9(blk_w + (size_t)b * nblk + tid) : xyzz9_identity();
     __syncthreads();
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
     for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] = xyzz_add(sh[tid], sh[tid + o]);
+        if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
         __syncthreads();
     }
-    if (tid == 0) st_xyzz(out + b, sh[0]);
+    if (tid == 0) st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
 }
 
 static uint32_t default_window_bits(size_t n) {
@@ -537,16 +537,16 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     uint32_t* tot = ws.get<uint32_t>((size_t)B * (nb + 2));
     uint32_t* ttotal = ws.get<uint32_t>(B);
     uint32_t* sorted = ws.get<uint32_t>((size_t)B * entries);
-    XYZZ* partial = ws.get<XYZZ>((size_t)B * max_tasks);
-    XYZZ* blk_w = ws.get<XYZZ>((size_t)B * nblk);
-    XYZZ* blk_p = ws.get<XYZZ>((size_t)B * nblk);
-    XYZZ* sfx = ws.get<XYZZ>((size_t)B * nblk * MSM_RB);
+    XYZZ9* partial = ws.get<XYZZ9>((size_t)B * max_tasks);
+    XYZZ9* blk_w = ws.get<XYZZ9>((size_t)B * nblk);
+    XYZZ9* blk_p = ws.get<XYZZ9>((size_t)B * nblk);
+    XYZZ9* sfx = ws.get<XYZZ9>((size_t)B * nblk * MSM_RB);
     // a hot bucket holds more than MSM_HEAVY * MSM_K entries
     const uint32_t max_heavy = (uint32_t)(entries / ((uint64_t)MSM_HEAVY * MSM_K)) + 1;
     uint32_t* hmap = ws.get<uint32_t>((size_t)B * (nb + 1));
     uint32_t* hlist = ws.get<uint32_t>((size_t)B * max_heavy);
     uint32_t* nheavy = ws.get<uint32_t>(B);
-    XYZZ* hsum = ws.get<XYZZ>((size_t)B * max_heavy);
+    XYZZ9* hsum = ws.get<XYZZ9>((size_t)B * max_heavy);
     if (ws.failed) return ZG_ERR_OOM;
 
     static bool lds_attr = false;
