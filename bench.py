@@ -125,22 +125,20 @@ def algorithmic_bytes_per_proof(cs) -> float:
     return float(msm + intt + ext + ext_inv + gp + eh)
 
 
-def field_products_per_proof(cs) -> float:
-    """Rough count of 254-bit Montgomery products one proof needs: MSM mixed adds
-    at 10 each (all digits taken as non-zero, c = 13) plus the bucket reduction, one per NTT butterfly,
-    ~270 per evaluate_h row, and the linear passes.  An estimate for the VALU utilisation line only."""
-    n, ek = 1 << cs.k, cs.extended_k()
-    en = 1 << ek
-    sets = (len(cs.perm_columns) + cs.degree() - 3) // (cs.degree() - 2)
-    nl = len(cs.lookups)
-    n_msm = cs.n_advice + 3 * nl + sets + 1 + (cs.degree() - 1) + 4
-    windows, nb = 20, 4096
-    msm = n_msm * (n * windows * 10 + (n * windows // 16 + 17 * nb) * 14)
-    polys = cs.n_advice + cs.n_instance + 3 * nl + sets
-    ntt = polys * (n // 2 * cs.k + en // 2 * ek) + en // 2 * ek
-    eh = en * 270
-    linear = (60 + 40 + 12) * n
-    return float(msm + ntt + eh + linear)
+def valu_utilisation(ms_per_proof: float):
+    """VALU issue utilisation: wave-instructions one proof issues (rocprofv3 --pmc SQ_INSTS_VALU, committed
+    under profiles/) per second, against the chip's issue rate of one wave-instruction per SIMD every 4
+    cycles (256 CUs x 4 SIMDs x 2.4 GHz / 4).  The multiply-adds that dominate (v_mad_u64_u32 /
+    v_mad_i64_i32) occupy the pipe ~1.5x longer than that, so the true pipe occupancy is higher."""
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["valu"]
+        per_proof = float(v["wave_instructions_per_proof"])
+    except (OSError, KeyError, ValueError):
+        return None
+    peak = 256 * 4 * 2.4e9 / 4
+    achieved = per_proof / (ms_per_proof * 1e-3)
+    return {"wave_instructions_per_proof": per_proof, "achieved_wave_instr_per_s": achieved,
+            "issue_peak_wave_instr_per_s": peak, "frac": achieved / peak}
 
 
 def cpu_baseline(job: ProofJob, threads: int):
@@ -318,12 +316,8 @@ def main():
             "algorithmic_GBps": algorithmic_bytes_per_proof(job.cs) / (ms_per_proof * 1e-3) / 1e9,
             "single_proof_gpu_kernel_ms": kernel_ms,
             "roofline": roofline,
-            # the kernels are VALU-bound: an estimate of the field products per proof against the
-            # measured chip-wide peak of the hand-written Montgomery product (tools/microbench.hip)
-            "valu": {"field_products_per_proof_est": field_products_per_proof(job.cs),
-                     "achieved_Gprod_s": field_products_per_proof(job.cs) / (ms_per_proof * 1e-3) / 1e9,
-                     "measured_peak_Gprod_s": 115.0,
-                     "frac": field_products_per_proof(job.cs) / (ms_per_proof * 1e-3) / 1e9 / 115.0},
+            # the kernels are VALU-bound: measured instruction count per proof against the issue rate
+            "valu": valu_utilisation(ms_per_proof) if args.model == "tiny" else None,
             "single_proof_kernels_ms": {k_: round(v[1] / 2, 4)
                                         for k_, v in sorted(split.items(), key=lambda kv: -kv[1][1])},
             "single_proof_phase_ms": dict(zip(["advice", "lookups_permuted", "products", "h", "evals", "gwc",
