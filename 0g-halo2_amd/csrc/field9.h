@@ -46,6 +46,22 @@ struct Fq9Params {
     }
 };
 
+struct Fr9Params {
+    static __device__ __forceinline__ int32_t p(int i) {
+        constexpr int32_t P[9] = {0x10000001, 0x1f0fac9f, 0x0e5c2450, 0x07d090f3, 0x1585d283,
+                                  0x02db40c0, 0x00a6e141, 0x0e5c2634, 0x0030644e};
+        return P[i];
+    }
+    static constexpr uint32_t INV29 = 0x0fffffffu;
+    static __device__ __forceinline__ F9 one() {  // 2^261 mod r
+        return F9{{0x0fffff57, 0x1ea70ab4, 0x052c068b, 0x17504f49, 0x0aa8075b, 0x1d4240ce, 0x11d54c07, 0x052ac7a8, 0x000dc836}};
+    }
+    // 2^261 mod r as an 8 x 32-bit integer: Fr::mul(X, c261) = X * 2^5, i.e. x*2^256 -> x*2^261
+    static ZG_HD Fe c261_fe() {
+        return Fe{{0x8fffff57u, 0x2fd4e156u, 0xa494b01au, 0x75bba827u, 0x819caa80u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u}};
+    }
+};
+
 // 8 x 32-bit packed (canonical, < 2^256) -> normalised limbs
 __device__ __forceinline__ F9 f9_unpack(const Fe& a) {
     F9 o;
@@ -190,6 +206,37 @@ struct Field9 {
 };
 
 using Fq9 = Field9<Fq9Params>;
+using Fr9 = Field9<Fr9Params>;
+
+// Normalised value of magnitude < 2^263 -> canonical packed form.  The quotient by p is estimated from
+// the top limb in float (2^232 / p = 3.1531751e-7 for both BN254 moduli): the float product is within
+// 8e-5 of v/p and the dropped low limbs add less than 4e-7, so floor(estimate - 1e-4) is floor(v/p) or
+// one less -- the remainder lies in [0, 2p) and one conditional subtraction finishes.
+template <class P>
+__device__ __forceinline__ Fe f9_reduce_pack(const F9& v) {
+    const int32_t q = (int32_t)floorf((float)v.l[8] * 3.153175148504101e-07f - 1.0e-4f);
+    F9 a, t;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int64_t w = (int64_t)v.l[i] - (int64_t)q * (int64_t)P::p(i) + c;
+        a.l[i] = (int32_t)((uint32_t)w & (uint32_t)MASK29);
+        c = w >> 29;
+    }
+    a.l[8] = (int32_t)((int64_t)v.l[8] - (int64_t)q * (int64_t)P::p(8) + c);
+    int32_t b = 0;  // t = a - p, normalised
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int32_t w = a.l[i] - P::p(i) + b;
+        t.l[i] = w & MASK29;
+        b = w >> 29;
+    }
+    t.l[8] = a.l[8] - P::p(8) + b;
+    const bool ge = t.l[8] >= 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) a.l[i] = ge ? t.l[i] : a.l[i];
+    return f9_pack(a);
+}
 
 // XYZZ point in the nine-limb form (coordinates x * 2^261, normalised); identity <=> zz limbs all zero
 struct alignas(16) XYZZ9 {

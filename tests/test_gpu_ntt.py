@@ -79,3 +79,19 @@ def test_ntt_rejects_bad_arguments(ctx, zg):
     with pytest.raises(zg.ZgError) as e:
         ctx.ntt(a, om)
     assert e.value.status == -4  # ZG_ERR_UNSUPPORTED
+
+
+def test_nine_limb_butterflies_are_bit_exact():
+    """The opt-in nine-limb NTT back end (ZG_NTT9=1, read once per process) must give the same bytes:
+    rerun this file's transforms and the golden NTT / proof vectors in a child process with it enabled."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("ZG_NTT9") == "1":
+        pytest.skip("already inside the nine-limb run")
+    env = dict(os.environ, ZG_NTT9="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_ntt.py"),
+                        os.path.join(here, "test_golden.py")], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
