@@ -79,8 +79,31 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
     constexpr uint32_t T = 1u << LOG_T;
     constexpr uint32_t NT = T / 4;
     extern __shared__ __align__(16) unsigned char smem[];
-    Fe* X = reinterpret_cast<Fe*>(smem);
-    Fe* TW = X + T;
+    // LDS layout: an element is two 16-byte halves in two separate arrays (a 32-byte stride puts lanes i
+    // and i+4 of a b128 access on the same banks), and its slot is its index with the higher 3-bit groups
+    // XOR-folded into the low three bits -- consecutive indices and every power-of-two stride (late
+    // butterfly stages, the bit-reversed reads of the store loop, twiddle strides) then fall on eight
+    // different bank quads.  Measured before: a third of the kernel's busy cycles were LDS bank conflicts.
+    uint4* XL = reinterpret_cast<uint4*>(smem);
+    uint4* XH = XL + T;
+    uint4* TL = XH + T;
+    uint4* TH = TL + (1u << ((COLS ? a.log_n1 : a.log_n2) > 0 ? (COLS ? a.log_n1 : a.log_n2) - 1 : 0));
+    auto slot = [](uint32_t i) { return i ^ ((i >> 3) & 7u) ^ ((i >> 6) & 7u) ^ ((i >> 9) & 7u); };
+    auto ldx = [&](uint32_t i) {
+        const uint32_t s = slot(i);
+        const uint4 lo = XL[s], hi = XH[s];
+        return Fe{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
+    auto stx = [&](uint32_t i, const Fe& v) {
+        const uint32_t s = slot(i);
+        XL[s] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+        XH[s] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    };
+    auto ldt = [&](uint32_t i) {
+        const uint32_t s = slot(i);
+        const uint4 lo = TL[s], hi = TH[s];
+        return Fe{{lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w}};
+    };
 
     const uint32_t tid = threadIdx.x;
     const uint32_t log_m = COLS ? a.log_n1 : a.log_n2;
@@ -103,7 +126,12 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
     // stage the sub-transform twiddles omega_M^t = omega^(t * N/M)
     {
         const uint32_t tw_shift = a.log_n - log_m;
-        for (uint32_t t = tid; t < M / 2; t += NT) TW[t] = ld_fe(a.tw + ((size_t)t << tw_shift));
+        for (uint32_t t = tid; t < M / 2; t += NT) {
+            const Fe w = ld_fe(a.tw + ((size_t)t << tw_shift));
+            const uint32_t s = slot(t);
+            TL[s] = make_uint4(w.l[0], w.l[1], w.l[2], w.l[3]);
+            TH[s] = make_uint4(w.l[4], w.l[5], w.l[6], w.l[7]);
+        }
     }
 
     // load the tile
@@ -133,7 +161,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
         } else {
             v = ld_fe(in + g);
         }
-        X[li] = v;
+        stx(li, v);
     }
     __syncthreads();
 
@@ -155,12 +183,12 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
             uint32_t lo = (blk << (log_half + 1)) + i, hi = lo + half;
             uint32_t ilo = COLS ? (lo << log_cnt) + s : (s << log_m) + lo;
             uint32_t ihi = COLS ? (hi << log_cnt) + s : (s << log_m) + hi;
-            Fe u = X[ilo], v = X[ihi];
-            X[ilo] = Fr::add(u, v);
+            Fe u = ldx(ilo), v = ldx(ihi);
+            stx(ilo, Fr::add(u, v));
             Fe d = Fr::sub(u, v);
             uint32_t twi = i << st;
-            if (twi != 0) d = Fr::mul(d, TW[twi]);
-            X[ihi] = d;
+            if (twi != 0) d = Fr::mul(d, ldt(twi));
+            stx(ihi, d);
         }
         __syncthreads();
     }
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
             uint32_t c = e & (cnt - 1), pos = e >> log_cnt;
             uint32_t k1 = bitrev(pos, log_m);
             uint32_t j2 = base + c;
-            Fe v = X[e];
+            Fe v = ldx(e);
             uint32_t ti = j2 * k1;  // < N
             if (ti != 0) v = Fr::mul(v, ld_fe(a.tw + ti));
             st_fe(out + (size_t)k1 * N2 + j2, v);
@@ -182,7 +210,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
             uint32_t pos = bitrev(k2, log_m);
             uint32_t k = (base + r) + N1 * k2;
             if (k >= a.out_len) continue;
-            Fe v = X[(r << log_m) + pos];
+            Fe v = ldx((r << log_m) + pos);
             if (a.scale_out) v = Fr::mul(v, a.scale);
             if (a.coset_out) {
                 uint32_t m3 = k % 3u;
