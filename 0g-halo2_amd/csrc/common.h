@@ -90,6 +90,8 @@ struct zg_ctx {
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;  // recycled by zg_ctx_profile_collect
     zg_ctx* side = nullptr;  // optional second stream + workspace pool (created on demand, same device)
+    // MSM bucket reduction with two lanes per EC addition (latency) or one (throughput); see msm.hip
+    bool msm_pair = true;
 };
 
 struct zg_bases {

@@ -17,6 +17,7 @@
 // by a constant (k266 / k256).  Memory keeps the packed 8 x 32-bit canonical form.
 #pragma once
 
+#include "curve.h"
 #include "field.h"
 
 namespace zg {
@@ -353,6 +354,130 @@ __device__ __forceinline__ XYZZ9 xyzz9_add(const XYZZ9& a, const XYZZ9& b) {
     o.zz = Fq9::mul(Fq9::mul(a.zz, b.zz), pp);
     o.zzz = Fq9::mul(Fq9::mul(a.zzz, b.zzz), ppp);
     return o;
+}
+
+
+// ---- two lanes per addition -------------------------------------------------------------------------
+// The bucket reduction of the MSM is a chain of DEPENDENT additions on a nearly idle chip, so its
+// wall time is the latency of one addition times the depth.  Lanes 2i ("A") and 2i+1 ("B") of a wave
+// share one addition: seven of the fourteen products each, intermediate values swapped with DPP
+// quad_perm [1,0,3,2] moves (45 moves per addition), results written per coordinate by the lane that
+// holds them (A: zz; B: x, y, zzz).  Same case analysis as xyzz9_add; the equal-x case falls back to
+// lane A doing the generic addition alone.
+__device__ __forceinline__ int32_t dpp_swap1(int32_t v) {
+    int32_t r = __builtin_amdgcn_update_dpp(0, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+    // keep the move a move: folded into a following subtraction (GCN DPP combine) the operands came out
+    // swapped -- dpp(h) - k instead of h - dpp(k) -- on this toolchain
+    asm volatile("" : "+v"(r));
+    return r;
+}
+__device__ __forceinline__ F9 f9_swap(const F9& a) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = dpp_swap1(a.l[i]);
+    return o;
+}
+__device__ __forceinline__ F9 f9_sel(bool c, const F9& a, const F9& b) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = c ? a.l[i] : b.l[i];
+    return o;
+}
+__device__ __forceinline__ F9 ld_f9(const F9* p) {
+    F9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = p->l[i];
+    return r;
+}
+__device__ __forceinline__ void st_f9(F9* p, const F9& v) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) p->l[i] = v.l[i];
+}
+
+// What one lane holds of a sum and which coordinates it has to write (bit 0 x, 1 y, 2 zz, 3 zzz).
+struct XSum {
+    XYZZ9 r;
+    uint32_t wm;
+};
+
+template <bool PAIR>
+__device__ __forceinline__ void xstore(XYZZ9* dst, const XSum& s) {
+    if (!PAIR) {
+        st_xyzz9(dst, s.r);
+        return;
+    }
+    if (s.wm & 1u) st_f9(&dst->x, s.r.x);
+    if (s.wm & 2u) st_f9(&dst->y, s.r.y);
+    if (s.wm & 4u) st_f9(&dst->zz, s.r.zz);
+    if (s.wm & 8u) st_f9(&dst->zzz, s.r.zzz);
+    // the partner lane reads these coordinates next: keep the compiler from carrying stale copies of
+    // what the other lane writes (wavefront scope: both lanes run in lockstep, no hardware wait needed)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+}
+
+// *pa + *pb.  PAIR: called by both lanes of a pair with the same pointers, role = lane parity.
+template <bool PAIR>
+__device__ __forceinline__ XSum xadd(const XYZZ9* pa, const XYZZ9* pb, uint32_t role) {
+    XSum s;
+    if (!PAIR) {
+        s.r = xyzz9_add(ld_xyzz9(pa), ld_xyzz9(pb));
+        s.wm = 0xFu;
+        return s;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const bool A = role == 0;
+    const XYZZ9* own = A ? pa : pb;
+    const XYZZ9* oth = A ? pb : pa;
+    const F9 mx = ld_f9(&own->x), my = ld_f9(&own->y);
+    const F9 mz = ld_f9(&oth->zz), mzzz = ld_f9(&oth->zzz);
+    const F9 e1 = ld_f9(A ? &own->zz : &own->zzz);  // A: ZZ1, B: ZZZ2
+    // identity flags as both lanes see them (identity points are all-zero)
+    const bool a_inf = A ? f9_limbs_zero(e1) : f9_limbs_zero(mz);
+    const bool b_inf = A ? f9_limbs_zero(mz) : f9_limbs_zero(e1);
+    if (a_inf || b_inf) {
+        if (a_inf) {  // result = b: A holds b.zz, B holds b.x, b.y, b.zzz
+            s.r.x = mx; s.r.y = my; s.r.zz = mz; s.r.zzz = e1;
+            s.wm = A ? 4u : 11u;
+        } else {      // result = a: A holds a.x, a.y, a.zz, B holds a.zzz
+            s.r.x = mx; s.r.y = my; s.r.zz = e1; s.r.zzz = mzzz;
+            s.wm = A ? 7u : 8u;
+        }
+        return s;
+    }
+    const F9 u = Fq9::mul(mx, mz);      // A: U1 = X1 ZZ2      B: U2 = X2 ZZ1
+    const F9 sv = Fq9::mul(my, mzzz);   // A: S1 = Y1 ZZZ2     B: S2 = Y2 ZZZ1
+    const F9 e = Fq9::mul(e1, A ? mz : mzzz);  // A: ZZ1 ZZ2   B: ZZZ2 ZZZ1
+    const F9 ou = f9_swap(u), os = f9_swap(sv);
+    const F9 p = A ? f9_sub(ou, u) : f9_sub(u, ou);    // U2 - U1
+    const F9 r = A ? f9_sub(os, sv) : f9_sub(sv, os);  // S2 - S1
+    const F9 f = Fq9::sqr(f9_sel(A, p, r));            // A: PP      B: RR
+    const F9 of = f9_swap(f);
+    const F9 pp = f9_sel(A, f, of), rr = f9_sel(A, of, f);
+    // equal x (doubling or inverse): decided by A on PP, told to B, settled by A alone
+    int32_t rare = (A && pp.l[8] >= 0 && Fq9::is_zero_mod_p(pp)) ? 1 : 0;
+    rare |= dpp_swap1(rare);
+    if (__builtin_expect(rare != 0, 0)) {
+        s.wm = 0;
+        if (A) {
+            s.r = xyzz9_add(ld_xyzz9(pa), ld_xyzz9(pb));
+            s.wm = 0xFu;
+        }
+        return s;
+    }
+    const F9 u1 = f9_sel(A, u, ou);
+    const F9 g = Fq9::mul(f9_sel(A, p, u1), pp);       // A: PPP = P PP    B: Q = U1 PP
+    const F9 og = f9_swap(g);
+    const F9 ppp = f9_sel(A, g, og), qq = f9_sel(A, og, g);
+    const F9 x3 = f9_norm(f9_sub(f9_sub(f9_sub(rr, ppp), qq), qq));
+    const F9 h = Fq9::mul(f9_sel(A, e, r), f9_sel(A, pp, f9_sub(qq, x3)));  // A: ZZ3 = ZZ12 PP   B: R (Q - X3)
+    const F9 k = Fq9::mul(f9_sel(A, sv, e), ppp);                            // A: S1 PPP          B: ZZZ3 = ZZZ12 PPP
+    const F9 ok = f9_swap(k);
+    s.r.x = x3;
+    s.r.y = f9_norm(f9_sub(h, ok));  // (meaningful on B)
+    s.r.zz = h;                      // (meaningful on A)
+    s.r.zzz = k;                     // (meaningful on B)
+    s.wm = A ? 4u : 11u;
+    return s;
 }
 
 // nine-limb 2^261 form -> the library's packed XYZZ (coordinates x * 2^256, canonical)

@@ -331,31 +331,35 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
 // into blocks of 256 buckets so that it parallelises (msm_bucket_scan / msm_bucket_sum / msm_finish).
 constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
 
+// All four reduction kernels are templated on PAIR: one lane per addition (throughput: least work), or
+// two lanes per addition (field9.h `xadd<true>`: half the dependent latency; the prover's latency
+// configuration and the stand-alone MSM entry points use it).  j = logical lane, role = lane in the pair.
+
 // One workgroup per hot bucket: lanes take a strided share of its task partials, tree through LDS.
-__global__ __launch_bounds__(256) void msm_heavy_kernel(const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff,
-                                                        const uint32_t* __restrict__ hlist,
-                                                        const uint32_t* __restrict__ nheavy, uint32_t max_tasks,
-                                                        uint32_t max_heavy, uint32_t c, XYZZ9* __restrict__ hsum) {
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256) void msm_heavy_kernel(const XYZZ9* __restrict__ partial,
+                                                                     const uint32_t* __restrict__ toff,
+                                                                     const uint32_t* __restrict__ hlist,
+                                                                     const uint32_t* __restrict__ nheavy, uint32_t max_tasks,
+                                                                     uint32_t max_heavy, uint32_t c,
+                                                                     XYZZ9* __restrict__ hsum) {
     __shared__ XYZZ9 sh[256];
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t tid = threadIdx.x, b = blockIdx.y;
+    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u, b = blockIdx.y;
     const uint32_t nh = nheavy[b];
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t k = hlist[(size_t)b * max_heavy + h];
         const uint32_t t0 = to[k], t1 = to[k + 1];
-        {
-            XYZZ9 acc = xyzz9_identity();
-            for (uint32_t t = t0 + tid; t < t1; t += 256) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
-            sh[tid] = acc;
-        }
+        if (role == 0) sh[j] = xyzz9_identity();
+        for (uint32_t t = t0 + j; t < t1; t += 256) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], pp + t, role));
         __syncthreads();
         for (uint32_t o = 128; o > 0; o >>= 1) {
-            if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
+            if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
             __syncthreads();
         }
-        if (tid == 0) st_xyzz9(hsum + (size_t)b * max_heavy + h, sh[0]);
+        if (threadIdx.x == 0) st_xyzz9(hsum + (size_t)b * max_heavy + h, sh[0]);
         __syncthreads();
     }
 }
@@ -364,93 +368,90 @@ __global__ __launch_bounds__(256) void msm_heavy_kernel(const XYZZ9* __restrict_
 // lane j merges the task partials of bucket k0 + j + 1 (hot buckets arrive pre-merged from
 // msm_heavy_kernel), a Hillis-Steele suffix scan through LDS gives the block-local S_j, stored for
 // stage 2 together with the block total P = S_0.
-__global__ __launch_bounds__(MSM_RB) void msm_bucket_scan_kernel(const XYZZ9* __restrict__ partial,
-                                                                const uint32_t* __restrict__ toff,
-                                                                const uint32_t* __restrict__ hmap,
-                                                                const XYZZ9* __restrict__ hsum, uint32_t max_tasks,
-                                                                uint32_t max_heavy, uint32_t c,
-                                                                XYZZ9* __restrict__ sfx, XYZZ9* __restrict__ blk_p,
-                                                                uint32_t nblk) {
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_scan_kernel(
+    const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ hmap,
+    const XYZZ9* __restrict__ hsum, uint32_t max_tasks, uint32_t max_heavy, uint32_t c, XYZZ9* __restrict__ sfx,
+    XYZZ9* __restrict__ blk_p, uint32_t nblk) {
     __shared__ XYZZ9 sh[MSM_RB];
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
-    const uint32_t k = blk * MSM_RB + tid + 1;
+    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u;
+    const uint32_t blk = blockIdx.x, b = blockIdx.y;
+    const uint32_t k = blk * MSM_RB + j + 1;
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
-    {
-        XYZZ9 acc = xyzz9_identity();
-        if (k <= nb) {
-            const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
-            if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
-                acc = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
-            } else {
-                const uint32_t t0 = to[k], t1 = to[k + 1];
-                for (uint32_t t = t0; t < t1; t++) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
-            }
+    if (role == 0) sh[j] = xyzz9_identity();
+    if (k <= nb) {
+        const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
+        if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
+            if (role == 0) sh[j] = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
+        } else {
+            const uint32_t t0 = to[k], t1 = to[k + 1];
+            for (uint32_t t = t0; t < t1; t++) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], pp + t, role));
         }
-        sh[tid] = acc;
     }
     __syncthreads();
     for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
-        XYZZ9 v = xyzz9_identity();
-        const bool has = tid + o < MSM_RB;
-        if (has) v = sh[tid + o];
+        const bool has = j + o < MSM_RB;
+        XSum s;
+        if (has) s = xadd<PAIR>(&sh[j], &sh[j + o], role);
         __syncthreads();
-        if (has) sh[tid] = xyzz9_add(sh[tid], v);
+        if (has) xstore<PAIR>(&sh[j], s);
         __syncthreads();
     }
-    st_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid, sh[tid]);
-    if (tid == 0) st_xyzz9(blk_p + (size_t)b * nblk + blk, sh[0]);
+    if (role == 0) {
+        st_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + j, sh[j]);
+        if (j == 0) st_xyzz9(blk_p + (size_t)b * nblk + blk, sh[0]);
+    }
 }
 
 // Stage 2: the global suffix sum at bucket (blk, j) is S_j + BS with BS = sum of the totals of the
 // blocks above.  Every lane adds BS once -- the factor 256 of "256 * BS" is supplied by the 256 lanes,
 // not by a doubling chain -- and a tree gives W' = sum_j (S_j + BS).
-__global__ __launch_bounds__(MSM_RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
-                                                               const XYZZ9* __restrict__ blk_p,
-                                                               XYZZ9* __restrict__ blk_w, uint32_t nblk) {
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
+                                                                                   const XYZZ9* __restrict__ blk_p,
+                                                                                   XYZZ9* __restrict__ blk_w,
+                                                                                   uint32_t nblk) {
     __shared__ XYZZ9 sh[MSM_RB];
-    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    __shared__ XYZZ9 bs;
+    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u;
+    const uint32_t blk = blockIdx.x, b = blockIdx.y;
     // BS = sum_{blk' > blk} P_blk'   (nblk <= 256)
-    {
-        XYZZ9 v = xyzz9_identity();
-        if (blk + 1 + tid < nblk) v = ld_xyzz9(blk_p + (size_t)b * nblk + blk + 1 + tid);
-        sh[tid] = v;
-    }
+    if (role == 0) sh[j] = blk + 1 + j < nblk ? ld_xyzz9(blk_p + (size_t)b * nblk + blk + 1 + j) : xyzz9_identity();
     __syncthreads();
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
     for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
+        if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
         __syncthreads();
     }
-    {
-        XYZZ9 bs = sh[0];
-        __syncthreads();
-        sh[tid] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + tid), bs);
-    }
+    if (threadIdx.x == 0) bs = sh[0];
+    __syncthreads();
+    xstore<PAIR>(&sh[j], xadd<PAIR>(sfx + ((size_t)b * nblk + blk) * MSM_RB + j, &bs, role));
     __syncthreads();
     for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
+        if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
         __syncthreads();
     }
-    if (tid == 0) st_xyzz9(blk_w + (size_t)b * nblk + blk, sh[0]);
+    if (threadIdx.x == 0) st_xyzz9(blk_w + (size_t)b * nblk + blk, sh[0]);
 }
 
 // result = sum_blk W'_blk
-__global__ __launch_bounds__(256) void msm_finish_kernel(const XYZZ9* __restrict__ blk_w, uint32_t nblk,
-                                                         XYZZ* __restrict__ out) {
+template <bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256) void msm_finish_kernel(const XYZZ9* __restrict__ blk_w, uint32_t nblk,
+                                                                      XYZZ* __restrict__ out) {
     __shared__ XYZZ9 sh[256];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    sh[tid] = tid < nblk ? ld_xyzz9(blk_w + (size_t)b * nblk + tid) : xyzz9_identity();
+    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u, b = blockIdx.x;
+    if (role == 0) sh[j] = j < nblk ? ld_xyzz9(blk_w + (size_t)b * nblk + j) : xyzz9_identity();
     __syncthreads();
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
     for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (tid < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
+        if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
         __syncthreads();
     }
-    if (tid == 0) st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
+    if (threadIdx.x == 0) st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
 }
 
 static uint32_t default_window_bits(size_t n) {
@@ -580,12 +581,24 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
               bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot, toff,
               ttotal, sorted, max_tasks, partial);
-    ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel, dim3(max_heavy < 2048 ? max_heavy : 2048, B), dim3(256), 0, partial,
-              toff, hlist, nheavy, max_tasks, max_heavy, c, hsum);
-    ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_bucket_scan_kernel, dim3(nblk, B), dim3(MSM_RB), 0, partial, toff, hmap,
-              hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
-    ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_bucket_sum_kernel, dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p, blk_w, nblk);
-    ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel, dim3(B), dim3(256), 0, blk_w, nblk, d_out);
+    const dim3 hgrid(max_heavy < 2048 ? max_heavy : 2048, B);
+    if (ctx->msm_pair) {  // two lanes per addition: half the dependent latency of the reduction
+        ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<true>, hgrid, dim3(512), 0, partial, toff, hlist, nheavy,
+                  max_tasks, max_heavy, c, hsum);
+        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_bucket_scan_kernel<true>, dim3(nblk, B), dim3(2 * MSM_RB), 0, partial,
+                  toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
+        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_bucket_sum_kernel<true>, dim3(nblk, B), dim3(2 * MSM_RB), 0, sfx, blk_p,
+                  blk_w, nblk);
+        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<true>, dim3(B), dim3(512), 0, blk_w, nblk, d_out);
+    } else {
+        ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<false>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
+                  max_tasks, max_heavy, c, hsum);
+        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_bucket_scan_kernel<false>, dim3(nblk, B), dim3(MSM_RB), 0, partial,
+                  toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
+        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_bucket_sum_kernel<false>, dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
+                  blk_w, nblk);
+        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<false>, dim3(B), dim3(256), 0, blk_w, nblk, d_out);
+    }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -812,6 +812,7 @@ int zg_prover_set_overlap(zg_prover* p, int enable) {
         p->ctx->side->prof_filter = p->ctx->prof_filter;
     }
     p->use_side = enable != 0;
+    p->ctx->msm_pair = enable != 0;  // latency configuration: two lanes per addition in the MSM reduction
     return ZG_OK;
 }
 
