@@ -352,11 +352,20 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void msm_heavy_kernel(const XYZZ9
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t k = hlist[(size_t)b * max_heavy + h];
         const uint32_t t0 = to[k], t1 = to[k + 1];
-        if (role == 0) sh[j] = xyzz9_identity();
-        for (uint32_t t = t0 + j; t < t1; t += 256) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], pp + t, role));
+        if constexpr (PAIR) {
+            if (role == 0) sh[j] = xyzz9_identity();
+            for (uint32_t t = t0 + j; t < t1; t += 256) xstore<true>(&sh[j], xadd<true>(&sh[j], pp + t, role));
+        } else {  // (one lane per addition: the running sum stays in registers)
+            XYZZ9 acc = xyzz9_identity();
+            for (uint32_t t = t0 + j; t < t1; t += 256) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
+            sh[j] = acc;
+        }
         __syncthreads();
         for (uint32_t o = 128; o > 0; o >>= 1) {
-            if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
+            if (j < o) {
+                if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(&sh[j], &sh[j + o], role));
+                else sh[j] = xyzz9_add(sh[j], sh[j + o]);
+            }
             __syncthreads();
         }
         if (threadIdx.x == 0) st_xyzz9(hsum + (size_t)b * max_heavy + h, sh[0]);
@@ -380,24 +389,47 @@ __global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_scan_ke
     const uint32_t k = blk * MSM_RB + j + 1;
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
-    if (role == 0) sh[j] = xyzz9_identity();
-    if (k <= nb) {
-        const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
-        if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
-            if (role == 0) sh[j] = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
-        } else {
-            const uint32_t t0 = to[k], t1 = to[k + 1];
-            for (uint32_t t = t0; t < t1; t++) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], pp + t, role));
+    if constexpr (PAIR) {
+        if (role == 0) sh[j] = xyzz9_identity();
+        if (k <= nb) {
+            const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
+            if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
+                if (role == 0) sh[j] = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
+            } else {
+                const uint32_t t0 = to[k], t1 = to[k + 1];
+                for (uint32_t t = t0; t < t1; t++) xstore<true>(&sh[j], xadd<true>(&sh[j], pp + t, role));
+            }
         }
-    }
-    __syncthreads();
-    for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
-        const bool has = j + o < MSM_RB;
-        XSum s;
-        if (has) s = xadd<PAIR>(&sh[j], &sh[j + o], role);
         __syncthreads();
-        if (has) xstore<PAIR>(&sh[j], s);
+        for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
+            const bool has = j + o < MSM_RB;
+            XSum s;
+            if (has) s = xadd<true>(&sh[j], &sh[j + o], role);
+            __syncthreads();
+            if (has) xstore<true>(&sh[j], s);
+            __syncthreads();
+        }
+    } else {
+        XYZZ9 acc = xyzz9_identity();
+        if (k <= nb) {
+            const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
+            if (hs < max_heavy) {
+                acc = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
+            } else {
+                const uint32_t t0 = to[k], t1 = to[k + 1];
+                for (uint32_t t = t0; t < t1; t++) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
+            }
+        }
+        sh[j] = acc;
         __syncthreads();
+        for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
+            XYZZ9 v = xyzz9_identity();
+            const bool has = j + o < MSM_RB;
+            if (has) v = sh[j + o];
+            __syncthreads();
+            if (has) sh[j] = xyzz9_add(sh[j], v);
+            __syncthreads();
+        }
     }
     if (role == 0) {
         st_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + j, sh[j]);
@@ -422,18 +454,20 @@ __global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_sum_ker
     __syncthreads();
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
-    for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
+    auto tree_step = [&](uint32_t o) {
+        if (j < o) {
+            if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(&sh[j], &sh[j + o], role));
+            else sh[j] = xyzz9_add(sh[j], sh[j + o]);
+        }
         __syncthreads();
-    }
+    };
+    for (uint32_t o = span / 2; o > 0; o >>= 1) tree_step(o);
     if (threadIdx.x == 0) bs = sh[0];
     __syncthreads();
-    xstore<PAIR>(&sh[j], xadd<PAIR>(sfx + ((size_t)b * nblk + blk) * MSM_RB + j, &bs, role));
+    if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(sfx + ((size_t)b * nblk + blk) * MSM_RB + j, &bs, role));
+    else sh[j] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + j), bs);
     __syncthreads();
-    for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) {
-        if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
-        __syncthreads();
-    }
+    for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) tree_step(o);
     if (threadIdx.x == 0) st_xyzz9(blk_w + (size_t)b * nblk + blk, sh[0]);
 }
 
@@ -448,7 +482,10 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void msm_finish_kernel(const XYZZ
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
     for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (j < o) xstore<PAIR>(&sh[j], xadd<PAIR>(&sh[j], &sh[j + o], role));
+        if (j < o) {
+            if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(&sh[j], &sh[j + o], role));
+            else sh[j] = xyzz9_add(sh[j], sh[j + o]);
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
