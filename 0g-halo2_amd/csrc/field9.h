@@ -70,8 +70,8 @@ __device__ __forceinline__ F9 f9_unpack(const Fe& a) {
 #pragma unroll
     for (int i = 1; i < 8; i++) {
         const int bit = 29 * i, w = bit / 32, s = bit % 32;
-        const uint64_t two = ((uint64_t)a.l[w + 1] << 32) | a.l[w];  // (selects to v_alignbit_b32)
-        o.l[i] = (int32_t)((uint32_t)(two >> s) & (uint32_t)MASK29);
+        // (two 32-bit shifts, not a 64-bit funnel: on kernel-argument operands the latter spills them to scratch)
+        o.l[i] = (int32_t)(((a.l[w] >> s) | (a.l[w + 1] << (32 - s))) & (uint32_t)MASK29);
     }
     o.l[8] = (int32_t)(a.l[7] >> 8);
     return o;

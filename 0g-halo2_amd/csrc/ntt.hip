@@ -44,10 +44,10 @@ struct NttArgs {
     uint32_t log_n, log_n1, log_n2;
     uint32_t in_len;    // FIRST pass: input entries beyond in_len read as zero
     uint32_t out_len;   // LAST pass: entries >= out_len are not written
-    uint32_t coset_in;  // FIRST pass: multiply entry j by zin[j % 3]
+    uint32_t coset_in;  // FIRST pass: 1 = multiply entry j by zin[j % 3] for j % 3 != 0; 2 = all three (zin0 too)
     uint32_t coset_out; // LAST pass: multiply entry k by zout[k % 3]
     uint32_t scale_out; // LAST pass: multiply by `scale`
-    Fe zin1, zin2, zout1, zout2, scale;
+    Fe zin0, zin1, zin2, zout1, zout2, scale;
 };
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t v, uint32_t bits) {
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
                     uint32_t m3 = g % 3u;
                     if (m3 == 1) v = Fr::mul(v, a.zin1);
                     else if (m3 == 2) v = Fr::mul(v, a.zin2);
+                    else if (a.coset_in == 2) v = Fr::mul(v, a.zin0);
                 }
             } else {
                 v = fe_zero();
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) 
                     uint32_t m3 = g % 3u;
                     if (m3 == 1) v = Fr9::mul(v, f9_unpack(a.zin1));
                     else if (m3 == 2) v = Fr9::mul(v, f9_unpack(a.zin2));
+                    else if (a.coset_in == 2) v = Fr9::mul(v, f9_unpack(a.zin0));
                 }
             } else {
 #pragma unroll
@@ -387,8 +389,9 @@ struct NttPlan {
     uint32_t log_n;
     Fe omega;
     uint32_t in_len, out_len;
-    bool coset_in = false, coset_out = false, scale_out = false;
-    Fe zin1, zin2, zout1, zout2, scale;
+    uint32_t coset_in = 0;  // 0 none, 1 zeta^(j%3) on j%3 != 0, 2 all entries (zin0 too)
+    bool coset_out = false, scale_out = false;
+    Fe zin0, zin1, zin2, zout1, zout2, scale;
 };
 
 static bool ntt9_enabled() {
@@ -415,10 +418,10 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
     a.coset_in = p.coset_in;
     a.coset_out = p.coset_out;
     a.scale_out = p.scale_out;
-    a.zin1 = p.zin1; a.zin2 = p.zin2; a.zout1 = p.zout1; a.zout2 = p.zout2; a.scale = p.scale;
+    a.zin0 = p.zin0; a.zin1 = p.zin1; a.zin2 = p.zin2; a.zout1 = p.zout1; a.zout2 = p.zout2; a.scale = p.scale;
     if (NINE) {  // constants go in as c * 2^261: a product with them leaves the data in its own form
         const Fe c261 = Fr9Params::c261_fe();
-        if (p.coset_in) { a.zin1 = Fr::mul(p.zin1, c261); a.zin2 = Fr::mul(p.zin2, c261); }
+        if (p.coset_in) { a.zin0 = Fr::mul(p.zin0, c261); a.zin1 = Fr::mul(p.zin1, c261); a.zin2 = Fr::mul(p.zin2, c261); }
         if (p.coset_out) { a.zout1 = Fr::mul(p.zout1, c261); a.zout2 = Fr::mul(p.zout2, c261); }
         if (p.scale_out) a.scale = Fr::mul(p.scale, c261);
     }
@@ -551,8 +554,11 @@ int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t lo
     return ntt_run(ctx, p, tmp, n);
 }
 
+// hat: the evaluations come out multiplied by 2^5, i.e. in the 2^261 Montgomery form evaluate_h's
+// nine-limb arithmetic works in (the factor rides on the coset constants: one extra product for the
+// entries with j % 3 == 0, n of the 8n loaded)
 int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
-                          size_t batch, uint32_t k, uint32_t ext_k) {
+                          size_t batch, uint32_t k, uint32_t ext_k, bool hat) {
     ZG_TRY(ensure_lds_attr());
     WsScope ws(ctx);
     NttPlan p;
@@ -563,9 +569,17 @@ int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_o
     p.omega = host_domain_omega(ext_k);
     p.in_len = 1u << k;
     p.out_len = 1u << ext_k;
-    p.coset_in = true;
+    p.coset_in = 1;
+    p.zin0 = Fr::one();
     p.zin1 = fr_zeta();
     p.zin2 = Fr::sqr(fr_zeta());
+    if (hat) {
+        const Fe c32 = Fr::from_u64(32);
+        p.coset_in = 2;
+        p.zin0 = c32;
+        p.zin1 = Fr::mul(p.zin1, c32);
+        p.zin2 = Fr::mul(p.zin2, c32);
+    }
     size_t n = (size_t)1 << ext_k;
     Fe* tmp = nullptr;
     if (ntt_needs_tmp(ext_k)) {
@@ -577,8 +591,9 @@ int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_o
     return ntt_run(ctx, p, tmp, n);
 }
 
+// unhat: the input is in the 2^261 form (see coeff_to_extended_dev); the output scale takes the 2^-5
 int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len,
-                          Fe* d_out) {
+                          Fe* d_out, bool unhat) {
     (void)k;
     ZG_TRY(ensure_lds_attr());
     WsScope ws(ctx);
@@ -593,7 +608,7 @@ int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, 
     p.in_len = (uint32_t)n;
     p.out_len = (uint32_t)out_len;
     p.scale_out = true;
-    p.scale = Fr::inv(Fr::from_u64((uint64_t)n));
+    p.scale = Fr::inv(Fr::from_u64((uint64_t)n * (unhat ? 32u : 1u)));
     p.coset_out = true;
     p.zout1 = Fr::sqr(fr_zeta());  // zeta^-1
     p.zout2 = fr_zeta();           // zeta^-2
@@ -674,7 +689,7 @@ int zg_coeff_to_extended_batch_dev(zg_ctx* ctx, const void* d_coeffs, size_t in_
     ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_coeff_to_extended: k=%u ext_k=%u", k, ext_k);
     ZG_HIP(hipSetDevice(ctx->device));
     return coeff_to_extended_dev(ctx, (const Fe*)d_coeffs, in_stride_elems, (Fe*)d_out,
-                                 out_stride_elems, batch, k, ext_k);
+                                 out_stride_elems, batch, k, ext_k, false);
 }
 
 int zg_coeff_to_extended(zg_ctx* ctx, const zg_fr* coeffs, uint32_t k, uint32_t ext_k, zg_fr* out) {
@@ -687,7 +702,7 @@ int zg_coeff_to_extended(zg_ctx* ctx, const zg_fr* coeffs, uint32_t k, uint32_t 
     Fe* dout = ws.get<Fe>(en);
     if (!din || !dout) return ZG_ERR_OOM;
     ZG_HIP(hipMemcpyAsync(din, coeffs, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZG_TRY(coeff_to_extended_dev(ctx, din, n, dout, en, 1, k, ext_k));
+    ZG_TRY(coeff_to_extended_dev(ctx, din, n, dout, en, 1, k, ext_k, false));
     ZG_HIP(hipMemcpyAsync(out, dout, en * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     return ZG_OK;
@@ -698,7 +713,7 @@ int zg_extended_to_coeff_dev(zg_ctx* ctx, void* d_evals, uint32_t k, uint32_t ex
     ZG_REQUIRE(ctx && d_evals && d_out, ZG_ERR_INVALID_ARG, "zg_extended_to_coeff: null argument");
     ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_extended_to_coeff: k=%u ext_k=%u", k, ext_k);
     ZG_HIP(hipSetDevice(ctx->device));
-    return extended_to_coeff_dev(ctx, (Fe*)d_evals, k, ext_k, out_len, (Fe*)d_out);
+    return extended_to_coeff_dev(ctx, (Fe*)d_evals, k, ext_k, out_len, (Fe*)d_out, false);
 }
 
 int zg_extended_to_coeff(zg_ctx* ctx, zg_fr* evals, uint32_t k, uint32_t ext_k, size_t out_len,
@@ -713,7 +728,7 @@ int zg_extended_to_coeff(zg_ctx* ctx, zg_fr* evals, uint32_t k, uint32_t ext_k, 
     Fe* dout = ws.get<Fe>(out_len ? out_len : 1);
     if (!din || !dout) return ZG_ERR_OOM;
     ZG_HIP(hipMemcpyAsync(din, evals, en * 32, hipMemcpyHostToDevice, ctx->stream));
-    ZG_TRY(extended_to_coeff_dev(ctx, din, k, ext_k, out_len, dout));
+    ZG_TRY(extended_to_coeff_dev(ctx, din, k, ext_k, out_len, dout, false));
     ZG_HIP(hipMemcpyAsync(out, dout, out_len * 32, hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     return ZG_OK;

@@ -56,6 +56,11 @@ struct EvalHArgs {
     int32_t last_rot;  // -(blinding_factors + 1)
     Fe y, beta, gamma, theta, delta_start, delta;
     Fe* h;
+    // nine-limb evaluation (hat = true): every coset slab, l-polynomial, ext_tw and t_eval entry and every
+    // constant above is in the 2^261 Montgomery form (x * 2^261 mod r, packed), and so are the monomial
+    // coefficients in monos_hat; h comes out in that form too (extended_to_coeff_dev(unhat) undoes it)
+    bool hat;
+    const DMono* monos_hat;
 };
 
 // blinding scalar = f(seed, tag, index); identical to the oracle's definition
@@ -98,7 +103,8 @@ size_t poly_kate_tmp_elems(uint32_t n, uint32_t batch);
 int poly_kate_division(zg_ctx* ctx, const Fe* a, size_t a_stride, const Fe* zs_host, Fe* q, size_t q_stride, Fe* tmp,
                        uint32_t n, uint32_t batch);
 int poly_l_cosets_init(zg_ctx* ctx, Fe* l0, Fe* llast, Fe* lblind, uint32_t n, uint32_t bf);
-int poly_lactive(zg_ctx* ctx, Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en);
+int poly_lactive(zg_ctx* ctx, Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en, bool hat);
+int poly_scale(zg_ctx* ctx, const Fe* in, Fe* out, size_t count, const Fe& factor);  // out[i] = in[i] * factor
 
 // from sort.hip: lookup::prover::permute_expression_pair on the device
 int poly_sort_pad(zg_ctx* ctx, Fe* keys, uint32_t n, uint32_t usable, uint32_t batch);
@@ -110,8 +116,8 @@ int poly_permute_pairs(zg_ctx* ctx, const Fe* a, const Fe* t, Fe* sprime, uint32
 int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
                   const Fe* divisor);
 int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
-                          size_t batch, uint32_t k, uint32_t ext_k);
-int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len, Fe* d_out);
+                          size_t batch, uint32_t k, uint32_t ext_k, bool hat);
+int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat);
 // from msm.hip
 int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch, size_t n,
                   XYZZ* d_out);

@@ -9,6 +9,7 @@
 // recurrences upstream runs on one core -- the running products z[i+1] = z[i]*num/den and the
 // synthetic division by (X - z) -- become block-level scans (1024 lanes x a strip each).
 #include "poly.h"
+#include "field9.h"
 
 namespace zg {
 
@@ -456,11 +457,138 @@ __global__ __launch_bounds__(256) void evaluate_h_kernel(EvalHArgs a, uint32_t e
     stg(a.h + idx, value);
 }
 
+
+// ---- the same evaluation on nine 29-bit limbs (field9.h).  Every operand is in the 2^261 Montgomery form,
+// so Fr9::mul is the field product; sums are limb-wise and lazily normalised under one rule: both
+// operands of a product have limb magnitudes < 2^29, except that ONE of them may be the sum of two
+// normalised values (< 2^30).  A normalised value plus a product (the Horner step) therefore feeds the
+// next product directly.
+__device__ __forceinline__ F9 ld9(const Fe* p) { return f9_unpack(ldg(p)); }
+
+__device__ __forceinline__ F9 eval_poly9(const DevCircuit& c, const DMono* monos, const Cols& cols, zg_poly p, uint32_t row) {
+    const uint32_t mask = (1u << cols.log_size) - 1u;
+    F9 acc;
+#pragma unroll
+    for (int i = 0; i < 9; i++) acc.l[i] = 0;
+    uint32_t pending = 0;  // products added since the last carry normalisation
+    for (uint32_t m = p.first; m < p.first + p.count; m++) {
+        const DMono* mo = monos + m;
+        const uint32_t nf = mo->n_factors;
+        F9 prod;
+        uint32_t f = 0;
+        if (mo->coeff_is_one && nf > 0) {
+            const zg_query q = c.queries[mo->factors[0]];
+            const Fe* base = q.kind == ZG_FIXED ? cols.fixed : q.kind == ZG_ADVICE ? cols.advice : cols.instance;
+            uint32_t idx = (row + (uint32_t)(q.rotation * cols.rot_scale)) & mask;
+            prod = ld9(base + ((size_t)q.column << cols.log_size) + idx);
+            f = 1;
+        } else {
+            prod = f9_unpack(mo->coeff);
+        }
+        for (; f < nf; f++) {
+            const zg_query q = c.queries[mo->factors[f]];
+            const Fe* base = q.kind == ZG_FIXED ? cols.fixed : q.kind == ZG_ADVICE ? cols.advice : cols.instance;
+            uint32_t idx = (row + (uint32_t)(q.rotation * cols.rot_scale)) & mask;
+            prod = Fr9::mul(prod, ld9(base + ((size_t)q.column << cols.log_size) + idx));
+        }
+        acc = f9_add(acc, prod);
+        if (++pending == 2) {  // (wave-uniform: the monomial list is)
+            acc = f9_norm(acc);
+            pending = 0;
+        }
+    }
+    return f9_norm(acc);
+}
+
+__global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t en) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= en) return;
+    const DevCircuit& c = a.c;
+    const uint32_t mask = en - 1;
+    const uint32_t rs = (uint32_t)a.cols.rot_scale;
+    const uint32_t r_next = (idx + rs) & mask;
+    const uint32_t r_prev = (idx - rs) & mask;
+    const uint32_t r_last = (idx + (uint32_t)(a.last_rot * (int32_t)rs)) & mask;
+    // (constants and l-polynomial values are re-materialised at each use: a nine-limb value is 9 VGPRs, and
+    // this kernel's occupancy is set by its register count)
+    // value <- value * y + term   (term normalised; the sum has limbs < 2^30 and goes into the next product)
+    auto fold = [&](const F9& value, const F9& term) { return f9_add(Fr9::mul(value, f9_unpack(a.y)), term); };
+    F9 value;
+#pragma unroll
+    for (int i = 0; i < 9; i++) value.l[i] = 0;
+    for (uint32_t g = 0; g < c.n_gates; g++) value = fold(value, eval_poly9(c, a.monos_hat, a.cols, c.gates[g], idx));
+
+    auto l0 = [&]() { return ld9(a.l0 + idx); };
+    auto llast = [&]() { return ld9(a.llast + idx); };
+    auto lactive = [&]() { return ld9(a.lactive + idx); };
+    auto one = [&]() { return Fr9Params::one(); };
+    if (c.n_sets > 0) {
+        const F9 zf = ld9(a.pz_cos + idx);
+        const F9 zl = ld9(a.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
+        value = fold(value, Fr9::mul(f9_sub(one(), zf), l0()));
+        value = fold(value, Fr9::mul(f9_sub(Fr9::sqr(zl), zl), llast()));
+        for (uint32_t s = 1; s < c.n_sets; s++) {
+            const F9 t = f9_sub(ld9(a.pz_cos + (size_t)s * en + idx), ld9(a.pz_cos + (size_t)(s - 1) * en + r_last));
+            value = fold(value, Fr9::mul(t, l0()));
+        }
+        F9 current_delta = Fr9::mul(f9_unpack(a.delta_start), ld9(a.ext_tw + idx));
+        const F9 delta = f9_unpack(a.delta);
+        for (uint32_t s = 0; s < c.n_sets; s++) {
+            uint32_t c0 = s * c.chunk, c1 = c0 + c.chunk;
+            if (c1 > c.n_perm) c1 = c.n_perm;
+            F9 left = ld9(a.pz_cos + (size_t)s * en + r_next);
+            F9 right = ld9(a.pz_cos + (size_t)s * en + idx);
+            for (uint32_t col = c0; col < c1; col++) {
+                const zg_query q = c.perm_cols[col];
+                const Fe* base = q.kind == ZG_FIXED ? a.cols.fixed : q.kind == ZG_ADVICE ? a.cols.advice : a.cols.instance;
+                const F9 v = ld9(base + ((size_t)q.column << a.cols.log_size) + idx);
+                const F9 sg = ld9(a.sigma_cos + (size_t)col * en + idx);
+                // three-term sums: normalise before they enter a product
+                left = Fr9::mul(left, f9_norm(f9_add(f9_add(Fr9::mul(f9_unpack(a.beta), sg), v), f9_unpack(a.gamma))));
+                right = Fr9::mul(right, f9_norm(f9_add(f9_add(v, current_delta), f9_unpack(a.gamma))));
+                current_delta = Fr9::mul(current_delta, delta);
+            }
+            value = fold(value, Fr9::mul(f9_sub(left, right), lactive()));
+        }
+    }
+    for (uint32_t l = 0; l < c.n_lookups; l++) {
+        const DLookup* lk = c.lookups + l;
+        F9 ai, ti;
+#pragma unroll
+        for (int i = 0; i < 9; i++) ai.l[i] = ti.l[i] = 0;
+        for (uint32_t e = 0; e < lk->width; e++) {
+            ai = f9_add(Fr9::mul(ai, f9_unpack(a.theta)), eval_poly9(c, a.monos_hat, a.cols, lk->inputs[e], idx));
+            ti = f9_add(Fr9::mul(ti, f9_unpack(a.theta)), eval_poly9(c, a.monos_hat, a.cols, lk->tables[e], idx));
+        }
+        const Fe* zc = a.lz_cos + (size_t)l * en;
+        const Fe* ap = a.pin_cos + (size_t)l * en;
+        const Fe* sp = a.ptab_cos + (size_t)l * en;
+        const F9 z = ld9(zc + idx), apv = ld9(ap + idx), spv = ld9(sp + idx);
+        value = fold(value, Fr9::mul(f9_sub(one(), z), l0()));
+        value = fold(value, Fr9::mul(f9_sub(Fr9::sqr(z), z), llast()));
+        // (x + beta)(y + gamma): one factor may stay a two-term sum, the other is normalised
+        const F9 lft = Fr9::mul(Fr9::mul(f9_add(apv, f9_unpack(a.beta)), f9_norm(f9_add(spv, f9_unpack(a.gamma)))), ld9(zc + r_next));
+        const F9 rgt = Fr9::mul(Fr9::mul(f9_norm(f9_add(ai, f9_unpack(a.beta))), f9_norm(f9_add(ti, f9_unpack(a.gamma)))), z);
+        value = fold(value, Fr9::mul(f9_sub(lft, rgt), lactive()));
+        const F9 ams = f9_sub(apv, spv);
+        value = fold(value, Fr9::mul(ams, l0()));
+        value = fold(value, Fr9::mul(Fr9::mul(ams, f9_sub(apv, ld9(ap + r_prev))), lactive()));
+    }
+    // divide_by_vanishing_poly, then back to the canonical packed form (still x * 2^261)
+    value = Fr9::mul(value, ld9(a.t_eval + (idx & a.t_mask)));
+    stg(a.h + idx, f9_reduce_pack<Fr9Params>(value));
+}
+
 int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en) {
     // algorithmic bytes: every input coset read once + h written
     const DevCircuit& c = a.c;
     double arrays = 3.0 + c.n_perm + c.n_sets + 3.0 * c.n_lookups + 1.0;  // l-polys, sigma, z's, lookup polys, h
-    ZG_LAUNCH(ctx, "evaluate_h", arrays * en * 32.0, evaluate_h_kernel, dim3((en + 255) / 256), dim3(256), 0, a, en);
+    ZG_REQUIRE(!a.hat || a.monos_hat != nullptr || (c.n_gates == 0 && c.n_lookups == 0), ZG_ERR_INVALID_ARG,
+               "evaluate_h: the 2^261-form monomial table is missing");
+    if (a.hat)
+        ZG_LAUNCH(ctx, "evaluate_h", arrays * en * 32.0, evaluate_h9_kernel, dim3((en + 255) / 256), dim3(256), 0, a, en);
+    else
+        ZG_LAUNCH(ctx, "evaluate_h", arrays * en * 32.0, evaluate_h_kernel, dim3((en + 255) / 256), dim3(256), 0, a, en);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -644,12 +772,25 @@ int poly_l_cosets_init(zg_ctx* ctx, Fe* l0, Fe* llast, Fe* lblind, uint32_t n, u
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
-__global__ void lactive_kernel(Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en) {
+__global__ void lactive_kernel(Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en, Fe one) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < en) stg(lactive + i, Fr::sub(Fr::one(), Fr::add(ldg(llast + i), ldg(lblind + i))));
+    if (i < en) stg(lactive + i, Fr::sub(one, Fr::add(ldg(llast + i), ldg(lblind + i))));
 }
-int poly_lactive(zg_ctx* ctx, Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en) {
-    ZG_LAUNCH(ctx, "lactive", 0, lactive_kernel, dim3((en + 255) / 256), dim3(256), 0, lactive, llast, lblind, en);
+int poly_lactive(zg_ctx* ctx, Fe* lactive, const Fe* llast, const Fe* lblind, uint32_t en, bool hat) {
+    const Fe one = hat ? Fr::mul(Fr::one(), Fr9Params::c261_fe()) : Fr::one();  // "1" in the slabs' form
+    ZG_LAUNCH(ctx, "lactive", 0, lactive_kernel, dim3((en + 255) / 256), dim3(256), 0, lactive, llast, lblind, en, one);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+__global__ void scale_kernel(const Fe* in, Fe* out, size_t count, Fe factor) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) stg(out + i, Fr::mul(ldg(in + i), factor));
+}
+int poly_scale(zg_ctx* ctx, const Fe* in, Fe* out, size_t count, const Fe& factor) {
+    if (!count) return ZG_OK;
+    ZG_LAUNCH(ctx, "scale", (double)count * 64, scale_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, in, out,
+              count, factor);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

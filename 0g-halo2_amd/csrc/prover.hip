@@ -14,6 +14,7 @@
 #include <memory>
 
 #include "poly.h"
+#include "field9.h"
 #include "transcript.h"
 
 namespace zg {
@@ -87,6 +88,10 @@ struct zg_prover {
     std::vector<void*> owned;  // device allocations freed at destroy
     zg_bases *g = nullptr, *gl = nullptr;
     bool use_side = true;   // coefficient / coset forms on a side stream (latency) or inline (throughput)
+    // evaluate_h on nine 29-bit limbs: the coset slabs, l-polynomials, t_eval and the monomial coefficients it
+    // reads are kept in the 2^261 Montgomery form (x * 2^5 of the library form); ZG_EVALH9=0 turns it off
+    bool hat = true;
+    DMono* monos_hat = nullptr;
     bool own_bases = true;  // false: tables shared with other provers of the same device
     Fe vk_repr{};
     Fe omega{}, omega_inv{}, ifft_div{};
@@ -264,6 +269,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    if (const char* e = getenv("ZG_EVALH9")) p->hat = atoi(e) != 0;
     if (p->use_side && !ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
 
     // ---- validate and upload the circuit tables
@@ -323,6 +329,12 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     p->dc.queries = d_q; p->dc.monos = d_m; p->dc.gates = d_g; p->dc.lookups = d_l; p->dc.perm_cols = d_pc;
     p->dc.n_gates = cs->n_gates; p->dc.n_lookups = cs->n_lookups; p->dc.n_perm = p->P; p->dc.chunk = p->chunk;
     p->dc.n_sets = p->sets;
+    if (p->hat && cs->n_monomials) {  // the same monomials with coefficients in the 2^261 form, for evaluate_h
+        const Fe c261 = Fr9Params::c261_fe();
+        for (auto& d : monos) d.coeff = Fr::mul(d.coeff, c261);
+        ZG_TRY(dalloc(p, &p->monos_hat, cs->n_monomials));
+        ZG_HIP(hipMemcpy(p->monos_hat, monos.data(), monos.size() * sizeof(DMono), hipMemcpyHostToDevice));
+    }
 
     // ---- SRS: upload + window tables, or tables shared with other provers on this device (read-only)
     if (shared_g) {
@@ -400,14 +412,14 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         Fe* fp = p->polys + (size_t)p->ix_fixed * n;
         ZG_HIP(hipMemcpyAsync(fp, p->fixed_val, (size_t)F * n * 32, hipMemcpyDeviceToDevice, st));
         ZG_TRY(ntt_batch_dev(ctx, fp, n, F, p->k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, fp, n, p->fixed_cos, en, F, p->k, p->ext_k));
+        ZG_TRY(coeff_to_extended_dev(ctx, fp, n, p->fixed_cos, en, F, p->k, p->ext_k, p->hat));
     }
     if (P) {
         ZG_HIP(hipMemcpyAsync(p->sigma_val, sigma_values, (size_t)P * n * 32, hipMemcpyHostToDevice, st));
         Fe* sp = p->polys + (size_t)p->ix_sigma * n;
         ZG_HIP(hipMemcpyAsync(sp, p->sigma_val, (size_t)P * n * 32, hipMemcpyDeviceToDevice, st));
         ZG_TRY(ntt_batch_dev(ctx, sp, n, P, p->k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, sp, n, p->sigma_cos, en, P, p->k, p->ext_k));
+        ZG_TRY(coeff_to_extended_dev(ctx, sp, n, p->sigma_cos, en, P, p->k, p->ext_k, p->hat));
     }
     {
         WsScope ws(ctx);
@@ -416,10 +428,10 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         if (ws.failed) return ZG_ERR_OOM;
         ZG_TRY(poly_l_cosets_init(ctx, t3, t3 + n, t3 + 2 * n, n, p->bf));
         ZG_TRY(ntt_batch_dev(ctx, t3, n, 3, p->k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, t3, n, p->l0, en, 1, p->k, p->ext_k));
-        ZG_TRY(coeff_to_extended_dev(ctx, t3 + n, n, p->llast, en, 1, p->k, p->ext_k));
-        ZG_TRY(coeff_to_extended_dev(ctx, t3 + 2 * n, n, lblind, en, 1, p->k, p->ext_k));
-        ZG_TRY(poly_lactive(ctx, p->lactive, p->llast, lblind, en));
+        ZG_TRY(coeff_to_extended_dev(ctx, t3, n, p->l0, en, 1, p->k, p->ext_k, p->hat));
+        ZG_TRY(coeff_to_extended_dev(ctx, t3 + n, n, p->llast, en, 1, p->k, p->ext_k, p->hat));
+        ZG_TRY(coeff_to_extended_dev(ctx, t3 + 2 * n, n, lblind, en, 1, p->k, p->ext_k, p->hat));
+        ZG_TRY(poly_lactive(ctx, p->lactive, p->llast, lblind, en, p->hat));
         ZG_HIP(hipStreamSynchronize(st));
     }
     // t_evaluations of EvaluationDomain: ((zeta * ext_omega^i)^n - 1)^-1, one period
@@ -430,6 +442,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         Fe cur = Fr::pow_u64(fr_zeta(), n), step = Fr::pow_u64(ext_omega, n);
         for (uint32_t i = 0; i < t_len; i++) {
             te[i] = Fr::inv(Fr::sub(cur, Fr::one()));
+            if (p->hat) te[i] = Fr::mul(te[i], Fr9Params::c261_fe());
             cur = Fr::mul(cur, step);
         }
         ZG_TRY(dalloc(p, &p->t_eval, t_len));
@@ -509,14 +522,14 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     if (I) {
         ZG_HIP(hipMemcpyAsync(poly_at(p->ix_inst), p->inst_val, (size_t)I * n * 32, hipMemcpyDeviceToDevice, ss));
         ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_inst), n, p->inst_cos, en, I, k, ek));
+        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_inst), n, p->inst_cos, en, I, k, ek, p->hat));
     }
     if (A) {
         ZG_TRY(msm_batch_dev(ctx, p->gl, adv, n, A, n, p->xyzz));
         ZG_TRY(fetch_points(p, A, pts));
         ZG_HIP(hipMemcpyAsync(poly_at(p->ix_adv), adv, (size_t)A * n * 32, hipMemcpyDeviceToDevice, ss));
         ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_adv), n, p->adv_cos, en, A, k, ek));
+        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_adv), n, p->adv_cos, en, A, k, ek, p->hat));
         ZG_TRY(wait_points(p, A, pts));
         for (auto& q : pts) tr.write_point(q);
     }
@@ -555,7 +568,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
         ZG_HIP(hipMemcpyAsync(poly_at(p->ix_perm), p->perm, (size_t)2 * NL * n * 32, hipMemcpyDeviceToDevice, ss));
         ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_perm), n, p->perm_cos, en, 2 * NL, k, ek));
+        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_perm), n, p->perm_cos, en, 2 * NL, k, ek, p->hat));
         // evaluate_h wants a'_l and s'_l cosets in separate [l] slabs
         for (uint32_t l = 0; l < NL; l++) {
             ZG_HIP(hipMemcpyAsync(p->pin_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, ss));
@@ -601,8 +614,8 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_TRY(fetch_points(p, npts, pts));
         ZG_HIP(hipMemcpyAsync(poly_at(p->ix_pz), p->zs, (size_t)(S + NL) * n * 32, hipMemcpyDeviceToDevice, ss));
         ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
-        if (S) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_pz), n, p->pz_cos, en, S, k, ek));
-        if (NL) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_lz), n, p->lz_cos, en, NL, k, ek));
+        if (S) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_pz), n, p->pz_cos, en, S, k, ek, p->hat));
+        if (NL) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_lz), n, p->lz_cos, en, NL, k, ek, p->hat));
         ZG_TRY(wait_points(p, npts, pts));
         for (uint32_t i = 0; i < S + NL; i++) tr.write_point(pts[i]);
         if (!have_random) {
@@ -632,15 +645,22 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         // perm_cos is interleaved [2l] = a', [2l+1] = s': the kernel wants [l] strides -> separate views
         a.pin_cos = p->pin_cos_c; a.ptab_cos = p->ptab_cos_c;
         a.l0 = p->l0; a.llast = p->llast; a.lactive = p->lactive;
-        a.ext_tw = p->ext_tw; a.t_eval = p->t_eval; a.t_mask = (1u << (ek - k)) - 1;
+        a.ext_tw = p->hat ? p->ext_tw + en : p->ext_tw;  // (the twiddle table's second half is the 2^261 form)
+        a.t_eval = p->t_eval; a.t_mask = (1u << (ek - k)) - 1;
         a.last_rot = -(int32_t)(bf + 1);
         a.y = y; a.beta = beta; a.gamma = gamma; a.theta = theta;
         a.delta_start = Fr::mul(beta, fr_zeta()); a.delta = fr_delta();
+        a.hat = p->hat;
+        a.monos_hat = p->monos_hat;
+        if (p->hat) {
+            const Fe c261 = Fr9Params::c261_fe();
+            for (Fe* cst : {&a.y, &a.beta, &a.gamma, &a.theta, &a.delta_start, &a.delta}) *cst = Fr::mul(*cst, c261);
+        }
         a.h = p->h;
         ZG_TRY(poly_evaluate_h(ctx, a, en));
     }
     p->have_last = true;
-    ZG_TRY(extended_to_coeff_dev(ctx, p->h, k, ek, (size_t)Q * n, poly_at(p->ix_hpiece)));
+    ZG_TRY(extended_to_coeff_dev(ctx, p->h, k, ek, (size_t)Q * n, poly_at(p->ix_hpiece), p->hat));
     ZG_TRY(msm_batch_dev(ctx, p->g, poly_at(p->ix_hpiece), n, Q, n, p->xyzz));
     ZG_TRY(fetch_points(p, Q, pts));
     ZG_TRY(wait_points(p, Q, pts));
@@ -843,6 +863,15 @@ int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, siz
     }
     ZG_REQUIRE(cap_elems >= count, ZG_ERR_INVALID_ARG, "zg_prover_fetch: need %zu elements", count);
     ZG_HIP(hipSetDevice(p->ctx->device));
+    if (what == 0 && p->hat) {  // h on the coset is kept as x * 2^261: hand back the library form
+        WsScope ws(p->ctx);
+        Fe* tmp = ws.get<Fe>(count);
+        if (!tmp) return ZG_ERR_OOM;
+        ZG_TRY(poly_scale(p->ctx, src, tmp, count, Fr::inv(Fr::from_u64(32))));
+        ZG_HIP(hipStreamSynchronize(p->ctx->stream));
+        ZG_HIP(hipMemcpy(out, tmp, count * 32, hipMemcpyDeviceToHost));
+        return ZG_OK;
+    }
     ZG_HIP(hipMemcpy(out, src, count * 32, hipMemcpyDeviceToHost));
     return ZG_OK;
 }
