@@ -162,7 +162,39 @@ struct Field9 {
         r.l[8] = (int32_t)acc;
         return r;
     }
-    static __device__ __forceinline__ F9 sqr(const F9& a) { return mul(a, a); }
+    // a * a * 2^-261: the 36 cross products are taken once against the doubled operand (limbs < 2^30,
+    // which the accumulator bound allows on one side) -- 45 + 81 mads instead of 81 + 81.
+    static __device__ __forceinline__ F9 sqr(const F9& a) {
+        int64_t acc = 0;
+        int32_t m[9], d[9];
+        F9 r;
+#pragma unroll
+        for (int i = 0; i < 9; i++) d[i] = a.l[i] + a.l[i];
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < 9 && i < j) acc += (int64_t)d[i] * (int64_t)a.l[j];
+                if (j == i) acc += (int64_t)a.l[i] * (int64_t)a.l[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (i < k && j >= 0 && j < 9) acc += (int64_t)m[i] * (int64_t)P::p(j);
+            }
+            if (k < 9) {
+                m[k] = (int32_t)(((uint32_t)acc * P::INV29) & (uint32_t)MASK29);
+                acc += (int64_t)m[k] * (int64_t)P::p(0);
+                acc >>= 29;
+            } else {
+                r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK29);
+                acc >>= 29;
+            }
+        }
+        r.l[8] = (int32_t)acc;
+        return r;
+    }
 
     // value in (-2p, 3p), any limbs -> the canonical representative in [0, p), normalised
     static __device__ F9 canon(const F9& x) {
