@@ -513,10 +513,13 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     // this kernel's occupancy is set by its register count)
     // value <- value * y + term   (term normalised; the sum has limbs < 2^30 and goes into the next product)
     auto fold = [&](const F9& value, const F9& term) { return f9_add(Fr9::mul(value, f9_unpack(a.y)), term); };
+    // value <- value * y + u * v with ONE Montgomery reduction (value normalised, u and v with limbs < 2^29)
+    auto fold2 = [&](const F9& value, const F9& u, const F9& v) { return Fr9::mul2<false>(value, f9_unpack(a.y), u, v); };
     F9 value;
 #pragma unroll
     for (int i = 0; i < 9; i++) value.l[i] = 0;
     for (uint32_t g = 0; g < c.n_gates; g++) value = fold(value, eval_poly9(c, a.monos_hat, a.cols, c.gates[g], idx));
+    value = f9_norm(value);  // from here on every term is a product: fold2 keeps value normalised
 
     auto l0 = [&]() { return ld9(a.l0 + idx); };
     auto llast = [&]() { return ld9(a.llast + idx); };
@@ -525,11 +528,11 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     if (c.n_sets > 0) {
         const F9 zf = ld9(a.pz_cos + idx);
         const F9 zl = ld9(a.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
-        value = fold(value, Fr9::mul(f9_sub(one(), zf), l0()));
-        value = fold(value, Fr9::mul(f9_sub(Fr9::sqr(zl), zl), llast()));
+        value = fold2(value, f9_sub(one(), zf), l0());
+        value = fold2(value, f9_sub(Fr9::sqr(zl), zl), llast());
         for (uint32_t s = 1; s < c.n_sets; s++) {
             const F9 t = f9_sub(ld9(a.pz_cos + (size_t)s * en + idx), ld9(a.pz_cos + (size_t)(s - 1) * en + r_last));
-            value = fold(value, Fr9::mul(t, l0()));
+            value = fold2(value, t, l0());
         }
         F9 current_delta = Fr9::mul(f9_unpack(a.delta_start), ld9(a.ext_tw + idx));
         const F9 delta = f9_unpack(a.delta);
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
                 right = Fr9::mul(right, f9_norm(f9_add(f9_add(v, current_delta), f9_unpack(a.gamma))));
                 current_delta = Fr9::mul(current_delta, delta);
             }
-            value = fold(value, Fr9::mul(f9_sub(left, right), lactive()));
+            value = fold2(value, f9_sub(left, right), lactive());
         }
     }
     for (uint32_t l = 0; l < c.n_lookups; l++) {
@@ -564,15 +567,15 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
         const Fe* ap = a.pin_cos + (size_t)l * en;
         const Fe* sp = a.ptab_cos + (size_t)l * en;
         const F9 z = ld9(zc + idx), apv = ld9(ap + idx), spv = ld9(sp + idx);
-        value = fold(value, Fr9::mul(f9_sub(one(), z), l0()));
-        value = fold(value, Fr9::mul(f9_sub(Fr9::sqr(z), z), llast()));
+        value = fold2(value, f9_sub(one(), z), l0());
+        value = fold2(value, f9_sub(Fr9::sqr(z), z), llast());
         // (x + beta)(y + gamma): one factor may stay a two-term sum, the other is normalised
         const F9 lft = Fr9::mul(Fr9::mul(f9_add(apv, f9_unpack(a.beta)), f9_norm(f9_add(spv, f9_unpack(a.gamma)))), ld9(zc + r_next));
         const F9 rgt = Fr9::mul(Fr9::mul(f9_norm(f9_add(ai, f9_unpack(a.beta))), f9_norm(f9_add(ti, f9_unpack(a.gamma)))), z);
-        value = fold(value, Fr9::mul(f9_sub(lft, rgt), lactive()));
+        value = fold2(value, f9_sub(lft, rgt), lactive());
         const F9 ams = f9_sub(apv, spv);
-        value = fold(value, Fr9::mul(ams, l0()));
-        value = fold(value, Fr9::mul(Fr9::mul(ams, f9_sub(apv, ld9(ap + r_prev))), lactive()));
+        value = fold2(value, ams, l0());
+        value = fold2(value, Fr9::mul(ams, f9_sub(apv, ld9(ap + r_prev))), lactive());
     }
     // divide_by_vanishing_poly, then back to the canonical packed form (still x * 2^261)
     value = Fr9::mul(value, ld9(a.t_eval + (idx & a.t_mask)));
