@@ -467,36 +467,50 @@ __device__ __forceinline__ F9 ld9(const Fe* p) { return f9_unpack(ldg(p)); }
 
 __device__ __forceinline__ F9 eval_poly9(const DevCircuit& c, const DMono* monos, const Cols& cols, zg_poly p, uint32_t row) {
     const uint32_t mask = (1u << cols.log_size) - 1u;
+    auto cell = [&](uint32_t qi) {
+        const zg_query q = c.queries[qi];
+        const Fe* base = q.kind == ZG_FIXED ? cols.fixed : q.kind == ZG_ADVICE ? cols.advice : cols.instance;
+        const uint32_t idx = (row + (uint32_t)(q.rotation * cols.rot_scale)) & mask;
+        return ld9(base + ((size_t)q.column << cols.log_size) + idx);
+    };
     F9 acc;
 #pragma unroll
     for (int i = 0; i < 9; i++) acc.l[i] = 0;
-    uint32_t pending = 0;  // products added since the last carry normalisation
-    for (uint32_t m = p.first; m < p.first + p.count; m++) {
-        const DMono* mo = monos + m;
-        const uint32_t nf = mo->n_factors;
-        F9 prod;
-        uint32_t f = 0;
-        if (mo->coeff_is_one && nf > 0) {
-            const zg_query q = c.queries[mo->factors[0]];
-            const Fe* base = q.kind == ZG_FIXED ? cols.fixed : q.kind == ZG_ADVICE ? cols.advice : cols.instance;
-            uint32_t idx = (row + (uint32_t)(q.rotation * cols.rot_scale)) & mask;
-            prod = ld9(base + ((size_t)q.column << cols.log_size) + idx);
-            f = 1;
-        } else {
-            prod = f9_unpack(mo->coeff);
-        }
-        for (; f < nf; f++) {
-            const zg_query q = c.queries[mo->factors[f]];
-            const Fe* base = q.kind == ZG_FIXED ? cols.fixed : q.kind == ZG_ADVICE ? cols.advice : cols.instance;
-            uint32_t idx = (row + (uint32_t)(q.rotation * cols.rot_scale)) & mask;
-            prod = Fr9::mul(prod, ld9(base + ((size_t)q.column << cols.log_size) + idx));
-        }
-        acc = f9_add(acc, prod);
+    uint32_t pending = 0;  // terms added since the last carry normalisation
+    auto add = [&](const F9& t) {
+        acc = f9_add(acc, t);
         if (++pending == 2) {  // (wave-uniform: the monomial list is)
             acc = f9_norm(acc);
             pending = 0;
         }
+    };
+    // A monomial is L * R with R its last factor; the final products of two consecutive monomials share one
+    // Montgomery reduction (Fr9::mul2).
+    F9 hl, hr;          // a monomial waiting for its partner
+    bool held = false;
+    for (uint32_t m = p.first; m < p.first + p.count; m++) {
+        const DMono* mo = monos + m;
+        const uint32_t nf = mo->n_factors;
+        const bool with_coeff = !(mo->coeff_is_one && nf > 0);
+        const uint32_t terms = nf + (with_coeff ? 1u : 0u);  // operands of the product
+        if (terms == 1) {  // a bare cell or a bare constant
+            add(with_coeff ? f9_unpack(mo->coeff) : cell(mo->factors[0]));
+            continue;
+        }
+        uint32_t f = 0;
+        F9 l = with_coeff ? f9_unpack(mo->coeff) : cell(mo->factors[f++]);
+        for (; f + 1 < nf; f++) l = Fr9::mul(l, cell(mo->factors[f]));
+        const F9 r = cell(mo->factors[nf - 1]);
+        if (held) {
+            add(Fr9::mul2<false>(hl, hr, l, r));
+            held = false;
+        } else {
+            hl = l;
+            hr = r;
+            held = true;
+        }
     }
+    if (held) add(Fr9::mul(hl, hr));
     return f9_norm(acc);
 }
 
@@ -547,11 +561,17 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
                 const F9 v = ld9(base + ((size_t)q.column << a.cols.log_size) + idx);
                 const F9 sg = ld9(a.sigma_cos + (size_t)col * en + idx);
                 // three-term sums: normalise before they enter a product
-                left = Fr9::mul(left, f9_norm(f9_add(f9_add(Fr9::mul(f9_unpack(a.beta), sg), v), f9_unpack(a.gamma))));
-                right = Fr9::mul(right, f9_norm(f9_add(f9_add(v, current_delta), f9_unpack(a.gamma))));
+                const F9 fl = f9_norm(f9_add(f9_add(Fr9::mul(f9_unpack(a.beta), sg), v), f9_unpack(a.gamma)));
+                const F9 fr = f9_norm(f9_add(f9_add(v, current_delta), f9_unpack(a.gamma)));
                 current_delta = Fr9::mul(current_delta, delta);
+                if (col + 1 < c1) {
+                    left = Fr9::mul(left, fl);
+                    right = Fr9::mul(right, fr);
+                } else {  // last column of the set: left * fl - right * fr under one reduction
+                    left = Fr9::mul2<true>(left, fl, right, fr);
+                }
             }
-            value = fold2(value, f9_sub(left, right), lactive());
+            value = fold2(value, left, lactive());
         }
     }
     for (uint32_t l = 0; l < c.n_lookups; l++) {
@@ -570,9 +590,9 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
         value = fold2(value, f9_sub(one(), z), l0());
         value = fold2(value, f9_sub(Fr9::sqr(z), z), llast());
         // (x + beta)(y + gamma): one factor may stay a two-term sum, the other is normalised
-        const F9 lft = Fr9::mul(Fr9::mul(f9_add(apv, f9_unpack(a.beta)), f9_norm(f9_add(spv, f9_unpack(a.gamma)))), ld9(zc + r_next));
-        const F9 rgt = Fr9::mul(Fr9::mul(f9_norm(f9_add(ai, f9_unpack(a.beta))), f9_norm(f9_add(ti, f9_unpack(a.gamma)))), z);
-        value = fold2(value, f9_sub(lft, rgt), lactive());
+        const F9 lft = Fr9::mul(f9_add(apv, f9_unpack(a.beta)), f9_norm(f9_add(spv, f9_unpack(a.gamma))));
+        const F9 rgt = Fr9::mul(f9_norm(f9_add(ai, f9_unpack(a.beta))), f9_norm(f9_add(ti, f9_unpack(a.gamma))));
+        value = fold2(value, Fr9::mul2<true>(lft, ld9(zc + r_next), rgt, z), lactive());
         const F9 ams = f9_sub(apv, spv);
         value = fold2(value, ams, l0());
         value = fold2(value, Fr9::mul(ams, f9_sub(apv, ld9(ap + r_prev))), lactive());
