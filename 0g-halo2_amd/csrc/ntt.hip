@@ -24,10 +24,10 @@
 // domain conversion of the data (d stays in the library's x * 2^256 form).  Magnitudes grow by one bit
 // per stage on the sum path (a product resets them to ~p), 2^253.6 * 2^9 < 2^263 fits the top limb, and
 // the store reduces to the canonical packed form.  It is bit-exact and issues 18 % fewer instructions per
-// butterfly (385 vs 470), but MEASURES SLOWER inside the proof (1.75 vs 1.65 ms/proof with 2048-element
-// tiles, 1.66 vs 1.65 with 1024): nine 4-byte LDS accesses per element instead of two 16-byte ones, on
-// tiles whose bit-reversed store indices already serialise on one LDS bank, cost more than the saved
-// VALU work -- the NTT is LDS-bound before it is VALU-bound.  Kept for the next layout experiment.
+// butterfly (385 vs 470).  With nine 4-byte LDS accesses per element it measured slower than the packed
+// back end (1.75 vs 1.65 ms/proof); with limbs 0..7 as two 16-byte LDS words plus a 4-byte one it is on
+// par (1.56 vs 1.56) -- the transform is bound by its LDS round trips and barriers before its VALU work,
+// so the default stays with the packed back end.
 #include <cstdlib>
 
 #include "common.h"
@@ -234,8 +234,28 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) 
     // would fit a CU, so the large tile reads its twiddles from the (L2-resident) HBM table instead
     constexpr bool TWL = LOG_T <= 10;
     extern __shared__ __align__(16) unsigned char smem[];
-    F9* X = reinterpret_cast<F9*>(smem);
-    F9* TW = X + T;
+    // LDS layout: limbs 0..3 and 4..7 of an element as two 16-byte words in two arrays, limb 8 in a third
+    // (three LDS accesses per element instead of nine 4-byte ones), slots XOR-folded as in ntt_pass_kernel
+    uint4* XL = reinterpret_cast<uint4*>(smem);
+    uint4* XH = XL + T;
+    int32_t* X8 = reinterpret_cast<int32_t*>(XH + T);
+    F9* TW = reinterpret_cast<F9*>(X8 + T);
+    auto slot = [](uint32_t i) { return i ^ ((i >> 3) & 7u) ^ ((i >> 6) & 7u) ^ ((i >> 9) & 7u); };
+    auto ldx = [&](uint32_t i) {
+        const uint32_t s = slot(i);
+        const uint4 lo = XL[s], hi = XH[s];
+        F9 r;
+        r.l[0] = (int32_t)lo.x; r.l[1] = (int32_t)lo.y; r.l[2] = (int32_t)lo.z; r.l[3] = (int32_t)lo.w;
+        r.l[4] = (int32_t)hi.x; r.l[5] = (int32_t)hi.y; r.l[6] = (int32_t)hi.z; r.l[7] = (int32_t)hi.w;
+        r.l[8] = X8[s];
+        return r;
+    };
+    auto stx = [&](uint32_t i, const F9& v) {
+        const uint32_t s = slot(i);
+        XL[s] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
+        XH[s] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
+        X8[s] = v.l[8];
+    };
 
     const uint32_t tid = threadIdx.x;
     const uint32_t log_m = COLS ? a.log_n1 : a.log_n2;
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) 
         } else {
             v = f9_unpack(ld_fe(in + g));
         }
-        X[e] = v;
+        stx(e, v);
     }
     __syncthreads();
 
@@ -305,14 +325,14 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) 
             uint32_t lo = (blk << (log_half + 1)) + i, hi = lo + half;
             uint32_t ilo = COLS ? (lo << log_cnt) + s : (s << log_m) + lo;
             uint32_t ihi = COLS ? (hi << log_cnt) + s : (s << log_m) + hi;
-            const F9 u = X[ilo], v = X[ihi];
-            X[ilo] = f9_norm(f9_add(u, v));
+            const F9 u = ldx(ilo), v = ldx(ihi);
+            stx(ilo, f9_norm(f9_add(u, v)));
             const F9 d = f9_sub(u, v);
             const uint32_t twi = i << st;
             if (twi != 0)
-                X[ihi] = Fr9::mul(d, TWL ? TW[twi] : f9_unpack(ld_fe(tw9 + ((size_t)twi << tw_shift))));
+                stx(ihi, Fr9::mul(d, TWL ? TW[twi] : f9_unpack(ld_fe(tw9 + ((size_t)twi << tw_shift)))));
             else
-                X[ihi] = f9_norm(d);
+                stx(ihi, f9_norm(d));
         }
         __syncthreads();
     }
@@ -322,7 +342,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) 
             uint32_t c = e & (cnt - 1), pos = e >> log_cnt;
             uint32_t k1 = bitrev(pos, log_m);
             uint32_t j2 = base + c;
-            F9 v = X[e];
+            F9 v = ldx(e);
             uint32_t ti = j2 * k1;  // < N
             if (ti != 0) v = Fr9::mul(v, f9_unpack(ld_fe(tw9 + ti)));
             st_fe(out + (size_t)k1 * N2 + j2, f9_reduce_pack<Fr9Params>(v));
@@ -333,7 +353,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) 
             uint32_t pos = bitrev(k2, log_m);
             uint32_t k = (base + r) + N1 * k2;
             if (k >= a.out_len) continue;
-            F9 v = X[(r << log_m) + pos];
+            F9 v = ldx((r << log_m) + pos);
             if (a.scale_out) v = Fr9::mul(v, f9_unpack(a.scale));
             if (a.coset_out) {
                 uint32_t m3 = k % 3u;
