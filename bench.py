@@ -136,9 +136,14 @@ def valu_utilisation(ms_per_proof: float):
     except (OSError, KeyError, ValueError):
         return None
     peak = 256 * 4 * 2.4e9 / 4
+    # tools/microbench.hip on this chip: a full-rate VALU op (v_add_co_u32) sustains 3.13e13 lane-ops/s =
+    # 4.9e11 wave-instructions/s (the clock under load is ~1.9 GHz, not 2.4); v_mad_u64_u32 / v_mad_i64_i32
+    # run at 0.87x that
+    measured_peak = 31263.2e9 / 64
     achieved = per_proof / (ms_per_proof * 1e-3)
     return {"wave_instructions_per_proof": per_proof, "achieved_wave_instr_per_s": achieved,
-            "issue_peak_wave_instr_per_s": peak, "frac": achieved / peak}
+            "issue_peak_wave_instr_per_s": peak, "frac": achieved / peak,
+            "measured_issue_peak_wave_instr_per_s": measured_peak, "frac_of_measured_peak": achieved / measured_peak}
 
 
 def cpu_baseline(job: ProofJob, threads: int):

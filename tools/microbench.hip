@@ -30,6 +30,7 @@ __global__ void probe(uint32_t* out, uint32_t seed) {
             if (OP == 6) { uint32_t lo = (uint32_t)acc[i]; asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(lo) : "v"(b)); acc[i] = lo; }
             if (OP == 7) { uint32_t lo = (uint32_t)acc[i]; asm volatile("v_mov_b32 %0, %1" : "+v"(lo) : "v"(b)); acc[i] = lo; }
             if (OP == 8) { uint32_t lo = (uint32_t)acc[i]; asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(lo) : "v"(b)); acc[i] = lo; }
+            if (OP == 10) { long long sa = (long long)acc[i]; asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(sa) : "v"(a), "v"(b) : "vcc"); acc[i] = (uint64_t)sa; }
             if (OP == 9) { uint32_t lo = (uint32_t)acc[i]; asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(lo) : "v"(b) : "vcc"); acc[i] = lo; }
         }
     }
@@ -83,6 +84,7 @@ int main() {
     uint32_t* d_out;
     CK(hipMalloc(&d_out, 256 * 4 * 256 * 64 * sizeof(uint32_t)));
     run<0>("v_mad_u64_u32", d_out);
+    run<10>("v_mad_i64_i32", d_out);
     run<1>("v_mul_lo_u32", d_out);
     run<2>("v_mul_hi_u32", d_out);
     run<3>("v_lshl_add_u64", d_out);
