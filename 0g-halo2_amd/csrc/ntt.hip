@@ -166,9 +166,50 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
     }
     __syncthreads();
 
-    // DIF butterflies: natural order in, bit-reversed order out
+    // DIF butterflies: natural order in, bit-reversed order out.  Two stages at a time in registers (a
+    // radix-2^2 group of four elements per lane: the same four products, half the LDS round trips and
+    // barriers), one radix-2 stage at the end when the count is odd.
+    auto at = [&](uint32_t sub, uint32_t e) { return COLS ? (e << log_cnt) + sub : (sub << log_m) + e; };
+    uint32_t st = 0;
+    for (; st + 1 < log_m; st += 2) {
+        const uint32_t log_half = log_m - st - 1, log_q = log_half - 1;
+        const uint32_t half = 1u << log_half, quarter = 1u << log_q;
+        for (uint32_t g = tid; g < tile / 4; g += NT) {
+            uint32_t sub, b;
+            if (COLS) {
+                sub = g & (cnt - 1);
+                b = g >> log_cnt;
+            } else {
+                b = g & (M / 4 - 1);
+                sub = g >> (log_m - 2);
+            }
+            const uint32_t blk = b >> log_q, i = b & (quarter - 1);
+            const uint32_t e0 = (blk << (log_half + 1)) + i;
+            const uint32_t i0 = at(sub, e0), i1 = at(sub, e0 + quarter), i2 = at(sub, e0 + half), i3 = at(sub, e0 + half + quarter);
+            const Fe x0 = ldx(i0), x1 = ldx(i1), x2 = ldx(i2), x3 = ldx(i3);
+            // stage st: (x0, x2) and (x1, x3), twiddles omega_M^(j << st) for j = i and i + quarter
+            const Fe a0 = Fr::add(x0, x2), a1 = Fr::add(x1, x3);
+            Fe a2 = Fr::sub(x0, x2), a3 = Fr::sub(x1, x3);
+            const uint32_t t0 = i << st;
+            if (t0 != 0) a2 = Fr::mul(a2, ldt(t0));
+            a3 = Fr::mul(a3, ldt((i + quarter) << st));
+            // stage st + 1: (a0, a1) and (a2, a3), twiddle omega_M^(i << (st + 1)) for both
+            const uint32_t t1 = i << (st + 1);
+            stx(i0, Fr::add(a0, a1));
+            stx(i2, Fr::add(a2, a3));
+            Fe b1 = Fr::sub(a0, a1), b3 = Fr::sub(a2, a3);
+            if (t1 != 0) {
+                const Fe w = ldt(t1);
+                b1 = Fr::mul(b1, w);
+                b3 = Fr::mul(b3, w);
+            }
+            stx(i1, b1);
+            stx(i3, b3);
+        }
+        __syncthreads();
+    }
     const uint32_t nbf = tile / 2;
-    for (uint32_t st = 0; st < log_m; st++) {
+    for (; st < log_m; st++) {
         const uint32_t log_half = log_m - st - 1;
         const uint32_t half = 1u << log_half;
         for (uint32_t bf = tid; bf < nbf; bf += NT) {
@@ -182,8 +223,7 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
             }
             uint32_t blk = b >> log_half, i = b & (half - 1);
             uint32_t lo = (blk << (log_half + 1)) + i, hi = lo + half;
-            uint32_t ilo = COLS ? (lo << log_cnt) + s : (s << log_m) + lo;
-            uint32_t ihi = COLS ? (hi << log_cnt) + s : (s << log_m) + hi;
+            uint32_t ilo = at(s, lo), ihi = at(s, hi);
             Fe u = ldx(ilo), v = ldx(ihi);
             stx(ilo, Fr::add(u, v));
             Fe d = Fr::sub(u, v);
