@@ -738,6 +738,12 @@ int zg_msm_batch(zg_ctx* ctx, const zg_bases* bases, const zg_fr* const* scalars
     return zg_msm_finish(ctx, r, batch, out);
 }
 
+int zg_ctx_set_msm_latency(zg_ctx* ctx, int latency) {
+    ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_set_msm_latency: ctx is null");
+    ctx->msm_pair = latency != 0;
+    return ZG_OK;
+}
+
 int zg_msm(zg_ctx* ctx, const zg_bases* bases, const zg_fr* scalars, size_t n, zg_g1* out) {
     const zg_fr* arr[1] = {scalars};
     return zg_msm_batch(ctx, bases, arr, 1, n, out);

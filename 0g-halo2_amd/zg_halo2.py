@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "zg_domain_omega", "zg_ctx_profile_enable", "zg_ctx_profile_collect", "zg_params_new",
     "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
     "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
-    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_set_overlap",
+    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_set_overlap", "zg_ctx_set_msm_latency",
     "zg_prover_create_shared",
 ]
 
@@ -186,6 +186,10 @@ class Ctx:
         _check(self.lib.zg_params_new_dev(self.h, c_uint32(k), _ptr(_fr(s)), c_void_p(d_g), c_void_p(d_gl)))
 
     # ---- MSM ----
+    def set_msm_latency(self, latency: bool):
+        """True (default): two lanes per addition in the MSM reduction; False: one lane per addition."""
+        _check(self.lib.zg_ctx_set_msm_latency(self.h, ctypes.c_int(1 if latency else 0)))
+
     def register_bases(self, bases: np.ndarray, window_bits: int = 0) -> "Bases":
         bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
         h = c_void_p()

@@ -98,6 +98,12 @@ void zg_bases_free(zg_bases *b);
 size_t zg_bases_len(const zg_bases *b);
 uint32_t zg_bases_window_bits(const zg_bases *b);
 
+/* Form of the MSM bucket reduction on this context: latency = 1 (default) spends two lanes per EC addition
+ * -- shortest dependent chain, for a lone MSM or proof; latency = 0 spends one lane per addition, the
+ * form for many MSMs in flight.  Results are identical.
+ * zg_prover_set_overlap sets it together with the prover's own scheduling. */
+int zg_ctx_set_msm_latency(zg_ctx *ctx, int latency);
+
 /* out = sum_i scalars[i] * bases[i], i < n <= zg_bases_len; == best_multiexp(scalars, &bases[..n]) */
 int zg_msm(zg_ctx *ctx, const zg_bases *bases, const zg_fr *scalars, size_t n, zg_g1 *out);
 /* `batch` scalar vectors against the same bases in one launch sequence; out[batch]. */

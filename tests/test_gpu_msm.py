@@ -111,3 +111,23 @@ def test_params_new_matches_oracle(ctx, zg, orc):
     prm = orc.params_new(k, 0x5EED)
     assert np.array_equal(g, prm.g_np())
     assert np.array_equal(gl, prm.g_lagrange_np())
+
+
+@pytest.mark.parametrize("latency", [True, False])
+def test_both_reduction_forms_match_the_oracle(ctx, zg, orc, srs, latency):
+    """zg_ctx_set_msm_latency: two lanes per addition (default) and one lane per addition."""
+    g, gl = srs
+    n = gl.shape[0]
+    ctx.set_msm_latency(latency)
+    try:
+        for c in (0, 6, 12):
+            bases = ctx.register_bases(gl, c)
+            for s in (orc.fill_fr(31, n), orc.fill_fr_sparse(32, n), np.tile(orc.fr_from_int(3), (n, 1))):
+                assert np.array_equal(ctx.msm(bases, s), orc.msm(s, gl, threads=8))
+            e = np.zeros((n, 4), np.uint64)
+            e[5] = orc.fr_from_int(1)
+            assert np.array_equal(ctx.msm(bases, e)[:8], gl[5])
+            assert not ctx.msm(bases, np.zeros((n, 4), np.uint64))[8:].any()
+            bases.free()
+    finally:
+        ctx.set_msm_latency(True)
