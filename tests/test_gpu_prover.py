@@ -240,3 +240,20 @@ def test_real_wnn_circuit_small_k15_verifies(ctx, zg, orc):
     got = prover.prove(adv, inst, 5)
     assert orc.verify_proof_pairing(pk, inst, got) == 1
     prover.close()
+
+
+def test_real_wnn_circuit_medium_k15_verifies(ctx, zg, orc):
+    """model_28input_2048entry_2hash_3bpi (BASELINE configs[3], k = 15; the layout fills 32 738 of the 32 762
+    usable rows): GPU proof in the throughput configuration, pairing verifier."""
+    import wnn_model
+
+    orc.load().orc_set_threads(16)
+    cs, asg, ilen, scores, pk, prover = _real_model(orc, zg, ctx, wnn_model.MNIST_MEDIUM)
+    assert scores == [29, 21, 40, 47, 45, 41, 28, 82, 35, 66]
+    prover.set_overlap(False)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    got = prover.prove(adv, inst, 11)
+    prover.set_overlap(True)
+    assert prover.prove(adv, inst, 11) == got
+    assert orc.verify_proof_pairing(pk, inst, got) == 1
+    prover.close()
