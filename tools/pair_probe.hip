@@ -1,4 +1,4 @@
-// Debug probe: two-lane addition (field9.h xadd<true>) against the one-lane xyzz9_add on the same inputs.
+// Probe: two-lane addition (field9.h xadd<true>) against the one-lane xyzz9_add on the same inputs.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "curve.h"
@@ -27,17 +27,6 @@ __global__ void probe(uint32_t* bad, XYZZ* outp, XYZZ* outs, int mode) {
     }
     __syncthreads();
     XSum s = xadd<true>(&sa[j], &sb[j], role);
-    if (mode == 0 && j == 1) {
-        // reference pieces
-        XYZZ9 a = sa[j], b = sb[j];
-        F9 u1 = Fq9::mul(a.x, b.zz), u2 = Fq9::mul(b.x, a.zz), s1 = Fq9::mul(a.y, b.zzz), s2 = Fq9::mul(b.y, a.zzz);
-        F9 p = f9_sub(u2, u1), r = f9_sub(s2, s1), pp = Fq9::sqr(p), ppp = Fq9::mul(p, pp), qq = Fq9::mul(u1, pp);
-        F9 x3 = f9_norm(f9_sub(f9_sub(f9_sub(Fq9::sqr(r), ppp), qq), qq));
-        F9 t = Fq9::mul(r, f9_sub(qq, x3)), w = Fq9::mul(s1, ppp);
-        printf("role %u: ref t0=%d w0=%d x30=%d | got y0=%d zz0=%d zzz0=%d x0=%d\n", role, t.l[0], w.l[0], x3.l[0], s.r.y.l[0], s.r.zz.l[0], s.r.zzz.l[0], s.r.x.l[0]);
-        F9 yy = f9_norm(f9_sub(t, w));
-        printf("role %u: ref y0=%d\n", role, yy.l[0]);
-    }
     xstore<true>(&sd[j], s);
     __syncthreads();
     if (role == 0) {
