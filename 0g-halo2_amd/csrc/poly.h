@@ -61,6 +61,11 @@ struct EvalHArgs {
     // coefficients in monos_hat; h comes out in that form too (extended_to_coeff_dev(unhat) undoes it)
     bool hat;
     const DMono* monos_hat;
+    // gates with a cell common to all their monomials (zero_g's are selector * (...)) are given factored:
+    // gates_hat[g] ranges over monos_hat entries with that cell removed, gate_common[g] is its query index
+    // (0xffffffff: not factored, gates_hat[g] is the plain polynomial)
+    const zg_poly* gates_hat;
+    const uint32_t* gate_common;
 };
 
 // blinding scalar = f(seed, tag, index); identical to the oracle's definition

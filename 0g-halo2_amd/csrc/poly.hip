@@ -532,7 +532,20 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     F9 value;
 #pragma unroll
     for (int i = 0; i < 9; i++) value.l[i] = 0;
-    for (uint32_t g = 0; g < c.n_gates; g++) value = fold(value, eval_poly9(c, a.monos_hat, a.cols, c.gates[g], idx));
+    auto cell = [&](uint32_t qi) {
+        const zg_query q = c.queries[qi];
+        const Fe* base = q.kind == ZG_FIXED ? a.cols.fixed : q.kind == ZG_ADVICE ? a.cols.advice : a.cols.instance;
+        return ld9(base + ((size_t)q.column << a.cols.log_size) + ((idx + (uint32_t)(q.rotation * a.cols.rot_scale)) & mask));
+    };
+    for (uint32_t g = 0; g < c.n_gates; g++) {
+        const F9 inner = eval_poly9(c, a.monos_hat, a.cols, a.gates_hat[g], idx);
+        const uint32_t common = a.gate_common[g];  // (wave-uniform)
+        if (common != 0xffffffffu) {
+            value = fold2(f9_norm(value), cell(common), inner);  // value * y + common * inner, one reduction
+        } else {
+            value = fold(value, inner);
+        }
+    }
     value = f9_norm(value);  // from here on every term is a product: fold2 keeps value normalised
 
     auto l0 = [&]() { return ld9(a.l0 + idx); };
@@ -608,6 +621,8 @@ int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en) {
     double arrays = 3.0 + c.n_perm + c.n_sets + 3.0 * c.n_lookups + 1.0;  // l-polys, sigma, z's, lookup polys, h
     ZG_REQUIRE(!a.hat || a.monos_hat != nullptr || (c.n_gates == 0 && c.n_lookups == 0), ZG_ERR_INVALID_ARG,
                "evaluate_h: the 2^261-form monomial table is missing");
+    ZG_REQUIRE(!a.hat || c.n_gates == 0 || (a.gates_hat != nullptr && a.gate_common != nullptr), ZG_ERR_INVALID_ARG,
+               "evaluate_h: the factored gate table is missing");
     if (a.hat)
         ZG_LAUNCH(ctx, "evaluate_h", arrays * en * 32.0, evaluate_h9_kernel, dim3((en + 255) / 256), dim3(256), 0, a, en);
     else

@@ -92,6 +92,8 @@ struct zg_prover {
     // reads are kept in the 2^261 Montgomery form (x * 2^5 of the library form); ZG_EVALH9=0 turns it off
     bool hat = true;
     DMono* monos_hat = nullptr;
+    zg_poly* gates_hat = nullptr;
+    uint32_t* gate_common = nullptr;
     bool own_bases = true;  // false: tables shared with other provers of the same device
     Fe vk_repr{};
     Fe omega{}, omega_inv{}, ifft_div{};
@@ -329,11 +331,51 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     p->dc.queries = d_q; p->dc.monos = d_m; p->dc.gates = d_g; p->dc.lookups = d_l; p->dc.perm_cols = d_pc;
     p->dc.n_gates = cs->n_gates; p->dc.n_lookups = cs->n_lookups; p->dc.n_perm = p->P; p->dc.chunk = p->chunk;
     p->dc.n_sets = p->sets;
-    if (p->hat && cs->n_monomials) {  // the same monomials with coefficients in the 2^261 form, for evaluate_h
+    if (p->hat) {  // evaluate_h's view: coefficients in the 2^261 form, gates factored by their common cell
         const Fe c261 = Fr9Params::c261_fe();
         for (auto& d : monos) d.coeff = Fr::mul(d.coeff, c261);
-        ZG_TRY(dalloc(p, &p->monos_hat, cs->n_monomials));
-        ZG_HIP(hipMemcpy(p->monos_hat, monos.data(), monos.size() * sizeof(DMono), hipMemcpyHostToDevice));
+        std::vector<zg_poly> gates_hat(cs->n_gates);
+        std::vector<uint32_t> common(cs->n_gates, 0xffffffffu);
+        for (uint32_t gi = 0; gi < cs->n_gates; gi++) {
+            const zg_poly g = cs->gates[gi];
+            gates_hat[gi] = g;
+            if (g.count < 2) continue;
+            // a query index present in every monomial of the gate (the selector, for zero_g's gates)
+            uint32_t f = 0xffffffffu;
+            const DMono& first = monos[g.first];
+            for (uint32_t a = 0; a < first.n_factors && f == 0xffffffffu; a++) {
+                bool all = true;
+                for (uint32_t m = g.first; m < g.first + g.count && all; m++) {
+                    bool has = false;
+                    for (uint32_t b = 0; b < monos[m].n_factors; b++) has |= monos[m].factors[b] == first.factors[a];
+                    all = has;
+                }
+                if (all) f = first.factors[a];
+            }
+            if (f == 0xffffffffu) continue;
+            gates_hat[gi].first = (uint32_t)monos.size();
+            for (uint32_t m = g.first; m < g.first + g.count; m++) {
+                DMono d = monos[m];
+                uint32_t w = 0;
+                bool dropped = false;
+                for (uint32_t b = 0; b < monos[m].n_factors; b++) {
+                    if (!dropped && monos[m].factors[b] == f) { dropped = true; continue; }
+                    d.factors[w++] = monos[m].factors[b];
+                }
+                for (uint32_t b = w; b < ZG_MAX_FACTORS; b++) d.factors[b] = 0;
+                d.n_factors = w;
+                monos.push_back(d);
+            }
+            common[gi] = f;
+        }
+        ZG_TRY(dalloc(p, &p->monos_hat, monos.size() ? monos.size() : 1));
+        ZG_TRY(dalloc(p, &p->gates_hat, cs->n_gates ? cs->n_gates : 1));
+        ZG_TRY(dalloc(p, &p->gate_common, cs->n_gates ? cs->n_gates : 1));
+        if (!monos.empty()) ZG_HIP(hipMemcpy(p->monos_hat, monos.data(), monos.size() * sizeof(DMono), hipMemcpyHostToDevice));
+        if (cs->n_gates) {
+            ZG_HIP(hipMemcpy(p->gates_hat, gates_hat.data(), cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice));
+            ZG_HIP(hipMemcpy(p->gate_common, common.data(), cs->n_gates * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
 
     // ---- SRS: upload + window tables, or tables shared with other provers on this device (read-only)
@@ -652,6 +694,8 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         a.delta_start = Fr::mul(beta, fr_zeta()); a.delta = fr_delta();
         a.hat = p->hat;
         a.monos_hat = p->monos_hat;
+        a.gates_hat = p->gates_hat;
+        a.gate_common = p->gate_common;
         if (p->hat) {
             const Fe c261 = Fr9Params::c261_fe();
             for (Fe* cst : {&a.y, &a.beta, &a.gamma, &a.theta, &a.delta_start, &a.delta}) *cst = Fr::mul(*cst, c261);
