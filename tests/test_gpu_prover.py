@@ -257,3 +257,26 @@ def test_real_wnn_circuit_medium_k15_verifies(ctx, zg, orc):
     assert prover.prove(adv, inst, 11) == got
     assert orc.verify_proof_pairing(pk, inst, got) == 1
     prover.close()
+
+
+def test_large_shape_k17_verifies(ctx, zg, orc):
+    """The k = 17 configuration (BASELINE configs[4]; seeded stand-in for the absent 49-input model): 2^17 rows,
+    2^20-point extended domain -- GPU proof, pairing verifier."""
+    import wnn_circuit
+    import wnn_model
+
+    orc.load().orc_set_threads(16)
+    k = wnn_model.MNIST_LARGE[0]
+    wnn = wnn_model.synthetic_wnn()
+    cs, asg, ilen, scores = wnn_circuit.build(wnn, wnn_model.load_test_image(), k)
+    assert scores == wnn.predict(wnn_model.load_test_image())
+    img = cs.to_c()
+    params = orc.params_new(k, 0x5EED)
+    vk_repr = orc.fr_from_int(0xC0FFEE)
+    fixed, sigma = asg.fixed_values(), asg.sigma_values()
+    prover = zg.Prover(ctx, img, fixed, sigma, params.g_np(), params.g_lagrange_np(), vk_repr)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    proof = prover.prove(adv, inst, 3)
+    prover.close()
+    pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
+    assert orc.verify_proof_pairing(pk, inst, proof) == 1
