@@ -230,7 +230,7 @@ def test_real_wnn_circuit_tiny_proof_bytes_match_oracle(ctx, zg, orc):
 
 
 def test_real_wnn_circuit_small_k15_verifies(ctx, zg, orc):
-    """model_28input_1024entry_2hash_2bpi (BASELINE configs[2], k = 15): GPU proof, pairing verifier."""
+    """model_28input_1024entry_2hash_2bpi (BASELINE configs[2], k = 15): GPU proof bytes == oracle, pairing verifier."""
     import wnn_model
 
     orc.load().orc_set_threads(16)
@@ -238,6 +238,8 @@ def test_real_wnn_circuit_small_k15_verifies(ctx, zg, orc):
     assert scores == [17, 13, 25, 27, 29, 21, 15, 55, 27, 32]
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
     got = prover.prove(adv, inst, 5)
+    st, want, _ = orc.create_proof(pk, adv, inst, 5)
+    assert st == 0 and got == want  # byte parity at k = 15 as well
     assert orc.verify_proof_pairing(pk, inst, got) == 1
     prover.close()
 
