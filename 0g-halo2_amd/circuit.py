@@ -22,7 +22,7 @@ ROOT_OF_UNITY = pow(7, (R - 1) >> 28, R)
 
 FIXED, ADVICE, INSTANCE = 0, 1, 2
 MAX_FACTORS, MAX_LOOKUP_WIDTH = 8, 4
-SELECTOR_BASE = 1 << 20   # provisional column ids / query indices of selectors before finalize_selectors()
+SELECTOR_BASE = 1 << 20   # provisional query indices of selectors before compress_selectors()
 
 
 def omega_for(k: int) -> int:
@@ -148,39 +148,116 @@ class ConstraintSystem:
     fixed_queries: list = field(default_factory=list)
     instance_queries: list = field(default_factory=list)
     n_selectors: int = 0
-    selector_columns: list = field(default_factory=list)  # selector id -> fixed column (after finalize_selectors)
+    selector_simple: list = field(default_factory=list)   # selector id -> created by selector() (True) / complex_selector()
+    selector_assignment: list = field(default_factory=list)  # after compress_selectors: id -> (fixed column, value when enabled)
 
-    # ---- selectors (circuit.rs `selector` / `complex_selector`).  halo2 keeps selectors virtual until keygen,
-    # where `compress_selectors` turns them into fixed columns appended AFTER the circuit's own fixed
-    # columns, with their cell queries appended after every other query.  finalize_selectors() does the
-    # same, one fixed column per selector (i.e. without halo2's optional merging of simple selectors).
+    # ---- selectors (circuit.rs `selector` / `complex_selector`).  halo2 keeps selectors virtual until keygen:
+    # synthesis records on which rows each is enabled, then `ConstraintSystem::compress_selectors`
+    # (circuit.rs + circuit/compress_selectors.rs) turns them into fixed columns appended AFTER the
+    # circuit's own fixed columns, their cell queries after every other query, and substitutes them in
+    # the gates and lookups.  compress_selectors() below restates that.
     def selector(self) -> int:
         self.n_selectors += 1
+        self.selector_simple.append(True)
         return self.n_selectors - 1
 
-    complex_selector = selector
+    def complex_selector(self) -> int:
+        self.n_selectors += 1
+        self.selector_simple.append(False)
+        return self.n_selectors - 1
 
     def query_selector(self, s: int) -> "Expr":
-        assert not self.selector_columns, "selectors already finalized"
+        assert not self.selector_assignment, "selectors already compressed"
         return Expr({(SELECTOR_BASE + s,): 1})
 
-    def finalize_selectors(self):
-        assert not self.selector_columns
-        self.selector_columns = [self.fixed_column() for _ in range(self.n_selectors)]
-        used = set()
-        for e in self.gates + [x for ins, tabs in self.lookups for x in ins + tabs]:
-            for key in e.terms:
-                used.update(qi - SELECTOR_BASE for qi in key if qi >= SELECTOR_BASE)
-        remap = {}
-        for s in sorted(used):
-            self.q(FIXED, self.selector_columns[s], 0)
-            remap[SELECTOR_BASE + s] = self.queries.index((FIXED, self.selector_columns[s], 0))
+    def _exprs(self):
+        return self.gates + [x for ins, tabs in self.lookups for x in ins + tabs]
+
+    def compress_selectors(self, activations, merge: bool = True):
+        """activations[s] = set of rows selector s is enabled on.  -> list of new fixed columns' values
+        (each a list of n ints), in the order their columns were allocated.
+
+        compress_selectors.rs `process`: a selector that is complex or appears in no gate keeps a column
+        of its own (0/1), allocated first, in selector order.  The simple ones are merged greedily, in
+        selector order: selector j joins the combination opened by selector i when it is never enabled
+        on a row where a member already is, and max(member gate degree - 1) + members <= cs.degree().  A
+        combination of m selectors is ONE column holding t on the rows where its t-th member is enabled
+        (t = 1..m, 0 elsewhere), and member t is replaced by  q * prod_{u != t} (u - q).
+        merge=False gives every selector its own column (halo2 with compress_selectors disabled)."""
+        assert not self.selector_assignment and len(activations) == self.n_selectors
+        n = 1 << self.k
+        max_degree = self.degree()
+        degrees = [0] * self.n_selectors
+        if merge:
+            for g in self.gates:  # extract_simple_selector: a gate polynomial mentions at most one
+                simple = {qi - SELECTOR_BASE for key in g.terms for qi in key
+                          if qi >= SELECTOR_BASE and self.selector_simple[qi - SELECTOR_BASE]}
+                assert len(simple) <= 1, "two simple selectors cannot be in the same expression"
+                for sel in simple:
+                    degrees[sel] = max(degrees[sel], g.degree())
+            for e in [x for ins, tabs in self.lookups for x in ins + tabs]:
+                assert not any(qi >= SELECTOR_BASE and self.selector_simple[qi - SELECTOR_BASE]
+                               for key in e.terms for qi in key), "simple selector in a lookup argument"
+        columns, subst = [], {}
+        self.selector_assignment = [None] * self.n_selectors
+
+        def allocate():
+            col = self.fixed_column()
+            return col, self.q(FIXED, col, 0)
+
+        for s in range(self.n_selectors):
+            if degrees[s] == 0:
+                col, q = allocate()
+                subst[SELECTOR_BASE + s] = q
+                self.selector_assignment[s] = (col, 1)
+                columns.append([1 if r in activations[s] else 0 for r in range(n)])
+        rest = [s for s in range(self.n_selectors) if degrees[s] > 0]
+        added = set()
+        for i, s in enumerate(rest):
+            if s in added:
+                continue
+            added.add(s)
+            assert degrees[s] <= max_degree
+            d, combination = degrees[s] - 1, [s]
+            for t in rest[i + 1:]:
+                if d + len(combination) == max_degree:
+                    break
+                if t in added or any(activations[t] & activations[u] for u in combination):
+                    continue
+                new_d = max(d, degrees[t] - 1)
+                if new_d + len(combination) + 1 > max_degree:
+                    continue
+                d = new_d
+                combination.append(t)
+                added.add(t)
+            col, q = allocate()
+            values = [0] * n
+            for root, member in enumerate(combination, start=1):
+                e = q
+                for u in range(1, len(combination) + 1):
+                    if u != root:
+                        e = e * (Expr.const(u) - q)
+                subst[SELECTOR_BASE + member] = e
+                self.selector_assignment[member] = (col, root)
+                for r in activations[member]:
+                    values[r] = root
+            columns.append(values)
 
         def fix(e: "Expr") -> "Expr":
-            return Expr({tuple(sorted(remap.get(qi, qi) for qi in key)): v for key, v in e.terms.items()})
+            out = Expr()
+            for key, v in e.terms.items():
+                m = Expr({tuple(qi for qi in key if qi < SELECTOR_BASE): v})
+                for qi in key:
+                    if qi >= SELECTOR_BASE:
+                        m = m * subst[qi]
+                out = out + m
+            return out
 
         self.gates = [fix(g) for g in self.gates]
         self.lookups = [([fix(e) for e in ins], [fix(e) for e in tabs]) for ins, tabs in self.lookups]
+        for g in self.gates:
+            assert g.degree() <= MAX_FACTORS
+        return columns
 
     # ---- columns
     def fixed_column(self) -> int:
@@ -328,11 +405,26 @@ class Assignment:
         self.fixed = [[0] * self.n for _ in range(cs.n_fixed)]
         self.advice = [[0] * self.n for _ in range(cs.n_advice)]
         self.instance = [[0] * self.n for _ in range(cs.n_instance)]
+        self.selectors = [set() for _ in range(cs.n_selectors)]  # rows each (virtual) selector is enabled on
         m = len(cs.perm_columns)
         # cycle representation as in halo2: mapping[col][row] = next cell of the cycle
         self.mapping = [[(c, r) for r in range(self.n)] for c in range(m)]
         self.aux = [[(c, r) for r in range(self.n)] for c in range(m)]
         self.sizes = [[1] * self.n for _ in range(m)]
+
+    def compress_selectors(self, merge: bool = True):
+        """keygen's step after synthesis: selectors -> fixed columns (appended), gates / lookups rewritten.
+        On a constraint system that is already compressed (a second synthesis of the same circuit) only
+        the columns are rebuilt, from cs.selector_assignment."""
+        cs = self.cs
+        if not cs.selector_assignment:
+            self.fixed.extend(cs.compress_selectors(self.selectors, merge))
+            return
+        assert len(self.fixed) == cs.n_fixed
+        for s, (col, value) in enumerate(cs.selector_assignment):
+            for r in self.selectors[s]:
+                assert self.fixed[col][r] == 0, "selectors of one combination enabled on the same row"
+                self.fixed[col][r] = value
 
     def col(self, kind):
         return {FIXED: self.fixed, ADVICE: self.advice, INSTANCE: self.instance}[kind]

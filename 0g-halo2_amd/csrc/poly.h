@@ -66,6 +66,14 @@ struct EvalHArgs {
     // (0xffffffff: not factored, gates_hat[g] is the plain polynomial)
     const zg_poly* gates_hat;
     const uint32_t* gate_common;
+    // the factor may be a polynomial in that cell (halo2's merged selectors: q * prod (u - q)):
+    // gate g = U(cell) * gates_hat[g], U(x) = sum_{k=1..count} uni_coef[first + k - 1] x^k; count 0: U(x) = x
+    const zg_poly* gate_uni;
+    const Fe* uni_coef;
+    // ... and when that cell is a fixed one, U(cell) is tabulated over the extended domain by poly_gate_factor:
+    // gate_slab[g] = index of the gate's slab (en entries) in gate_slabs, 0xffffffff: evaluate U in the kernel
+    const uint32_t* gate_slab;
+    const Fe* gate_slabs;
 };
 
 // blinding scalar = f(seed, tag, index); identical to the oracle's definition
@@ -98,6 +106,8 @@ size_t poly_grand_product_tmp_elems(uint32_t n, uint32_t batch);
 int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
                        uint32_t batch, uint32_t chain, uint32_t last);
 int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en);
+// out[i] = U(col[(i + rot_off) mod en]),  U(x) = sum_{k=1..count} coef[k-1] x^k; everything in the 2^261 form
+int poly_gate_factor(zg_ctx* ctx, const Fe* col, uint32_t rot_off, uint32_t en, const Fe* coef, uint32_t count, Fe* out);
 int poly_powers(zg_ctx* ctx, const Fe* points_host, uint32_t npoints, uint32_t n, Fe* d_pow);
 int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint32_t* d_poly_idx,
              const uint32_t* d_point_idx, const Fe* d_pow, uint32_t count, Fe* d_out);

@@ -514,6 +514,28 @@ __device__ __forceinline__ F9 eval_poly9(const DevCircuit& c, const DMono* monos
     return f9_norm(acc);
 }
 
+// U(x) = x * (c_1 + x * (c_2 + ... )) for wave-uniform coefficients c_k = coef[k-1], k = 1..count
+__device__ __forceinline__ F9 horner9(const F9& x, const Fe* coef, uint32_t count) {
+    F9 u = f9_unpack(coef[count - 1]);
+    for (uint32_t k = count - 1; k >= 1; k--) u = f9_add(Fr9::mul(u, x), f9_unpack(coef[k - 1]));
+    return Fr9::mul(u, x);
+}
+
+__global__ __launch_bounds__(256) void gate_factor9_kernel(const Fe* __restrict__ col, uint32_t rot_off, uint32_t en,
+                                                           const Fe* __restrict__ coef, uint32_t count, Fe* __restrict__ out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= en) return;
+    stg(out + idx, f9_reduce_pack<Fr9Params>(horner9(ld9(col + ((idx + rot_off) & (en - 1))), coef, count)));
+}
+
+int poly_gate_factor(zg_ctx* ctx, const Fe* col, uint32_t rot_off, uint32_t en, const Fe* coef, uint32_t count, Fe* out) {
+    ZG_REQUIRE(count >= 1 && (en & (en - 1)) == 0, ZG_ERR_INVALID_ARG, "poly_gate_factor: %u coefficients, %u points", count, en);
+    ZG_LAUNCH(ctx, "gate_factor", 2.0 * en * 32.0, gate_factor9_kernel, dim3((en + 255) / 256), dim3(256), 0, col, rot_off, en, coef,
+              count, out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t en) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= en) return;
@@ -541,7 +563,17 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
         const F9 inner = eval_poly9(c, a.monos_hat, a.cols, a.gates_hat[g], idx);
         const uint32_t common = a.gate_common[g];  // (wave-uniform)
         if (common != 0xffffffffu) {
-            value = fold2(f9_norm(value), cell(common), inner);  // value * y + common * inner, one reduction
+            const uint32_t slab = a.gate_slab[g];
+            const zg_poly uni = a.gate_uni[g];
+            F9 u;
+            if (slab != 0xffffffffu) {
+                u = ld9(a.gate_slabs + (size_t)slab * en + idx);  // U(fixed cell), tabulated with the proving key
+            } else if (uni.count) {
+                u = horner9(cell(common), a.uni_coef + uni.first, uni.count);
+            } else {
+                u = cell(common);
+            }
+            value = fold2(f9_norm(value), u, inner);  // value * y + U(common) * inner, one reduction
         } else {
             value = fold(value, inner);
         }
@@ -621,7 +653,7 @@ int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en) {
     double arrays = 3.0 + c.n_perm + c.n_sets + 3.0 * c.n_lookups + 1.0;  // l-polys, sigma, z's, lookup polys, h
     ZG_REQUIRE(!a.hat || a.monos_hat != nullptr || (c.n_gates == 0 && c.n_lookups == 0), ZG_ERR_INVALID_ARG,
                "evaluate_h: the 2^261-form monomial table is missing");
-    ZG_REQUIRE(!a.hat || c.n_gates == 0 || (a.gates_hat != nullptr && a.gate_common != nullptr), ZG_ERR_INVALID_ARG,
+    ZG_REQUIRE(!a.hat || c.n_gates == 0 || (a.gates_hat != nullptr && a.gate_common != nullptr && a.gate_uni != nullptr && a.uni_coef != nullptr && a.gate_slab != nullptr && a.gate_slabs != nullptr), ZG_ERR_INVALID_ARG,
                "evaluate_h: the factored gate table is missing");
     if (a.hat)
         ZG_LAUNCH(ctx, "evaluate_h", arrays * en * 32.0, evaluate_h9_kernel, dim3((en + 255) / 256), dim3(256), 0, a, en);

@@ -94,6 +94,12 @@ struct zg_prover {
     DMono* monos_hat = nullptr;
     zg_poly* gates_hat = nullptr;
     uint32_t* gate_common = nullptr;
+    zg_poly* gate_uni = nullptr;
+    Fe* uni_coef = nullptr;
+    uint32_t* gate_slab = nullptr;  // per gate: index of its U(fixed cell) coset in gate_slabs, or 0xffffffff
+    Fe* gate_slabs = nullptr;
+    struct SlabJob { uint32_t gate, query, first, count; };
+    std::vector<SlabJob> slab_jobs;  // filled when the gates are factored, run once the fixed cosets exist
     bool own_bases = true;  // false: tables shared with other provers of the same device
     Fe vk_repr{};
     Fe omega{}, omega_inv{}, ifft_div{};
@@ -184,6 +190,93 @@ int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
     out.resize(count);
     xyzz_batch_normalise((const XYZZ*)((char*)p->pinned + PIN_RESULTS), count, reinterpret_cast<zg_g1*>(out.data()));
     return ZG_OK;
+}
+
+
+// ---- evaluate_h's view of one gate: gate = U(cell f) * inner, f a query index present in every monomial.
+// U(x) = x when f occurs exactly once per monomial (uc empty); otherwise the monomials are grouped by the
+// power of f and, when every group is a scalar multiple of the lowest one, U(x) = sum_k uc[k-1] x^k --
+// the shape halo2's selector compression leaves behind (selector -> q * prod_{u != t} (u - q)).  Failing
+// that, one occurrence of f is split off and the rest stays expanded.  Coefficients are in the 2^261 form.
+struct GateFactor {
+    std::vector<DMono> inner;
+    std::vector<Fe> uc;
+    uint32_t cost = 0;  // field products per row
+};
+
+GateFactor factor_gate(const std::vector<DMono>& monos, zg_poly g, uint32_t f, const Fe& c261, bool tabulated) {
+    auto strip = [&](const DMono& src, bool all) {  // src without one / every occurrence of f
+        DMono d = src;
+        uint32_t w = 0;
+        bool dropped = false;
+        for (uint32_t b = 0; b < src.n_factors; b++) {
+            if (src.factors[b] == f && (all || !dropped)) { dropped = true; continue; }
+            d.factors[w++] = src.factors[b];
+        }
+        for (uint32_t b = w; b < ZG_MAX_FACTORS; b++) d.factors[b] = 0;
+        d.n_factors = w;
+        return d;
+    };
+    auto power = [&](const DMono& d) { return (uint32_t)std::count(d.factors, d.factors + d.n_factors, f); };
+    auto same_cells = [](const DMono& x, const DMono& y) {
+        return x.n_factors == y.n_factors && std::equal(x.factors, x.factors + x.n_factors, y.factors);
+    };
+    auto cell_order = [](const DMono& x, const DMono& y) {
+        return std::lexicographical_compare(x.factors, x.factors + x.n_factors, y.factors, y.factors + y.n_factors);
+    };
+    uint32_t pmin = ZG_MAX_FACTORS + 1, pmax = 0;
+    for (uint32_t m = g.first; m < g.first + g.count; m++) {
+        pmin = std::min(pmin, power(monos[m]));
+        pmax = std::max(pmax, power(monos[m]));
+    }
+    GateFactor out;
+    bool univariate = pmax > 1;
+    if (univariate) {
+        std::vector<std::vector<DMono>> by_power(pmax + 1);
+        for (uint32_t m = g.first; m < g.first + g.count; m++) by_power[power(monos[m])].push_back(strip(monos[m], true));
+        for (auto& grp : by_power) std::sort(grp.begin(), grp.end(), cell_order);
+        std::vector<DMono>& base = by_power[pmin];
+        const Fe b0_inv = Fr::inv(base[0].coeff);
+        out.uc.assign(pmax, Fe{});
+        out.uc[pmin - 1] = Fr::mul(Fr::one(), c261);
+        for (uint32_t k = pmin + 1; k <= pmax && univariate; k++) {
+            const auto& grp = by_power[k];
+            if (grp.empty()) continue;
+            univariate = grp.size() == base.size();
+            for (size_t i = 0; i < grp.size() && univariate; i++)  // grp = ratio * base, term by term
+                univariate = same_cells(grp[i], base[i]) &&
+                             fe_eq(Fr::mul(grp[i].coeff, base[0].coeff), Fr::mul(grp[0].coeff, base[i].coeff));
+            if (univariate) out.uc[k - 1] = Fr::mul(Fr::mul(grp[0].coeff, b0_inv), c261);
+        }
+        if (univariate) {
+            // U * B = (d U) * (B / d) with d the most frequent coefficient of B: those monomials become
+            // coefficient-free products again, as they were before the selector was substituted
+            size_t best = 0, best_n = 0;
+            for (size_t i = 0; i < base.size(); i++) {
+                size_t cnt = 0;
+                for (const DMono& o : base) cnt += fe_eq(o.coeff, base[i].coeff);
+                if (cnt > best_n) best = i, best_n = cnt;
+            }
+            const Fe d = base[best].coeff, d_inv = Fr::inv(d);
+            const Fe one_hat = Fr::mul(Fr::one(), c261);
+            for (DMono& o : base) {
+                o.coeff = Fr::mul(Fr::mul(o.coeff, d_inv), c261);  // (o / d) back in the 2^261 form
+                o.coeff_is_one = fe_eq(o.coeff, one_hat) ? 1 : 0;
+            }
+            for (Fe& u : out.uc) u = Fr::mul(u, Fr::mul(d, Fr::inv(c261)));  // (d carries the 2^261 factor already)
+            out.inner = std::move(base);
+        }
+    }
+    if (!univariate) {
+        out.uc.clear();
+        for (uint32_t m = g.first; m < g.first + g.count; m++) out.inner.push_back(strip(monos[m], false));
+    }
+    for (const DMono& d : out.inner) {
+        const uint32_t operands = d.n_factors + (d.coeff_is_one && d.n_factors ? 0u : 1u);
+        out.cost += operands ? operands - 1 : 0;
+    }
+    if (!out.uc.empty() && !tabulated) out.cost += (uint32_t)out.uc.size();  // Horner in the kernel
+    return out;
 }
 
 }  // namespace
@@ -336,38 +429,44 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         for (auto& d : monos) d.coeff = Fr::mul(d.coeff, c261);
         std::vector<zg_poly> gates_hat(cs->n_gates);
         std::vector<uint32_t> common(cs->n_gates, 0xffffffffu);
+        std::vector<zg_poly> gate_uni(cs->n_gates, zg_poly{0, 0});  // count 0: the factor is the cell itself
+        std::vector<Fe> uni_coef;
         for (uint32_t gi = 0; gi < cs->n_gates; gi++) {
             const zg_poly g = cs->gates[gi];
             gates_hat[gi] = g;
             if (g.count < 2) continue;
-            // a query index present in every monomial of the gate (the selector, for zero_g's gates)
+            // Every query index present in all monomials of the gate is a candidate factor (q * (b^2 - b) has
+            // two); the cheapest evaluation wins.  zero_g's gates are selector * (...), and a selector halo2
+            // merged with others is a polynomial in its column: that one is tabulated with the proving key.
+            GateFactor best;
             uint32_t f = 0xffffffffu;
             const DMono& first = monos[g.first];
-            for (uint32_t a = 0; a < first.n_factors && f == 0xffffffffu; a++) {
+            for (uint32_t a = 0; a < first.n_factors; a++) {
+                const uint32_t cand = first.factors[a];
+                if (a && cand == first.factors[a - 1]) continue;
                 bool all = true;
-                for (uint32_t m = g.first; m < g.first + g.count && all; m++) {
-                    bool has = false;
-                    for (uint32_t b = 0; b < monos[m].n_factors; b++) has |= monos[m].factors[b] == first.factors[a];
-                    all = has;
-                }
-                if (all) f = first.factors[a];
+                for (uint32_t m = g.first; m < g.first + g.count && all; m++)
+                    all = std::find(monos[m].factors, monos[m].factors + monos[m].n_factors, cand) != monos[m].factors + monos[m].n_factors;
+                if (!all) continue;
+                GateFactor opt = factor_gate(monos, g, cand, c261, cs->queries[cand].kind == ZG_FIXED);
+                if (f == 0xffffffffu || opt.cost < best.cost) best = std::move(opt), f = cand;
             }
             if (f == 0xffffffffu) continue;
             gates_hat[gi].first = (uint32_t)monos.size();
-            for (uint32_t m = g.first; m < g.first + g.count; m++) {
-                DMono d = monos[m];
-                uint32_t w = 0;
-                bool dropped = false;
-                for (uint32_t b = 0; b < monos[m].n_factors; b++) {
-                    if (!dropped && monos[m].factors[b] == f) { dropped = true; continue; }
-                    d.factors[w++] = monos[m].factors[b];
-                }
-                for (uint32_t b = w; b < ZG_MAX_FACTORS; b++) d.factors[b] = 0;
-                d.n_factors = w;
-                monos.push_back(d);
+            gates_hat[gi].count = (uint32_t)best.inner.size();
+            monos.insert(monos.end(), best.inner.begin(), best.inner.end());
+            if (!best.uc.empty()) {
+                gate_uni[gi].first = (uint32_t)uni_coef.size();
+                gate_uni[gi].count = (uint32_t)best.uc.size();
+                if (cs->queries[f].kind == ZG_FIXED) p->slab_jobs.push_back({gi, f, gate_uni[gi].first, gate_uni[gi].count});
+                uni_coef.insert(uni_coef.end(), best.uc.begin(), best.uc.end());
             }
             common[gi] = f;
         }
+        ZG_TRY(dalloc(p, &p->gate_uni, cs->n_gates ? cs->n_gates : 1));
+        ZG_TRY(dalloc(p, &p->uni_coef, uni_coef.size() ? uni_coef.size() : 1));
+        if (cs->n_gates) ZG_HIP(hipMemcpy(p->gate_uni, gate_uni.data(), cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice));
+        if (!uni_coef.empty()) ZG_HIP(hipMemcpy(p->uni_coef, uni_coef.data(), uni_coef.size() * sizeof(Fe), hipMemcpyHostToDevice));
         ZG_TRY(dalloc(p, &p->monos_hat, monos.size() ? monos.size() : 1));
         ZG_TRY(dalloc(p, &p->gates_hat, cs->n_gates ? cs->n_gates : 1));
         ZG_TRY(dalloc(p, &p->gate_common, cs->n_gates ? cs->n_gates : 1));
@@ -455,6 +554,22 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_HIP(hipMemcpyAsync(fp, p->fixed_val, (size_t)F * n * 32, hipMemcpyDeviceToDevice, st));
         ZG_TRY(ntt_batch_dev(ctx, fp, n, F, p->k, p->omega_inv, &p->ifft_div));
         ZG_TRY(coeff_to_extended_dev(ctx, fp, n, p->fixed_cos, en, F, p->k, p->ext_k, p->hat));
+    }
+    if (p->hat) {
+        // a gate factor that is a polynomial in a FIXED cell (a merged selector) does not depend on the
+        // witness: its coset is part of the proving key here, as the unmerged selector's would have been
+        std::vector<uint32_t> slab_of(cs->n_gates ? cs->n_gates : 1, 0xffffffffu);
+        ZG_TRY(dalloc(p, &p->gate_slab, slab_of.size()));
+        ZG_TRY(dalloc(p, &p->gate_slabs, std::max<size_t>(1, p->slab_jobs.size() * (size_t)en)));
+        for (size_t j = 0; j < p->slab_jobs.size(); j++) {
+            const auto& job = p->slab_jobs[j];
+            const zg_query q = cs->queries[job.query];
+            ZG_TRY(poly_gate_factor(ctx, p->fixed_cos + (size_t)q.column * en, (uint32_t)(q.rotation * (int32_t)(en / n)), en,
+                                    p->uni_coef + job.first, job.count, p->gate_slabs + j * (size_t)en));
+            slab_of[job.gate] = (uint32_t)j;
+        }
+        ZG_HIP(hipMemcpyAsync(p->gate_slab, slab_of.data(), slab_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        ZG_HIP(hipStreamSynchronize(st));
     }
     if (P) {
         ZG_HIP(hipMemcpyAsync(p->sigma_val, sigma_values, (size_t)P * n * 32, hipMemcpyHostToDevice, st));
@@ -696,6 +811,10 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         a.monos_hat = p->monos_hat;
         a.gates_hat = p->gates_hat;
         a.gate_common = p->gate_common;
+        a.gate_uni = p->gate_uni;
+        a.uni_coef = p->uni_coef;
+        a.gate_slab = p->gate_slab;
+        a.gate_slabs = p->gate_slabs;
         if (p->hat) {
             const Fe c261 = Fr9Params::c261_fe();
             for (Fe* cst : {&a.y, &a.beta, &a.gamma, &a.theta, &a.delta_start, &a.delta}) *cst = Fr::mul(*cst, c261);

@@ -66,7 +66,6 @@ class Region:
 
 class Layouter:
     def __init__(self, cs: ConstraintSystem, constants_column: int):
-        assert cs.selector_columns or cs.n_selectors == 0, "call cs.finalize_selectors() after configure"
         self.cs = cs
         self.asg = Assignment(cs)
         self.constants_column = constants_column
@@ -88,7 +87,7 @@ class Layouter:
         for c in region.cells:
             asg.set(ADVICE, c.column, c.row, c.value)
         for s, off in region.selectors:
-            asg.set(FIXED, self.cs.selector_columns[s], region.start + off, 1)
+            asg.selectors[s].add(region.start + off)
         for src, dst in region.copies:
             asg.copy(src.cell(), dst.cell())
         key = ("f", self.constants_column)

@@ -6,7 +6,9 @@ sigma columns keygen would derive, and the six advice columns -- so this is the 
 path, used to prove REAL inferences of the checked-in models in tests and bench.py.
 
 Known deviations from a real halo2 keygen of the same circuit (neither changes satisfiability):
-  * selectors become one fixed column each (halo2's `compress_selectors` may merge simple selectors);
+  * selector compression (`ConstraintSystem::compress_selectors`, run by keygen) is restated from its
+    published algorithm in circuit.py; the merged columns it yields for this circuit cannot be compared
+    with a real keygen here;
   * `LookupRangeCheckConfig` (halo2_gadgets v2023_04_20 utilities/lookup_range_check.rs) is not in the
     reference tree; it is restated from its published layout (K = 8, range_check.rs:10).
 """
@@ -600,8 +602,8 @@ class WnnChip:
 class WnnCircuit:
     """`WnnCircuit::configure_with_params` + `synthesize` (wnn.rs:334-393)."""
 
-    def __init__(self, wnn: Wnn, k: int):
-        self.wnn, self.k = wnn, k
+    def __init__(self, wnn: Wnn, k: int, compress_selectors: bool = True):
+        self.wnn, self.k, self.merge = wnn, k, compress_selectors
         self.params = wnn.get_circuit_params()
         cs = ConstraintSystem(k)
         self.instance_column = cs.instance_column()
@@ -612,7 +614,6 @@ class WnnCircuit:
         self.constants = cs.fixed_column()
         cs.enable_equality(FIXED, self.constants)  # enable_constant
         self.config = WnnChip.configure(cs, self.advice_columns, self.params)
-        cs.finalize_selectors()
         self.cs = cs
 
     def synthesize(self, image: np.ndarray):
@@ -626,11 +627,12 @@ class WnnCircuit:
         for i, score in enumerate(result):
             layouter.constrain_instance(score, self.instance_column, i, score.value)
         self.rows_used, self.n_regions = layouter.rows_used(), layouter.n_regions
+        layouter.asg.compress_selectors(self.merge)  # keygen_vk: cs.compress_selectors(assembly.selectors)
         return layouter.asg, [s.value for s in result]
 
 
-def build(wnn: Wnn, image: np.ndarray, k: int):
+def build(wnn: Wnn, image: np.ndarray, k: int, compress_selectors: bool = True):
     """-> (ConstraintSystem, Assignment, instance length, scores): what tests / bench.py feed the prover."""
-    circuit = WnnCircuit(wnn, k)
+    circuit = WnnCircuit(wnn, k, compress_selectors)
     asg, scores = circuit.synthesize(image)
     return circuit.cs, asg, len(scores), scores

@@ -72,7 +72,8 @@ class Circuit:
         wnn = wnn_model.synthetic_wnn() if model == "large" else wnn_model.load_checked_in(self.model_name)
         # zero_g's WnnCircuit for this model, synthesised on benches/example_image_7.png: the real
         # constraint system, fixed / sigma columns and witness (wnn_circuit.py restates WnnChip)
-        self.cs, self.asg, self.ilen, self.scores = wnn_circuit.build(wnn, wnn_model.load_test_image(), self.k)
+        self.cs, self.asg, self.ilen, self.scores = wnn_circuit.build(
+            wnn, wnn_model.load_test_image(), self.k, compress_selectors=os.environ.get("ZG_BENCH_NO_SELECTOR_COMPRESSION") != "1")
         k = self.k
         self.img = self.cs.to_c()
         self.fixed, self.sigma = self.asg.fixed_values(), self.asg.sigma_values()

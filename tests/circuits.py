@@ -79,6 +79,7 @@ def variant_circuit(kind: str, k: int = 5, seed: int = 3):
                      permutation products)
     "gates_only"     no lookup, no permutation, no instance column
     "wide_lookup"    one width-2 lookup ((a, b) in {(v, 3v+1)}), two instance columns, no gates
+    "advice_factor", "merged_selectors"   gates with a univariate polynomial factor (see below)
     """
     rng = random.Random(seed)
     cs = ConstraintSystem(k)
@@ -116,6 +117,54 @@ def variant_circuit(kind: str, k: int = 5, seed: int = 3):
             asg.set(FIXED, q, r, 1)
             asg.set(ADVICE, a0, r, v)
             asg.set(ADVICE, a1, r + 1, 7 - v)
+        return cs, asg, 0
+    if kind in ("advice_factor", "merged_selectors"):
+        # Gates of the shape U(cell) * B with U a univariate polynomial -- what halo2's selector compression
+        # produces.  "advice_factor": the cell is an advice cell (queried first, so that it is the common
+        # cell the prover factors by): a0 (1 - a0)(2 - a0) * q * (a1 - 9).  "merged_selectors": three simple
+        # selectors on disjoint rows, merged by compress_selectors into one fixed column.
+        a0, a1 = cs.advice_column(), cs.advice_column()
+        asg_rows = cs.usable_rows() - 1
+        if kind == "advice_factor":
+            x = cs.advice(a0)
+            q = cs.fixed_column()
+            cs.create_gate([x * (1 - x) * (2 - x) * cs.fixed(q) * (cs.advice(a1) - 9)])
+            asg = Assignment(cs)
+            for r in range(asg_rows):
+                asg.set(FIXED, q, r, 1)
+                free = rng.randrange(2)
+                asg.set(ADVICE, a0, r, rng.randrange(1 << 30) if free else rng.randrange(3))
+                asg.set(ADVICE, a1, r, 9 if free else rng.randrange(1 << 30))
+            return cs, asg, 0
+        sel = [cs.selector() for _ in range(3)]
+        cs.create_gate([cs.query_selector(sel[0]) * (cs.advice(a0) * cs.advice(a0) - cs.advice(a1)),
+                        cs.query_selector(sel[1]) * (cs.advice(a0) + cs.advice(a1, 1) - 7),
+                        cs.query_selector(sel[2]) * (cs.advice(a0) * cs.advice(a1) - 3 * cs.advice(a1, -1) + 1)])
+        # (a selector only joins others while gate degree - 1 + members <= cs.degree(): this plain gate lifts it to 5)
+        qf = cs.fixed_column()
+        y = cs.advice(a0)
+        cs.create_gate([cs.fixed(qf) * y * (y - 1) * (y - 2) * (y - 3)])
+        asg = Assignment(cs)
+        for r in range(3, asg_rows - 1, 3):  # every third row: a gate's neighbours r - 1, r + 1 stay its own
+            which = rng.randrange(4)
+            v = rng.randrange(1 << 16)
+            if which < 3:
+                asg.selectors[which].add(r)
+            if which == 0:    # a0^2 = a1
+                asg.set(ADVICE, a0, r, v)
+                asg.set(ADVICE, a1, r, v * v)
+            elif which == 1:  # a0 + a1(next) = 7
+                asg.set(ADVICE, a0, r, v)
+                asg.set(ADVICE, a1, r + 1, 7 - v)
+            elif which == 2:  # a0 * a1 = 3 * a1(prev) - 1
+                asg.set(ADVICE, a1, r - 1, v)
+                asg.set(ADVICE, a1, r, 1)
+                asg.set(ADVICE, a0, r, 3 * v - 1)
+            else:
+                asg.set(FIXED, qf, r, 1)
+                asg.set(ADVICE, a0, r, rng.randrange(4))
+        asg.compress_selectors()
+        assert cs.n_fixed == 2 and {c for c, _ in cs.selector_assignment} == {1}, "the three selectors share one column"
         return cs, asg, 0
     if kind == "wide_lookup":
         t0, t1, q = cs.fixed_column(), cs.fixed_column(), cs.fixed_column()

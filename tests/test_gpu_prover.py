@@ -172,7 +172,7 @@ def test_wnn_shaped_circuit_k15_verifies(ctx, zg, orc):
     glb.free()
 
 
-@pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup"])
+@pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup", "advice_factor", "merged_selectors"])
 def test_circuit_variants_match_oracle(ctx, zg, orc, kind):
     """No-lookup / no-permutation / several-instance-column / width-2-lookup paths of the prover."""
     from circuits import variant_circuit

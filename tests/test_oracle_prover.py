@@ -101,7 +101,7 @@ def test_wnn_shaped_circuit_proof_verifies(orc):
     assert orc.verify_proof(pk, inst, proof) == 1 and orc.verify_proof_pairing(pk, inst, proof) == 1
 
 
-@pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup"])
+@pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup", "advice_factor", "merged_selectors"])
 def test_circuit_variants_verify(orc, params5, kind):
     from circuits import variant_circuit
 

@@ -39,14 +39,56 @@ def test_constraint_system_shape_is_appendix_a(tiny):
     _, circuit, _, _ = tiny
     cs = circuit.cs
     assert (cs.n_advice, cs.n_instance, len(cs.gates), len(cs.lookups)) == (6, 1, 12, 4)
-    assert cs.n_fixed == 1 + 6 + 16  # constants, 6 table columns, 16 selectors (uncompressed)
+    # constants, 6 table columns, 5 complex selectors, 11 simple selectors merged into 4 columns
+    assert cs.n_fixed == 1 + 6 + 5 + 4 and len(cs.fixed_queries) == cs.n_fixed
     assert cs.degree() == 6 and cs.extended_k() == cs.k + 3 and cs.blinding_factors() == 5
     assert len(cs.perm_columns) == 8
     assert [len(t) for _, t in cs.lookups] == [3, 3, 1, 1]
     # rotations queried: a0 {0,+1}; a1..a3 {0}; a4 {0,+1}; a5 {-1,0,+1}
     assert sorted(cs.advice_queries) == sorted([(0, 0), (0, 1), (1, 0), (2, 0), (3, 0), (4, 0), (4, 1),
                                                 (5, -1), (5, 0), (5, 1)])
+    # a selector merged with m - 1 others is a polynomial of degree m in its column
+    assert [g.degree() for g in cs.gates] == [6, 4, 5, 3, 6, 6, 5, 4, 6, 4, 4, 4]
+    assert max(g.degree() for g in cs.gates) <= cs.degree()
+
+
+def test_constraint_system_shape_without_selector_compression():
+    k, name = wm.MNIST_TINY
+    circuit = wc.WnnCircuit(wm.load_checked_in(name), k, compress_selectors=False)
+    asg, _ = circuit.synthesize(wm.load_test_image())
+    cs = circuit.cs
+    assert cs.n_fixed == 1 + 6 + 16 and cs.degree() == 6
     assert [g.degree() for g in cs.gates] == [3, 2, 3, 3, 3, 3, 2, 2, 4, 2, 2, 2]
+    assert all(set(col) <= {0, 1} for col in asg.fixed[7:])
+    asg.check()
+
+
+def test_merged_selectors_are_nonzero_exactly_where_enabled(tiny):
+    """compress_selectors.rs: member t of a combination becomes q * prod_{u != t} (u - q) and the column holds
+    t on its rows -- the substituted polynomial must be non-zero on precisely the rows the selector was
+    enabled on, and members of one column must never share a row."""
+    _, circuit, asg, _ = tiny
+    cs = circuit.cs
+    by_column = {}
+    for s, (col, value) in enumerate(cs.selector_assignment):
+        by_column.setdefault(col, []).append((value, s))
+    assert sorted(len(v) for v in by_column.values()) == [1] * 6 + [3, 3, 4]
+    for col, members in by_column.items():
+        m = len(members)
+        assert sorted(v for v, _ in members) == list(range(1, m + 1))
+        rows_seen = set()
+        for value, s in members:
+            rows = asg.selectors[s]
+            assert not rows & rows_seen
+            rows_seen |= rows
+            for r in list(rows)[:50] + [0, 1, asg.n - 1]:
+                q = asg.fixed[col][r]
+                poly = q
+                for u in range(1, m + 1):
+                    if u != value:
+                        poly = poly * (u - q) % wc.R
+                assert (poly != 0) == (r in rows)
+        assert all((asg.fixed[col][r] != 0) == (r in rows_seen) for r in range(asg.n))
 
 
 def test_mock_proof_mnist_tiny(tiny, snapshots):
@@ -89,7 +131,8 @@ def test_keygen_does_not_depend_on_the_image(tiny):
 def test_a_wrong_witness_is_caught(tiny):
     _, circuit, _, _ = tiny
     asg, scores = circuit.synthesize(wm.load_test_image())
-    row = next(r for r in range(asg.n) if asg.fixed[circuit.cs.selector_columns[-1]][r])  # a bits2num row
+    col, value = circuit.cs.selector_assignment[-1]
+    row = next(r for r in range(asg.n) if asg.fixed[col][r] == value)  # a bits2num row
     asg.advice[4][row + 1] = (asg.advice[4][row + 1] + 1) % wc.R
     with pytest.raises(AssertionError):
         asg.check()
@@ -103,8 +146,8 @@ def test_oracle_proves_and_pairing_verifies_the_real_tiny_circuit(orc, tiny):
     pk = orc.ProvingKey(cs.to_c(), asg.fixed_values(), asg.sigma_values(), params, orc.fr_from_int(0xC0FFEE))
     inst = asg.instance_values(len(scores))
     st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, 1)
-    # 30 points (6 advice, 8 permuted, 2+4 products, 1 random, 5 h pieces, 4 openings) + 67 evaluations
-    assert st == 0 and len(proof) == 30 * 64 + (10 + 23 + 1 + 8 + 5 + 20) * 32 <= orc.proof_size(cs.to_c())
+    # 30 points (6 advice, 8 permuted, 2+4 products, 1 random, 5 h pieces, 4 openings) + 60 evaluations
+    assert st == 0 and len(proof) == 30 * 64 + (10 + 16 + 1 + 8 + 5 + 20) * 32 <= orc.proof_size(cs.to_c())
     assert orc.verify_proof_pairing(pk, inst, proof) == 1
     wrong = inst.copy()
     wrong[0, 7] = orc.fr_from_int(scores[7] + 1)
