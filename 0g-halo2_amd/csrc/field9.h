@@ -548,6 +548,54 @@ __device__ __forceinline__ XSum xadd(const XYZZ9* pa, const XYZZ9* pb, uint32_t 
     return s;
 }
 
+// ---- mixed addition acc += (qx, qy) by a pair of lanes, the running sum split between them for the whole
+// chain:   lane A: m = X, z = ZZ, w = ZZZ        lane B: m = Y, z = ZZZ.
+// Five products per lane instead of ten (madd-2008-s): U2 | S2,  PP | RR,  Q | PPP,  ZZ3 | Y1 PPP,
+// ZZZ3 | R (Q - X3); five quad_perm exchanges.  Both lanes pass the same qx, qy (already sign-adjusted) and
+// carry the same `inf`.  Equal x (doubling / inverse) is settled by both lanes running the one-lane
+// formula on the reassembled point.
+struct PairAcc {
+    F9 m, z, w;
+};
+__device__ __forceinline__ void xmadd_pair(PairAcc& a, bool& inf, const F9& qx, const F9& qy, bool A) {
+    if (inf) {
+        a.m = A ? qx : f9_norm(qy);  // (a negated y arrives with negative limbs)
+        a.z = Fq9Params::one();
+        a.w = Fq9Params::one();
+        inf = false;
+        return;
+    }
+    const F9 v = Fq9::mul(f9_sel(A, qx, qy), a.z);   // A: U2 = qx ZZ1      B: S2 = qy ZZZ1
+    const F9 d = f9_sub(v, a.m);                     // A: P                B: R
+    const F9 f = Fq9::sqr(d);                        // A: PP               B: RR
+    const F9 od = f9_swap(d), of = f9_swap(f);       // A: R, RR            B: P, PP
+    int32_t rare = (A && f.l[8] >= 0 && Fq9::is_zero_mod_p(f)) ? 1 : 0;
+    rare |= dpp_swap1(rare);
+    if (__builtin_expect(rare != 0, 0)) {
+        const F9 om = f9_swap(a.m), oz = f9_swap(a.z);
+        XYZZ9 full;
+        full.x = f9_sel(A, a.m, om);
+        full.y = f9_sel(A, om, a.m);
+        full.zz = f9_sel(A, a.z, oz);
+        full.zzz = f9_sel(A, a.w, a.z);
+        xyzz9_madd(full, inf, qx, qy);
+        a.m = f9_sel(A, full.x, full.y);
+        a.z = f9_sel(A, full.zz, full.zzz);
+        a.w = full.zzz;
+        return;
+    }
+    const F9 g = Fq9::mul(f9_sel(A, a.m, od), f9_sel(A, f, of));  // A: Q = X1 PP      B: PPP = P PP
+    const F9 og = f9_swap(g);                                     // A: PPP            B: Q
+    const F9 x3 = f9_norm(f9_sub(f9_sub(f9_sub(of, og), g), g));  // A: RR - PPP - 2Q
+    const F9 ot = f9_swap(f9_sub(g, x3));                         //                   B: T = Q - X3
+    const F9 h = Fq9::mul(f9_sel(A, a.z, a.m), f9_sel(A, f, g));  // A: ZZ3 = ZZ1 PP   B: Y1 PPP
+    const F9 k = Fq9::mul(f9_sel(A, a.w, d), f9_sel(A, og, ot));  // A: ZZZ3 = ZZZ1 PPP   B: R T
+    const F9 ok = f9_swap(k);                                     //                   B: ZZZ3
+    a.m = f9_sel(A, x3, f9_norm(f9_sub(k, h)));
+    a.z = f9_sel(A, h, ok);
+    a.w = k;
+}
+
 // nine-limb 2^261 form -> the library's packed XYZZ (coordinates x * 2^256, canonical)
 __device__ __forceinline__ XYZZ xyzz9_to_xyzz(const XYZZ9& a, bool inf) {
     if (inf || xyzz9_is_identity(a)) return xyzz_identity();

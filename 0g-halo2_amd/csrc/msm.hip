@@ -285,12 +285,17 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __rest
 // One lane per task: at most K points of one bucket, mixed adds in XYZZ on nine 29-bit limbs (field9.h:
 // no carry word per partial product, no per-operation modular correction); the partial sum leaves in
 // the library's packed form.
+// PAIR (the latency configuration): two lanes per task, the running sum split between them (field9.h
+// `xmadd_pair`): half the dependent products per point, for a launch that does not fill the chip alone.
+template <bool PAIR>
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table,
     uint32_t c, uint32_t windows, uint32_t n,
     const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
     const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ9* __restrict__ partial) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = PAIR ? lane >> 1 : lane;
+    const bool role_a = !PAIR || (lane & 1u) == 0;
     uint32_t b = blockIdx.y;
     if (t >= ttotal[b]) return;
     const Affine* table = b < split ? table_a : table_b;  // vectors >= split use the second base set
@@ -312,19 +317,43 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     uint32_t len = total - j * MSM_K;
     if (len > MSM_K) len = MSM_K;
     const uint32_t* so = sorted + (size_t)b * windows * n + start;
-    XYZZ9 acc;
+    XYZZ9* dst = partial + (size_t)b * max_tasks + t;
     bool inf = true;
-    for (uint32_t e = 0; e < len; e++) {
-        uint32_t ent = so[e];
-        uint32_t i = ent & 0xffffffu, w = (ent >> 24) & 0x7fu;
-        const Affine* src = table + (size_t)w * n_table + i;
-        const F9 qx = f9_unpack(ld_fe_g(&src->x));
-        F9 qy = f9_unpack(ld_fe_g(&src->y));
-        if (f9_limbs_zero(qx) && f9_limbs_zero(qy)) continue;  // identity base point
-        if (ent >> 31) qy = f9_neg(qy);
-        xyzz9_madd(acc, inf, qx, qy);
+    if constexpr (PAIR) {
+        PairAcc acc;
+        for (uint32_t e = 0; e < len; e++) {  // (both lanes of a pair see the same entries)
+            uint32_t ent = so[e];
+            uint32_t i = ent & 0xffffffu, w = (ent >> 24) & 0x7fu;
+            const Affine* src = table + (size_t)w * n_table + i;
+            const F9 qx = f9_unpack(ld_fe_g(&src->x));
+            F9 qy = f9_unpack(ld_fe_g(&src->y));
+            if (f9_limbs_zero(qx) && f9_limbs_zero(qy)) continue;  // identity base point
+            if (ent >> 31) qy = f9_neg(qy);
+            xmadd_pair(acc, inf, qx, qy, role_a);
+        }
+        if (inf) {
+            if (role_a) st_xyzz9(dst, xyzz9_identity());
+        } else if (role_a) {
+            st_f9(&dst->x, acc.m);
+            st_f9(&dst->zz, acc.z);
+        } else {
+            st_f9(&dst->y, acc.m);
+            st_f9(&dst->zzz, acc.z);
+        }
+    } else {
+        XYZZ9 acc;
+        for (uint32_t e = 0; e < len; e++) {
+            uint32_t ent = so[e];
+            uint32_t i = ent & 0xffffffu, w = (ent >> 24) & 0x7fu;
+            const Affine* src = table + (size_t)w * n_table + i;
+            const F9 qx = f9_unpack(ld_fe_g(&src->x));
+            F9 qy = f9_unpack(ld_fe_g(&src->y));
+            if (f9_limbs_zero(qx) && f9_limbs_zero(qy)) continue;  // identity base point
+            if (ent >> 31) qy = f9_neg(qy);
+            xyzz9_madd(acc, inf, qx, qy);
+        }
+        st_xyzz9(dst, inf ? xyzz9_identity() : acc);
     }
-    st_xyzz9(partial + (size_t)b * max_tasks + t, inf ? xyzz9_identity() : acc);
 }
 
 // sum_k k*B_k = sum_k S_k with S_k = sum_{k' >= k} B_k' (the classic running sum of running sums), cut
@@ -377,16 +406,16 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void msm_heavy_kernel(const XYZZ9
 // lane j merges the task partials of bucket k0 + j + 1 (hot buckets arrive pre-merged from
 // msm_heavy_kernel), a Hillis-Steele suffix scan through LDS gives the block-local S_j, stored for
 // stage 2 together with the block total P = S_0.
-template <bool PAIR>
-__global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_scan_kernel(
+template <bool PAIR, uint32_t RB>
+__global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_scan_kernel(
     const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ hmap,
     const XYZZ9* __restrict__ hsum, uint32_t max_tasks, uint32_t max_heavy, uint32_t c, XYZZ9* __restrict__ sfx,
     XYZZ9* __restrict__ blk_p, uint32_t nblk) {
-    __shared__ XYZZ9 sh[MSM_RB];
+    __shared__ XYZZ9 sh[RB];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u;
     const uint32_t blk = blockIdx.x, b = blockIdx.y;
-    const uint32_t k = blk * MSM_RB + j + 1;
+    const uint32_t k = blk * RB + j + 1;
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
     if constexpr (PAIR) {
@@ -401,8 +430,8 @@ __global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_scan_ke
             }
         }
         __syncthreads();
-        for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
-            const bool has = j + o < MSM_RB;
+        for (uint32_t o = 1; o < RB; o <<= 1) {
+            const bool has = j + o < RB;
             XSum s;
             if (has) s = xadd<true>(&sh[j], &sh[j + o], role);
             __syncthreads();
@@ -422,9 +451,9 @@ __global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_scan_ke
         }
         sh[j] = acc;
         __syncthreads();
-        for (uint32_t o = 1; o < MSM_RB; o <<= 1) {
+        for (uint32_t o = 1; o < RB; o <<= 1) {
             XYZZ9 v = xyzz9_identity();
-            const bool has = j + o < MSM_RB;
+            const bool has = j + o < RB;
             if (has) v = sh[j + o];
             __syncthreads();
             if (has) sh[j] = xyzz9_add(sh[j], v);
@@ -432,7 +461,7 @@ __global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_scan_ke
         }
     }
     if (role == 0) {
-        st_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + j, sh[j]);
+        st_xyzz9(sfx + ((size_t)b * nblk + blk) * RB + j, sh[j]);
         if (j == 0) st_xyzz9(blk_p + (size_t)b * nblk + blk, sh[0]);
     }
 }
@@ -440,16 +469,16 @@ __global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_scan_ke
 // Stage 2: the global suffix sum at bucket (blk, j) is S_j + BS with BS = sum of the totals of the
 // blocks above.  Every lane adds BS once -- the factor 256 of "256 * BS" is supplied by the 256 lanes,
 // not by a doubling chain -- and a tree gives W' = sum_j (S_j + BS).
-template <bool PAIR>
-__global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
+template <bool PAIR, uint32_t RB>
+__global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
                                                                                    const XYZZ9* __restrict__ blk_p,
                                                                                    XYZZ9* __restrict__ blk_w,
                                                                                    uint32_t nblk) {
-    __shared__ XYZZ9 sh[MSM_RB];
+    __shared__ XYZZ9 sh[RB];
     __shared__ XYZZ9 bs;
     const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u;
     const uint32_t blk = blockIdx.x, b = blockIdx.y;
-    // BS = sum_{blk' > blk} P_blk'   (nblk <= 256)
+    // BS = sum_{blk' > blk} P_blk'   (nblk <= RB: checked at launch)
     if (role == 0) sh[j] = blk + 1 + j < nblk ? ld_xyzz9(blk_p + (size_t)b * nblk + blk + 1 + j) : xyzz9_identity();
     __syncthreads();
     uint32_t span = 1;
@@ -464,10 +493,10 @@ __global__ __launch_bounds__(PAIR ? 2 * MSM_RB : MSM_RB) void msm_bucket_sum_ker
     for (uint32_t o = span / 2; o > 0; o >>= 1) tree_step(o);
     if (threadIdx.x == 0) bs = sh[0];
     __syncthreads();
-    if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(sfx + ((size_t)b * nblk + blk) * MSM_RB + j, &bs, role));
-    else sh[j] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * MSM_RB + j), bs);
+    if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(sfx + ((size_t)b * nblk + blk) * RB + j, &bs, role));
+    else sh[j] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * RB + j), bs);
     __syncthreads();
-    for (uint32_t o = MSM_RB / 2; o > 0; o >>= 1) tree_step(o);
+    for (uint32_t o = RB / 2; o > 0; o >>= 1) tree_step(o);
     if (threadIdx.x == 0) st_xyzz9(blk_w + (size_t)b * nblk + blk, sh[0]);
 }
 
@@ -563,8 +592,17 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
     uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
     const uint32_t max_tasks = (uint32_t)mt;
-    const uint32_t nblk = (nb + MSM_RB - 1) / MSM_RB;
-    ZG_REQUIRE(nblk <= 256, ZG_ERR_UNSUPPORTED, "zg_msm: window_bits %u too large", c);
+    // buckets per reduction block: 256 in the throughput configuration; the latency configuration spreads
+    // the same buckets over more, smaller workgroups (one wave per SIMD, shorter scans) while the block
+    // totals still fit one block's LDS array (nblk <= rb)
+    uint32_t rb = MSM_RB;
+    if (ctx->msm_pair) {
+        static const int rb_env = getenv("ZG_MSM_RB") ? atoi(getenv("ZG_MSM_RB")) : 0;  // tuning override
+        const uint32_t want = rb_env == 64 || rb_env == 128 || rb_env == 256 ? (uint32_t)rb_env : 128u;  // tools/sweep_rb.sh
+        if ((nb + want - 1) / want <= want) rb = want;
+    }
+    const uint32_t nblk = (nb + rb - 1) / rb;
+    ZG_REQUIRE(nblk <= 256 && nblk <= rb, ZG_ERR_UNSUPPORTED, "zg_msm: window_bits %u too large", c);
 
     WsScope ws(ctx);
     uint32_t* dig = ws.get<uint32_t>((size_t)B * entries);
@@ -578,7 +616,7 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     XYZZ9* partial = ws.get<XYZZ9>((size_t)B * max_tasks);
     XYZZ9* blk_w = ws.get<XYZZ9>((size_t)B * nblk);
     XYZZ9* blk_p = ws.get<XYZZ9>((size_t)B * nblk);
-    XYZZ9* sfx = ws.get<XYZZ9>((size_t)B * nblk * MSM_RB);
+    XYZZ9* sfx = ws.get<XYZZ9>((size_t)B * nblk * rb);
     // a hot bucket holds more than MSM_HEAVY * MSM_K entries
     const uint32_t max_heavy = (uint32_t)(entries / ((uint64_t)MSM_HEAVY * MSM_K)) + 1;
     uint32_t* hmap = ws.get<uint32_t>((size_t)B * (nb + 1));
@@ -615,24 +653,36 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               off);
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted);
-    ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
-              bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot, toff,
-              ttotal, sorted, max_tasks, partial);
+    if (ctx->msm_pair) {
+        ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<true>, dim3((2 * max_tasks + 255) / 256, B), dim3(256),
+                  0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
+                  toff, ttotal, sorted, max_tasks, partial);
+    } else {
+        ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<false>, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
+                  bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
+                  toff, ttotal, sorted, max_tasks, partial);
+    }
     const dim3 hgrid(max_heavy < 2048 ? max_heavy : 2048, B);
     if (ctx->msm_pair) {  // two lanes per addition: half the dependent latency of the reduction
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<true>, hgrid, dim3(512), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
-        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_bucket_scan_kernel<true>, dim3(nblk, B), dim3(2 * MSM_RB), 0, partial,
-                  toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
-        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_bucket_sum_kernel<true>, dim3(nblk, B), dim3(2 * MSM_RB), 0, sfx, blk_p,
-                  blk_w, nblk);
+        auto reduce = [&](auto tag) {
+            constexpr uint32_t RB = decltype(tag)::value;
+            ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<true, RB>), dim3(nblk, B), dim3(2 * RB), 0,
+                      partial, toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
+            ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<true, RB>), dim3(nblk, B), dim3(2 * RB), 0, sfx,
+                      blk_p, blk_w, nblk);
+        };
+        if (rb == 64) reduce(std::integral_constant<uint32_t, 64>{});
+        else if (rb == 128) reduce(std::integral_constant<uint32_t, 128>{});
+        else reduce(std::integral_constant<uint32_t, MSM_RB>{});
         ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<true>, dim3(B), dim3(512), 0, blk_w, nblk, d_out);
     } else {
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<false>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
-        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_bucket_scan_kernel<false>, dim3(nblk, B), dim3(MSM_RB), 0, partial,
+        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<false, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
                   toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
-        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_bucket_sum_kernel<false>, dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
+        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<false, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
                   blk_w, nblk);
         ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<false>, dim3(B), dim3(256), 0, blk_w, nblk, d_out);
     }
