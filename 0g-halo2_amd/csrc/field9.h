@@ -548,6 +548,88 @@ __device__ __forceinline__ XSum xadd(const XYZZ9* pa, const XYZZ9* pb, uint32_t 
     return s;
 }
 
+// ---- *pa + *pb by FOUR lanes (a quad, role = lane & 3): four rounds of one product per lane instead of the
+// pair's seven,
+//      round 1   U1 = X1 ZZ2 | U2 = X2 ZZ1 | S1 = Y1 ZZZ2 | S2 = Y2 ZZZ1
+//      round 2   ZZ1 ZZ2     | PP = P^2    | ZZZ1 ZZZ2    | RR = R^2
+//      round 3   Q = U1 PP   | PPP = P PP  | ZZ3          | -
+//      round 4   -           | S1 PPP      | ZZZ3         | R (Q - X3)
+// with quad_perm exchanges / broadcasts in between; lane 3 ends up with x and y, lane 2 with zz and zzz.
+// Every lane runs the same instruction stream (squares go through the general product: a divergent
+// branch would cost more than it saves).  Identity operands and equal x are settled as in xadd<true>.
+template <int CTRL>
+__device__ __forceinline__ int32_t dpp_quad(int32_t v) {
+    int32_t r = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+    asm volatile("" : "+v"(r));  // (see dpp_swap1)
+    return r;
+}
+template <int CTRL>
+__device__ __forceinline__ F9 f9_quad(const F9& a) {
+    F9 o;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o.l[i] = dpp_quad<CTRL>(a.l[i]);
+    return o;
+}
+constexpr int QUAD_SWAP1 = 0xB1, QUAD_SWAP2 = 0x4E, QUAD_B0 = 0x00, QUAD_B1 = 0x55, QUAD_B2 = 0xAA;
+
+__device__ __forceinline__ XSum xadd4(const XYZZ9* pa, const XYZZ9* pb, uint32_t role) {
+    XSum s;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    const bool first = (role & 1u) == 0;  // lanes 0, 2 start from a's coordinate, lanes 1, 3 from b's
+    const bool ypart = role >= 2;
+    const XYZZ9* own = first ? pa : pb;
+    const XYZZ9* oth = first ? pb : pa;
+    const F9 m = ld_f9(ypart ? &own->y : &own->x);      // X1 | X2 | Y1 | Y2
+    const F9 mz = ld_f9(ypart ? &oth->zzz : &oth->zz);  // ZZ2 | ZZ1 | ZZZ2 | ZZZ1
+    const F9 e1 = ld_f9(ypart ? &pa->zzz : &pa->zz);    // ZZ1 | . | ZZZ1 | .
+    // identity flags from lane 0 (it holds ZZ1 and ZZ2; identity points are all-zero)
+    int32_t fl = (f9_limbs_zero(e1) ? 1 : 0) | (f9_limbs_zero(mz) ? 2 : 0);
+    fl = dpp_quad<QUAD_B0>(fl);
+    if (fl) {  // result = the other operand (b when a is the identity), copied by the two writer lanes
+        const XYZZ9* src = (fl & 1) ? pb : pa;
+        s.wm = 0;
+        if (role == 3) { s.r.x = ld_f9(&src->x); s.r.y = ld_f9(&src->y); s.wm = 3u; }
+        if (role == 2) { s.r.zz = ld_f9(&src->zz); s.r.zzz = ld_f9(&src->zzz); s.wm = 12u; }
+        return s;
+    }
+    const F9 t1 = Fq9::mul(m, mz);                       // U1 | U2 | S1 | S2
+    const F9 o1 = f9_quad<QUAD_SWAP1>(t1);
+    const F9 d = first ? f9_sub(o1, t1) : f9_sub(t1, o1);  // P | P | R | R
+    const F9 t2 = Fq9::mul(f9_sel(first, e1, d), f9_sel(first, mz, d));  // ZZ1 ZZ2 | PP | ZZZ1 ZZZ2 | RR
+    int32_t rare = (role == 1 && t2.l[8] >= 0 && Fq9::is_zero_mod_p(t2)) ? 1 : 0;
+    rare = dpp_quad<QUAD_B1>(rare);
+    if (__builtin_expect(rare != 0, 0)) {  // equal x: lane 0 settles it alone
+        s.wm = 0;
+        if (role == 0) {
+            s.r = xyzz9_add(ld_xyzz9(pa), ld_xyzz9(pb));
+            s.wm = 0xFu;
+        }
+        return s;
+    }
+    const F9 pp = f9_quad<QUAD_B1>(t2);
+    const F9 z12 = f9_quad<QUAD_SWAP2>(t2);              // lane 2: ZZ1 ZZ2
+    const F9 t3 = Fq9::mul(role == 0 ? t1 : role == 2 ? z12 : d, pp);  // Q | PPP | ZZ3 | .
+    const F9 ppp = f9_quad<QUAD_B1>(t3), qq = f9_quad<QUAD_B0>(t3);
+    const F9 x3 = f9_norm(f9_sub(f9_sub(f9_sub(t2, ppp), qq), qq));   // lane 3: RR - PPP - 2Q
+    const F9 tt = f9_sub(qq, x3);
+    const F9 s1 = f9_quad<QUAD_B2>(t1);
+    const F9 t4 = Fq9::mul(role == 3 ? d : role == 2 ? t2 : s1, role == 3 ? tt : ppp);  // . | S1 PPP | ZZZ3 | R (Q - X3)
+    const F9 o4 = f9_quad<QUAD_B1>(t4);
+    s.r.x = x3;
+    s.r.y = f9_norm(f9_sub(t4, o4));  // (meaningful on lane 3)
+    s.r.zz = t3;                       // (meaningful on lane 2)
+    s.r.zzz = t4;
+    s.wm = role == 3 ? 3u : role == 2 ? 12u : 0u;
+    return s;
+}
+
+// L lanes per addition: 1 (registers), 2 (xadd<true>) or 4 (xadd4); the result is written with xstore<L > 1>.
+template <int L>
+__device__ __forceinline__ XSum xaddl(const XYZZ9* pa, const XYZZ9* pb, uint32_t role) {
+    if constexpr (L == 4) return xadd4(pa, pb, role);
+    else return xadd<L == 2>(pa, pb, role);
+}
+
 // ---- mixed addition acc += (qx, qy) by a pair of lanes, the running sum split between them for the whole
 // chain:   lane A: m = X, z = ZZ, w = ZZZ        lane B: m = Y, z = ZZZ.
 // Five products per lane instead of ten (madd-2008-s): U2 | S2,  PP | RR,  Q | PPP,  ZZ3 | Y1 PPP,

@@ -360,13 +360,14 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
 // into blocks of 256 buckets so that it parallelises (msm_bucket_scan / msm_bucket_sum / msm_finish).
 constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
 
-// All four reduction kernels are templated on PAIR: one lane per addition (throughput: least work), or
-// two lanes per addition (field9.h `xadd<true>`: half the dependent latency; the prover's latency
-// configuration and the stand-alone MSM entry points use it).  j = logical lane, role = lane in the pair.
+// All four reduction kernels are templated on L, the lanes per addition: 1 (throughput: least work), or 2 / 4
+// (field9.h `xadd<true>`, `xadd4`: seven / four dependent products per lane instead of fourteen; the
+// prover's latency configuration and the stand-alone MSM entry points use them).  j = logical lane,
+// role = lane within the group.
 
 // One workgroup per hot bucket: lanes take a strided share of its task partials, tree through LDS.
-template <bool PAIR>
-__global__ __launch_bounds__(PAIR ? 512 : 256) void msm_heavy_kernel(const XYZZ9* __restrict__ partial,
+template <int L>
+__global__ __launch_bounds__(256 * L) void msm_heavy_kernel(const XYZZ9* __restrict__ partial,
                                                                      const uint32_t* __restrict__ toff,
                                                                      const uint32_t* __restrict__ hlist,
                                                                      const uint32_t* __restrict__ nheavy, uint32_t max_tasks,
@@ -374,16 +375,16 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void msm_heavy_kernel(const XYZZ9
                                                                      XYZZ9* __restrict__ hsum) {
     __shared__ XYZZ9 sh[256];
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u, b = blockIdx.y;
+    const uint32_t j = threadIdx.x / L, role = threadIdx.x % L, b = blockIdx.y;
     const uint32_t nh = nheavy[b];
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t k = hlist[(size_t)b * max_heavy + h];
         const uint32_t t0 = to[k], t1 = to[k + 1];
-        if constexpr (PAIR) {
+        if constexpr (L > 1) {
             if (role == 0) sh[j] = xyzz9_identity();
-            for (uint32_t t = t0 + j; t < t1; t += 256) xstore<true>(&sh[j], xadd<true>(&sh[j], pp + t, role));
+            for (uint32_t t = t0 + j; t < t1; t += 256) xstore<true>(&sh[j], xaddl<L>(&sh[j], pp + t, role));
         } else {  // (one lane per addition: the running sum stays in registers)
             XYZZ9 acc = xyzz9_identity();
             for (uint32_t t = t0 + j; t < t1; t += 256) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void msm_heavy_kernel(const XYZZ9
         __syncthreads();
         for (uint32_t o = 128; o > 0; o >>= 1) {
             if (j < o) {
-                if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(&sh[j], &sh[j + o], role));
+                if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(&sh[j], &sh[j + o], role));
                 else sh[j] = xyzz9_add(sh[j], sh[j + o]);
             }
             __syncthreads();
@@ -406,19 +407,19 @@ __global__ __launch_bounds__(PAIR ? 512 : 256) void msm_heavy_kernel(const XYZZ9
 // lane j merges the task partials of bucket k0 + j + 1 (hot buckets arrive pre-merged from
 // msm_heavy_kernel), a Hillis-Steele suffix scan through LDS gives the block-local S_j, stored for
 // stage 2 together with the block total P = S_0.
-template <bool PAIR, uint32_t RB>
-__global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_scan_kernel(
+template <int L, uint32_t RB>
+__global__ __launch_bounds__(L * RB) void msm_bucket_scan_kernel(
     const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ hmap,
     const XYZZ9* __restrict__ hsum, uint32_t max_tasks, uint32_t max_heavy, uint32_t c, XYZZ9* __restrict__ sfx,
     XYZZ9* __restrict__ blk_p, uint32_t nblk) {
     __shared__ XYZZ9 sh[RB];
     const uint32_t nb = 1u << (c - 1);
-    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u;
+    const uint32_t j = threadIdx.x / L, role = threadIdx.x % L;
     const uint32_t blk = blockIdx.x, b = blockIdx.y;
     const uint32_t k = blk * RB + j + 1;
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
-    if constexpr (PAIR) {
+    if constexpr (L > 1) {
         if (role == 0) sh[j] = xyzz9_identity();
         if (k <= nb) {
             const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
@@ -426,14 +427,14 @@ __global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_scan_kernel(
                 if (role == 0) sh[j] = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
             } else {
                 const uint32_t t0 = to[k], t1 = to[k + 1];
-                for (uint32_t t = t0; t < t1; t++) xstore<true>(&sh[j], xadd<true>(&sh[j], pp + t, role));
+                for (uint32_t t = t0; t < t1; t++) xstore<true>(&sh[j], xaddl<L>(&sh[j], pp + t, role));
             }
         }
         __syncthreads();
         for (uint32_t o = 1; o < RB; o <<= 1) {
             const bool has = j + o < RB;
             XSum s;
-            if (has) s = xadd<true>(&sh[j], &sh[j + o], role);
+            if (has) s = xaddl<L>(&sh[j], &sh[j + o], role);
             __syncthreads();
             if (has) xstore<true>(&sh[j], s);
             __syncthreads();
@@ -469,14 +470,14 @@ __global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_scan_kernel(
 // Stage 2: the global suffix sum at bucket (blk, j) is S_j + BS with BS = sum of the totals of the
 // blocks above.  Every lane adds BS once -- the factor 256 of "256 * BS" is supplied by the 256 lanes,
 // not by a doubling chain -- and a tree gives W' = sum_j (S_j + BS).
-template <bool PAIR, uint32_t RB>
-__global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
+template <int L, uint32_t RB>
+__global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
                                                                                    const XYZZ9* __restrict__ blk_p,
                                                                                    XYZZ9* __restrict__ blk_w,
                                                                                    uint32_t nblk) {
     __shared__ XYZZ9 sh[RB];
     __shared__ XYZZ9 bs;
-    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u;
+    const uint32_t j = threadIdx.x / L, role = threadIdx.x % L;
     const uint32_t blk = blockIdx.x, b = blockIdx.y;
     // BS = sum_{blk' > blk} P_blk'   (nblk <= RB: checked at launch)
     if (role == 0) sh[j] = blk + 1 + j < nblk ? ld_xyzz9(blk_p + (size_t)b * nblk + blk + 1 + j) : xyzz9_identity();
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_sum_kernel(cons
     while (span < nblk) span <<= 1;
     auto tree_step = [&](uint32_t o) {
         if (j < o) {
-            if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(&sh[j], &sh[j + o], role));
+            if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(&sh[j], &sh[j + o], role));
             else sh[j] = xyzz9_add(sh[j], sh[j + o]);
         }
         __syncthreads();
@@ -493,7 +494,7 @@ __global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_sum_kernel(cons
     for (uint32_t o = span / 2; o > 0; o >>= 1) tree_step(o);
     if (threadIdx.x == 0) bs = sh[0];
     __syncthreads();
-    if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(sfx + ((size_t)b * nblk + blk) * RB + j, &bs, role));
+    if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(sfx + ((size_t)b * nblk + blk) * RB + j, &bs, role));
     else sh[j] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * RB + j), bs);
     __syncthreads();
     for (uint32_t o = RB / 2; o > 0; o >>= 1) tree_step(o);
@@ -501,18 +502,18 @@ __global__ __launch_bounds__(PAIR ? 2 * RB : RB) void msm_bucket_sum_kernel(cons
 }
 
 // result = sum_blk W'_blk
-template <bool PAIR>
-__global__ __launch_bounds__(PAIR ? 512 : 256) void msm_finish_kernel(const XYZZ9* __restrict__ blk_w, uint32_t nblk,
+template <int L>
+__global__ __launch_bounds__(256 * L) void msm_finish_kernel(const XYZZ9* __restrict__ blk_w, uint32_t nblk,
                                                                       XYZZ* __restrict__ out) {
     __shared__ XYZZ9 sh[256];
-    const uint32_t j = PAIR ? threadIdx.x >> 1 : threadIdx.x, role = PAIR ? threadIdx.x & 1u : 0u, b = blockIdx.x;
+    const uint32_t j = threadIdx.x / L, role = threadIdx.x % L, b = blockIdx.x;
     if (role == 0) sh[j] = j < nblk ? ld_xyzz9(blk_w + (size_t)b * nblk + j) : xyzz9_identity();
     __syncthreads();
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
     for (uint32_t o = span / 2; o > 0; o >>= 1) {
         if (j < o) {
-            if constexpr (PAIR) xstore<true>(&sh[j], xadd<true>(&sh[j], &sh[j + o], role));
+            if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(&sh[j], &sh[j + o], role));
             else sh[j] = xyzz9_add(sh[j], sh[j + o]);
         }
         __syncthreads();
@@ -596,10 +597,16 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     // the same buckets over more, smaller workgroups (one wave per SIMD, shorter scans) while the block
     // totals still fit one block's LDS array (nblk <= rb)
     uint32_t rb = MSM_RB;
+    int lanes = 1;
     if (ctx->msm_pair) {
-        static const int rb_env = getenv("ZG_MSM_RB") ? atoi(getenv("ZG_MSM_RB")) : 0;  // tuning override
-        const uint32_t want = rb_env == 64 || rb_env == 128 || rb_env == 256 ? (uint32_t)rb_env : 128u;  // tools/sweep_rb.sh
+        // tuning overrides (tools/sweep_rb.sh, tools/sweep_lanes.sh); by default 64-bucket blocks with four
+        // lanes per addition when the block totals fit (c <= 13), else 128-bucket blocks with two
+        static const int rb_env = getenv("ZG_MSM_RB") ? atoi(getenv("ZG_MSM_RB")) : 0;
+        static const int lanes_env = getenv("ZG_MSM_LANES") ? atoi(getenv("ZG_MSM_LANES")) : 0;
+        uint32_t want = rb_env == 64 || rb_env == 128 || rb_env == 256 ? (uint32_t)rb_env : (nb + 63) / 64 <= 64 ? 64u : 128u;
         if ((nb + want - 1) / want <= want) rb = want;
+        lanes = lanes_env == 2 || lanes_env == 4 ? lanes_env : rb == 64 ? 4 : 2;
+        if (rb > 128) lanes = 2;  // (4 lanes x 256 buckets would exceed a workgroup)
     }
     const uint32_t nblk = (nb + rb - 1) / rb;
     ZG_REQUIRE(nblk <= 256 && nblk <= rb, ZG_ERR_UNSUPPORTED, "zg_msm: window_bits %u too large", c);
@@ -663,28 +670,34 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                   toff, ttotal, sorted, max_tasks, partial);
     }
     const dim3 hgrid(max_heavy < 2048 ? max_heavy : 2048, B);
-    if (ctx->msm_pair) {  // two lanes per addition: half the dependent latency of the reduction
-        ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<true>, hgrid, dim3(512), 0, partial, toff, hlist, nheavy,
-                  max_tasks, max_heavy, c, hsum);
-        auto reduce = [&](auto tag) {
-            constexpr uint32_t RB = decltype(tag)::value;
-            ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<true, RB>), dim3(nblk, B), dim3(2 * RB), 0,
+    if (ctx->msm_pair) {  // several lanes per addition: shorter dependent chains in the reduction
+        ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<2>, hgrid, dim3(512), 0, partial, toff, hlist, nheavy, max_tasks,
+                  max_heavy, c, hsum);
+        auto reduce = [&](auto ltag, auto rtag) {
+            constexpr int L = decltype(ltag)::value;
+            constexpr uint32_t RB = decltype(rtag)::value;
+            ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<L, RB>), dim3(nblk, B), dim3(L * RB), 0,
                       partial, toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
-            ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<true, RB>), dim3(nblk, B), dim3(2 * RB), 0, sfx,
+            ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<L, RB>), dim3(nblk, B), dim3(L * RB), 0, sfx,
                       blk_p, blk_w, nblk);
         };
-        if (rb == 64) reduce(std::integral_constant<uint32_t, 64>{});
-        else if (rb == 128) reduce(std::integral_constant<uint32_t, 128>{});
-        else reduce(std::integral_constant<uint32_t, MSM_RB>{});
-        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<true>, dim3(B), dim3(512), 0, blk_w, nblk, d_out);
+        using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>;
+        // (four lanes pay off while the workgroup stays at one wave per SIMD: 64-bucket blocks)
+        if (rb == 64 && lanes == 4) reduce(I4{}, std::integral_constant<uint32_t, 64>{});
+        else if (rb == 64) reduce(I2{}, std::integral_constant<uint32_t, 64>{});
+        else if (rb == 128 && lanes == 4) reduce(I4{}, std::integral_constant<uint32_t, 128>{});
+        else if (rb == 128) reduce(I2{}, std::integral_constant<uint32_t, 128>{});
+        else reduce(I2{}, std::integral_constant<uint32_t, MSM_RB>{});
+        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<2>, dim3(B), dim3(512), 0, blk_w, nblk, d_out);
     } else {
-        ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<false>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
+        ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<1>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
-        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<false, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
+        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
                   toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
-        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<false, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
+        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
                   blk_w, nblk);
-        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<false>, dim3(B), dim3(256), 0, blk_w, nblk, d_out);
+        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<1>, dim3(B), dim3(256), 0, blk_w, nblk, d_out);
     }
     ZG_HIP(hipGetLastError());
     return ZG_OK;

@@ -1,4 +1,4 @@
-// Probe: two-lane addition (field9.h xadd<true>) against the one-lane xyzz9_add on the same inputs.
+// Probe: two- and four-lane additions (field9.h xadd<true>, xadd4) against the one-lane xyzz9_add on the same inputs.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "curve.h"
@@ -14,9 +14,10 @@ __device__ XYZZ9 mulG(uint32_t k) {  // k*G by repeated mixed addition (k small)
     return inf ? xyzz9_identity() : acc;
 }
 
+template <int L>
 __global__ void probe(uint32_t* bad, XYZZ* outp, XYZZ* outs, int mode) {
     __shared__ XYZZ9 sa[128], sb[128], sd[128];
-    const uint32_t j = threadIdx.x >> 1, role = threadIdx.x & 1;
+    const uint32_t j = threadIdx.x / L, role = threadIdx.x % L;
     if (role == 0) {
         uint32_t ka = j + 2, kb = 3 * j + 5;
         if (mode == 1 && j % 7 == 0) ka = 0;            // a identity
@@ -26,7 +27,7 @@ __global__ void probe(uint32_t* bad, XYZZ* outp, XYZZ* outs, int mode) {
         sb[j] = mulG(kb);
     }
     __syncthreads();
-    XSum s = xadd<true>(&sa[j], &sb[j], role);
+    XSum s = xaddl<L>(&sa[j], &sb[j], role);
     xstore<true>(&sd[j], s);
     __syncthreads();
     if (role == 0) {
@@ -42,16 +43,19 @@ __global__ void probe(uint32_t* bad, XYZZ* outp, XYZZ* outs, int mode) {
 int main() {
     uint32_t* d_bad; XYZZ *dp, *ds;
     hipMalloc(&d_bad, 4); hipMalloc(&dp, sizeof(XYZZ) * 128); hipMalloc(&ds, sizeof(XYZZ) * 128);
-    for (int mode = 0; mode < 3; mode++) {
-        hipMemset(d_bad, 0, 4);
-        hipLaunchKernelGGL(probe, dim3(1), dim3(256), 0, 0, d_bad, dp, ds, mode);
-        uint32_t bad = 0;
-        hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
-        XYZZ hp[4], hs[4];
-        hipMemcpy(hp, dp, sizeof(hp), hipMemcpyDeviceToHost);
-        hipMemcpy(hs, ds, sizeof(hs), hipMemcpyDeviceToHost);
-        printf("mode %d: %u of 128 differ; lane1 pair x=%08x.. y=%08x.. zz=%08x.. zzz=%08x.. | single x=%08x.. y=%08x.. zz=%08x.. zzz=%08x..\n", mode, bad,
-               hp[1].x.l[0], hp[1].y.l[0], hp[1].zz.l[0], hp[1].zzz.l[0], hs[1].x.l[0], hs[1].y.l[0], hs[1].zz.l[0], hs[1].zzz.l[0]);
-    }
+    for (int lanes = 2; lanes <= 4; lanes += 2)
+        for (int mode = 0; mode < 3; mode++) {
+            hipMemset(d_bad, 0, 4);
+            if (lanes == 2) hipLaunchKernelGGL(probe<2>, dim3(1), dim3(256), 0, 0, d_bad, dp, ds, mode);
+            else hipLaunchKernelGGL(probe<4>, dim3(1), dim3(512), 0, 0, d_bad, dp, ds, mode);
+            uint32_t bad = 0;
+            hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost);
+            XYZZ hp[4], hs[4];
+            hipMemcpy(hp, dp, sizeof(hp), hipMemcpyDeviceToHost);
+            hipMemcpy(hs, ds, sizeof(hs), hipMemcpyDeviceToHost);
+            printf("%d lanes, mode %d: %u of 128 differ; slot 1 x=%08x.. y=%08x.. zz=%08x.. zzz=%08x.. | single x=%08x.. y=%08x.. zz=%08x.. zzz=%08x..\n", lanes,
+                   mode, bad, hp[1].x.l[0], hp[1].y.l[0], hp[1].zz.l[0], hp[1].zzz.l[0], hs[1].x.l[0], hs[1].y.l[0], hs[1].zz.l[0],
+                   hs[1].zzz.l[0]);
+        }
     return 0;
 }
