@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <array>
 #include <cstdarg>
@@ -129,15 +130,18 @@ struct WsScope {
 };
 int pinned_reserve(zg_ctx* ctx, size_t bytes);
 
-// Launch wrapper: when profiling is on, two hipEvents bracket the kernel on the context stream and
-// `algo_bytes` (the ALGORITHMIC bytes this launch is charged with) is recorded beside it.
-bool prof_begin(zg_ctx* ctx, const char* name, double algo_bytes);  // false: filtered out
-void prof_end(zg_ctx* ctx);
-#define ZG_LAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                 \
-    do {                                                                           \
-        const bool _zg_p = (ctx)->profiling && ::zg::prof_begin((ctx), (name), (double)(bytes)); \
-        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);  \
-        if (_zg_p) ::zg::prof_end((ctx));                                          \
+// Launch wrapper: when profiling is on, the dispatch carries a start and a stop event of its own
+// (hipExtLaunchKernelGGL: the timestamps are the kernel's begin and end, as rocprofv3 reports them -- events
+// recorded around the launch would add the queueing time of a busy stream) and `algo_bytes` (the
+// ALGORITHMIC bytes this launch is charged with) is recorded beside them.
+zg_ctx::ProfRec* prof_slot(zg_ctx* ctx, const char* name, double algo_bytes);  // nullptr: filtered out
+#define ZG_LAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                                       \
+    do {                                                                                                 \
+        zg_ctx::ProfRec* _zg_r = (ctx)->profiling ? ::zg::prof_slot((ctx), (name), (double)(bytes)) : nullptr; \
+        if (_zg_r)                                                                                       \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, _zg_r->e0, _zg_r->e1, 0, __VA_ARGS__); \
+        else                                                                                             \
+            hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);                    \
     } while (0)
 
 // twiddle table for (log_n, omega), created on first use

@@ -67,19 +67,16 @@ static hipEvent_t pool_event(zg_ctx* ctx) {
     return e;
 }
 
-bool prof_begin(zg_ctx* ctx, const char* name, double algo_bytes) {
-    if (!ctx->prof_filter.empty() && ctx->prof_filter != name) return false;
+zg_ctx::ProfRec* prof_slot(zg_ctx* ctx, const char* name, double algo_bytes) {
+    if (!ctx->prof_filter.empty() && ctx->prof_filter != name) return nullptr;
     zg_ctx::ProfRec r;
     r.name = name;
     r.bytes = algo_bytes;
     r.e0 = pool_event(ctx);
     r.e1 = pool_event(ctx);
-    (void)hipEventRecord(r.e0, ctx->stream);
     ctx->prof.push_back(r);
-    return true;
+    return &ctx->prof.back();  // (valid until the next slot is taken: the launch macro uses it at once)
 }
-
-void prof_end(zg_ctx* ctx) { (void)hipEventRecord(ctx->prof.back().e1, ctx->stream); }
 
 Fe host_domain_omega(uint32_t log_n) {
     Fe w = fr_root_of_unity();

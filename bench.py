@@ -181,7 +181,7 @@ def main():
                     help="proofs per step = independent proofs in flight per GPU (each on its own HIP stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket kernels with HIP events in the timed region (no roofline object)")
+                    help="no HIP events on the dominant kernel's launches in the timed region (no roofline object)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -229,7 +229,7 @@ def main():
 
     run(max(args.warmup, 1))
     # single-proof latency: one stream alone (transforms overlapped on its side stream), a few proofs;
-    # with every kernel bracketed by HIP events once, to learn the per-kernel split and which dominates
+    # with every launch timed by HIP events once, to learn the per-kernel split and which dominates
     job.prover.set_overlap(True)
     for _ in range(2):
         job.step()
@@ -253,8 +253,8 @@ def main():
     if dominant not in split or split[top][1] > 1.5 * split[dominant][1]:
         dominant = top
     job.prover.set_overlap(False)  # throughput configuration: one HIP stream per proof
-    # timed region: only the dominant kernel carries events (two records per launch); bracketing all
-    # ~90 launches of a proof costs ~0.7 ms of host time per proof
+    # timed region: only the dominant kernel's dispatches carry a start / stop event (on the proof's own
+    # stream, hipExtLaunchKernelGGL); timing all ~150 launches of a proof costs ~0.7 ms of host time per proof
     for c in ctxs:
         c.profile_filter(dominant)
         c.profile(not args.no_kernel_events)

@@ -76,8 +76,9 @@ typedef struct {
     double algo_bytes;
 } zg_kernel_stat;
 int zg_ctx_profile_enable(zg_ctx *ctx, int on);
-/* Bracket only launches of the named kernel (NULL or "" = every kernel): two event records per launch
- * are cheap for one kernel, not for the ~90 launches of a whole proof. */
+/* Time only launches of the named kernel (NULL or "" = every kernel).  A timed launch carries its own start and
+ * stop event (hipExtLaunchKernelGGL): the kernel's begin and end as rocprofv3 reports them; two events per launch
+ * are cheap for one kernel, not for the ~150 launches of a whole proof. */
 int zg_ctx_profile_filter(zg_ctx *ctx, const char *kernel_name);
 int zg_ctx_profile_collect(zg_ctx *ctx, zg_kernel_stat *out, size_t cap, size_t *count);
 
