@@ -299,9 +299,12 @@ __global__ __launch_bounds__(1024) void gp_totals_kernel(Fe* __restrict__ totn, 
     shn[tid] = vn;
     shd[tid] = vd;
     __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
+    // (entries at and beyond nblk are ones: the scan only has to span the block totals)
+    uint32_t span = 64;
+    while (span < nblk) span <<= 1;
+    for (uint32_t off = 1; off < span; off <<= 1) {
         Fe pn = Fr::one(), pd = Fr::one();
-        const bool hn = tid >= off, hd = tid + off < 1024;
+        const bool hn = tid >= off && tid < span, hd = tid + off < span;
         if (hn) pn = shn[tid - off];
         if (hd) pd = shd[tid + off];
         __syncthreads();
