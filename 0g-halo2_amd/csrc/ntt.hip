@@ -590,13 +590,15 @@ static int ensure_lds_attr() {
 
 // Device-resident batched transform, in place on d_a (through a workspace copy when two passes
 // are needed).
-int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
-                  const Fe* divisor) {
+// d_out <- NTT(d_in), both [batch][stride]; d_out may be d_in.  (The first pass reads d_in, the last one writes
+// d_out: a caller that needs the input afterwards saves itself a copy.)
+int ntt_batch_to_dev(zg_ctx* ctx, const Fe* d_in, Fe* d_out, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
+                     const Fe* divisor) {
     ZG_TRY(ensure_lds_attr());
     WsScope ws(ctx);
     NttPlan p;
-    p.in = d_a; p.in_stride = stride;
-    p.out = d_a; p.out_stride = stride;
+    p.in = d_in; p.in_stride = stride;
+    p.out = d_out; p.out_stride = stride;
     p.batch = batch;
     p.log_n = log_n;
     p.omega = omega;
@@ -612,6 +614,11 @@ int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t lo
         if (!tmp) return ZG_ERR_OOM;
     }
     return ntt_run(ctx, p, tmp, n);
+}
+
+int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
+                  const Fe* divisor) {
+    return ntt_batch_to_dev(ctx, d_a, d_a, stride, batch, log_n, omega, divisor);
 }
 
 // hat: the evaluations come out multiplied by 2^5, i.e. in the 2^261 Montgomery form evaluate_h's

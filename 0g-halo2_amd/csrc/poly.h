@@ -45,8 +45,9 @@ struct EvalHArgs {
     const Fe* sigma_cos;
     const Fe* pz_cos;
     const Fe* lz_cos;
-    const Fe* pin_cos;
+    const Fe* pin_cos;   // lookup l's permuted input / table cosets: pin_cos + l * perm_stride, ptab_cos + l * perm_stride
     const Fe* ptab_cos;
+    size_t perm_stride;  // (2 * en when the two live interleaved in one batch, as the prover keeps them)
     const Fe* l0;
     const Fe* llast;
     const Fe* lactive;
@@ -130,6 +131,8 @@ int poly_permute_pairs(zg_ctx* ctx, const Fe* a, const Fe* t, Fe* sprime, uint32
 // from ntt.hip
 int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
                   const Fe* divisor);
+int ntt_batch_to_dev(zg_ctx* ctx, const Fe* d_in, Fe* d_out, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
+                     const Fe* divisor);
 int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
                           size_t batch, uint32_t k, uint32_t ext_k, bool hat);
 int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat);

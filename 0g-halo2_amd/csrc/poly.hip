@@ -443,8 +443,8 @@ __global__ __launch_bounds__(256) void evaluate_h_kernel(EvalHArgs a, uint32_t e
             ti = Fr::add(Fr::mul(ti, a.theta), eval_poly(c, a.cols, lk->tables[e], idx));
         }
         const Fe* zc = a.lz_cos + (size_t)l * en;
-        const Fe* ap = a.pin_cos + (size_t)l * en;
-        const Fe* sp = a.ptab_cos + (size_t)l * en;
+        const Fe* ap = a.pin_cos + (size_t)l * a.perm_stride;
+        const Fe* sp = a.ptab_cos + (size_t)l * a.perm_stride;
         const Fe z = ldg(zc + idx), apv = ldg(ap + idx), spv = ldg(sp + idx);
         value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(Fr::one(), z), l0));
         value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(Fr::sqr(z), z), llast));
@@ -632,8 +632,8 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
             ti = f9_add(Fr9::mul(ti, f9_unpack(a.theta)), eval_poly9(c, a.monos_hat, a.cols, lk->tables[e], idx));
         }
         const Fe* zc = a.lz_cos + (size_t)l * en;
-        const Fe* ap = a.pin_cos + (size_t)l * en;
-        const Fe* sp = a.ptab_cos + (size_t)l * en;
+        const Fe* ap = a.pin_cos + (size_t)l * a.perm_stride;
+        const Fe* sp = a.ptab_cos + (size_t)l * a.perm_stride;
         const F9 z = ld9(zc + idx), apv = ld9(ap + idx), spv = ld9(sp + idx);
         value = fold2(value, f9_sub(one(), z), l0());
         value = fold2(value, f9_sub(Fr9::sqr(z), z), llast());

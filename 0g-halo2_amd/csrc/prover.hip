@@ -118,7 +118,7 @@ struct zg_prover {
     Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *h = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr,
        *raw = nullptr, *sraw = nullptr, *sort_fe = nullptr;
     uint32_t *sort_u32 = nullptr, *d_err = nullptr;
-    Fe *pin_cos_c = nullptr, *ptab_cos_c = nullptr, *pin_c = nullptr, *ptab_c = nullptr;
+    Fe *pin_c = nullptr, *ptab_c = nullptr;
     XYZZ* xyzz = nullptr;
     uint32_t* d_idx = nullptr;
     Fe* ktmp = nullptr;
@@ -517,8 +517,6 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_TRY(dalloc(p, &p->pz_cos, (size_t)S * en));
     ZG_TRY(dalloc(p, &p->lz_cos, (size_t)NL * en));
     ZG_TRY(dalloc(p, &p->perm_cos, (size_t)2 * NL * en));
-    ZG_TRY(dalloc(p, &p->pin_cos_c, (size_t)NL * en));
-    ZG_TRY(dalloc(p, &p->ptab_cos_c, (size_t)NL * en));
     ZG_TRY(dalloc(p, &p->pin_c, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->ptab_c, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->cin, (size_t)NL * n));
@@ -551,8 +549,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     if (F) {
         ZG_HIP(hipMemcpyAsync(p->fixed_val, fixed_values, (size_t)F * n * 32, hipMemcpyHostToDevice, st));
         Fe* fp = p->polys + (size_t)p->ix_fixed * n;
-        ZG_HIP(hipMemcpyAsync(fp, p->fixed_val, (size_t)F * n * 32, hipMemcpyDeviceToDevice, st));
-        ZG_TRY(ntt_batch_dev(ctx, fp, n, F, p->k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(ntt_batch_to_dev(ctx, p->fixed_val, fp, n, F, p->k, p->omega_inv, &p->ifft_div));
         ZG_TRY(coeff_to_extended_dev(ctx, fp, n, p->fixed_cos, en, F, p->k, p->ext_k, p->hat));
     }
     if (p->hat) {
@@ -574,8 +571,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     if (P) {
         ZG_HIP(hipMemcpyAsync(p->sigma_val, sigma_values, (size_t)P * n * 32, hipMemcpyHostToDevice, st));
         Fe* sp = p->polys + (size_t)p->ix_sigma * n;
-        ZG_HIP(hipMemcpyAsync(sp, p->sigma_val, (size_t)P * n * 32, hipMemcpyDeviceToDevice, st));
-        ZG_TRY(ntt_batch_dev(ctx, sp, n, P, p->k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(ntt_batch_to_dev(ctx, p->sigma_val, sp, n, P, p->k, p->omega_inv, &p->ifft_div));
         ZG_TRY(coeff_to_extended_dev(ctx, sp, n, p->sigma_cos, en, P, p->k, p->ext_k, p->hat));
     }
     {
@@ -677,15 +673,13 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     if (A) ZG_TRY(poly_blind_rows(ctx, adv, n, A, usable, bf + 1, seed, TAG_ADVICE_BLIND));
     ZG_TRY(fork());
     if (I) {
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_inst), p->inst_val, (size_t)I * n * 32, hipMemcpyDeviceToDevice, ss));
-        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
         ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_inst), n, p->inst_cos, en, I, k, ek, p->hat));
     }
     if (A) {
         ZG_TRY(msm_batch_dev(ctx, p->gl, adv, n, A, n, p->xyzz));
         ZG_TRY(fetch_points(p, A, pts));
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_adv), adv, (size_t)A * n * 32, hipMemcpyDeviceToDevice, ss));
-        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(ntt_batch_to_dev(sx, adv, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
         ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_adv), n, p->adv_cos, en, A, k, ek, p->hat));
         ZG_TRY(wait_points(p, A, pts));
         for (auto& q : pts) tr.write_point(q);
@@ -723,14 +717,8 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pinned_cap - 256);
         ZG_HIP(hipMemcpyAsync(h_err, p->d_err, NL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_perm), p->perm, (size_t)2 * NL * n * 32, hipMemcpyDeviceToDevice, ss));
-        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(ntt_batch_to_dev(sx, p->perm, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
         ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_perm), n, p->perm_cos, en, 2 * NL, k, ek, p->hat));
-        // evaluate_h wants a'_l and s'_l cosets in separate [l] slabs
-        for (uint32_t l = 0; l < NL; l++) {
-            ZG_HIP(hipMemcpyAsync(p->pin_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, ss));
-            ZG_HIP(hipMemcpyAsync(p->ptab_cos_c + (size_t)l * en, p->perm_cos + (size_t)(2 * l + 1) * en, (size_t)en * 32, hipMemcpyDeviceToDevice, ss));
-        }
         ZG_TRY(wait_points(p, 2 * NL + 1, pts));
         for (uint32_t l = 0; l < NL; l++)
             if (h_err[l]) {
@@ -769,8 +757,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         }
         const uint32_t npts = S + NL + (have_random ? 0 : 1);
         ZG_TRY(fetch_points(p, npts, pts));
-        ZG_HIP(hipMemcpyAsync(poly_at(p->ix_pz), p->zs, (size_t)(S + NL) * n * 32, hipMemcpyDeviceToDevice, ss));
-        ZG_TRY(ntt_batch_dev(sx, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
+        ZG_TRY(ntt_batch_to_dev(sx, p->zs, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
         if (S) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_pz), n, p->pz_cos, en, S, k, ek, p->hat));
         if (NL) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_lz), n, p->lz_cos, en, NL, k, ek, p->hat));
         ZG_TRY(wait_points(p, npts, pts));
@@ -799,8 +786,8 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         a.cols.fixed = p->fixed_cos; a.cols.advice = p->adv_cos; a.cols.instance = p->inst_cos;
         a.cols.log_size = ek; a.cols.rot_scale = (int32_t)(en / n);
         a.sigma_cos = p->sigma_cos; a.pz_cos = p->pz_cos; a.lz_cos = p->lz_cos;
-        // perm_cos is interleaved [2l] = a', [2l+1] = s': the kernel wants [l] strides -> separate views
-        a.pin_cos = p->pin_cos_c; a.ptab_cos = p->ptab_cos_c;
+        // perm_cos is interleaved, [2l] = a'_l and [2l+1] = s'_l: two views with a stride of two slabs
+        a.pin_cos = p->perm_cos; a.ptab_cos = p->perm_cos + en; a.perm_stride = (size_t)2 * en;
         a.l0 = p->l0; a.llast = p->llast; a.lactive = p->lactive;
         a.ext_tw = p->hat ? p->ext_tw + en : p->ext_tw;  // (the twiddle table's second half is the 2^261 form)
         a.t_eval = p->t_eval; a.t_mask = (1u << (ek - k)) - 1;
