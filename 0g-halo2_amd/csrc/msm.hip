@@ -166,26 +166,16 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t* __restri
     for (uint32_t k = tid; k <= nb; k += 1024) cb[k] = hist[k];
 }
 
-// Bucket totals over the windows: tot[b][k] = sum_w cnt[b][w][k]   (grid-parallel, coalesced)
-__global__ __launch_bounds__(256) void msm_totals_kernel(const uint32_t* __restrict__ cnt, uint32_t c, uint32_t windows,
-                                                         uint32_t* __restrict__ tot) {
-    const uint32_t nb = 1u << (c - 1);
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (k > nb) return;
-    const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
-    uint32_t v = 0;
-#pragma unroll 8
-    for (uint32_t w = 0; w < windows; w++) v += cb[(size_t)w * (nb + 1) + k];  // independent loads
-    tot[(size_t)b * (nb + 2) + k] = v;
-}
-
-// Per vector: exclusive scans of the bucket totals (entry offsets, in place) and of ceil(total/K)
-// (task offsets), and the list of hot buckets.  One 1024-lane workgroup per vector; the totals are
-// staged in LDS (coalesced in, coalesced out) so that the per-lane strips do not walk HBM.
-__global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t c, uint32_t* __restrict__ toff, uint32_t* __restrict__ tot,
+// Per vector, one 1024-lane workgroup: bucket totals over the windows (tot[k] = sum_w cnt[w][k]), their
+// exclusive scan (entry offsets) and that of ceil(total/K) (task offsets), the list of hot buckets, and the
+// absolute offset of every (window, bucket) cell, off[w][k] = tot[k] + sum_{w' < w} cnt[w'][k].  The totals
+// are staged in LDS (coalesced in, coalesced out) so that the per-lane strips do not walk HBM.  (Three
+// kernels once; under 16 proof streams every launch costs a stream ~0.1 ms of waiting, whatever its size.)
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ cnt, uint32_t c, uint32_t windows,
+                                                        uint32_t* __restrict__ toff, uint32_t* __restrict__ tot,
                                                         uint32_t* __restrict__ ttotal, uint32_t* __restrict__ hmap,
                                                         uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
-                                                        uint32_t max_heavy) {
+                                                        uint32_t max_heavy, uint32_t* __restrict__ off) {
     extern __shared__ uint32_t scan_smem[];  // [nb+2] bucket totals -> entry offsets
     __shared__ uint32_t se[1024], st[1024];
     __shared__ uint32_t hcount;
@@ -195,7 +185,13 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t c, uint32_t* __
     uint32_t* tt = tot + (size_t)b * (nb + 2);
     uint32_t* le = scan_smem;
     if (tid == 0) hcount = 0;
-    for (uint32_t k = tid; k <= nb; k += 1024) le[k] = tt[k];
+    const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
+    for (uint32_t k = tid; k <= nb; k += 1024) {
+        uint32_t v = 0;
+#pragma unroll 8
+        for (uint32_t w = 0; w < windows; w++) v += cb[(size_t)w * (nb + 1) + k];  // independent, coalesced loads
+        le[k] = v;
+    }
     __syncthreads();
     const uint32_t per = (nb + 1 + 1023) / 1024;
     uint32_t lo = tid * per, hi = lo + per;
@@ -246,22 +242,15 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t c, uint32_t* __
     }
     __syncthreads();
     for (uint32_t k = tid; k <= nb + 1; k += 1024) tt[k] = le[k];
-}
-
-// Absolute offset of every (window, bucket) cell: off[b][w][k] = tot[b][k] + sum_{w' < w} cnt[b][w'][k]
-__global__ __launch_bounds__(256) void msm_offsets_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ tot,
-                                                          uint32_t c, uint32_t windows, uint32_t* __restrict__ off) {
-    const uint32_t nb = 1u << (c - 1);
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
-    if (k > nb) return;
-    const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
     uint32_t* ob = off + (size_t)b * windows * (nb + 1);
-    uint32_t run = tot[(size_t)b * (nb + 2) + k];
+    for (uint32_t k = tid; k <= nb; k += 1024) {
+        uint32_t run = le[k];
 #pragma unroll 8
-    for (uint32_t w = 0; w < windows; w++) {
-        const uint32_t v = cb[(size_t)w * (nb + 1) + k];
-        ob[(size_t)w * (nb + 1) + k] = run;
-        run += v;
+        for (uint32_t w = 0; w < windows; w++) {
+            const uint32_t v = cb[(size_t)w * (nb + 1) + k];
+            ob[(size_t)w * (nb + 1) + k] = run;
+            run += v;
+        }
     }
 }
 
@@ -653,11 +642,8 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               W, tbits, dig);
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
-    ZG_LAUNCH(ctx, "msm_totals", msm_bytes, msm_totals_kernel, dim3((nb + 1 + 255) / 256, B), dim3(256), 0, cnt, c, W, tot);
-    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, c, toff, tot, ttotal,
-              hmap, hlist, nheavy, max_heavy);
-    ZG_LAUNCH(ctx, "msm_offsets", msm_bytes, msm_offsets_kernel, dim3((nb + 1 + 255) / 256, B), dim3(256), 0, cnt, tot, c, W,
-              off);
+    ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
+              ttotal, hmap, hlist, nheavy, max_heavy, off);
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted);
     if (ctx->msm_pair) {

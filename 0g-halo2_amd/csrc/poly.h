@@ -97,8 +97,8 @@ int poly_to_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
 int poly_from_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
 int poly_from_raw_rows(zg_ctx* ctx, const Fe* src, size_t src_stride, Fe* dst, size_t dst_stride, uint32_t rows,
                        uint32_t len);
-int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab, const Fe& beta,
-                      const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups);
+int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab, size_t perm_stride,
+                      const Fe& beta, const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups);
 int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe* sigma_val, const Fe* omega_tw,
                     const Fe& beta, const Fe& gamma, Fe* num, Fe* den, uint32_t n);
 // z[b][0] = z0[b] (device array, or all ones if null), z[b][i+1] = z[b][i]*num[b][i]/den[b][i]; the first

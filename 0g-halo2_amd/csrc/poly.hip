@@ -178,20 +178,21 @@ int poly_from_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count) {
 
 // ------------------------------------------------------------------ grand-product terms
 // lookup commit_product: den = (a' + beta)(s' + gamma), num = (A + beta)(S + gamma)
+// (lookup l = blockIdx.y: compressed columns and outputs at l * n, permuted columns at l * perm_stride)
 __global__ __launch_bounds__(256) void lookup_terms_kernel(const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab,
-                                                           Fe beta, Fe gamma, Fe* num, Fe* den, uint32_t n) {
+                                                           size_t perm_stride, Fe beta, Fe gamma, Fe* num, Fe* den, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    size_t o = (size_t)blockIdx.y * n + i;
-    stg(den + o, Fr::mul(Fr::add(ldg(pin + o), beta), Fr::add(ldg(ptab + o), gamma)));
+    size_t o = (size_t)blockIdx.y * n + i, po = (size_t)blockIdx.y * perm_stride + i;
+    stg(den + o, Fr::mul(Fr::add(ldg(pin + po), beta), Fr::add(ldg(ptab + po), gamma)));
     stg(num + o, Fr::mul(Fr::add(ldg(cin + o), beta), Fr::add(ldg(ctab + o), gamma)));
 }
 
-int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab, const Fe& beta,
-                      const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups) {
+int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab, size_t perm_stride,
+                      const Fe& beta, const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups) {
     if (!n_lookups) return ZG_OK;
     ZG_LAUNCH(ctx, "lookup_terms", (double)n_lookups * n * 192, lookup_terms_kernel, dim3((n + 255) / 256, n_lookups),
-              dim3(256), 0, cin, ctab, pin, ptab, beta, gamma, num, den, n);
+              dim3(256), 0, cin, ctab, pin, ptab, perm_stride, beta, gamma, num, den, n);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -738,10 +738,9 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     Fe* pz = p->zs;
     Fe* lz = p->zs + (size_t)S * n;
     if (S) ZG_TRY(poly_perm_terms(ctx, p->dc, base_cols, p->sigma_val, p->omega_tw, beta, gamma, p->num, p->den, n));
-    for (uint32_t l = 0; l < NL; l++)  // a'_l / s'_l are interleaved in `perm`
-        ZG_TRY(poly_lookup_terms(ctx, p->cin + (size_t)l * n, p->ctab + (size_t)l * n, p->perm + (size_t)(2 * l) * n,
-                                 p->perm + (size_t)(2 * l + 1) * n, beta, gamma, p->num + (size_t)(S + l) * n,
-                                 p->den + (size_t)(S + l) * n, n, 1));
+    // (a'_l / s'_l are interleaved in `perm`: two views with a stride of two columns)
+    ZG_TRY(poly_lookup_terms(ctx, p->cin, p->ctab, p->perm, p->perm + n, (size_t)2 * n, beta, gamma, p->num + (size_t)S * n,
+                             p->den + (size_t)S * n, n, NL));
     if (S + NL) {
         // all running products of the proof in one scan sequence; the S permutation sets are chained
         // through row n - bf - 1, the lookup products start from one
