@@ -93,6 +93,7 @@ struct zg_ctx {
     zg_ctx* side = nullptr;  // optional second stream + workspace pool (created on demand, same device)
     // MSM bucket reduction with two lanes per EC addition (latency) or one (throughput); see msm.hip
     bool msm_pair = true;
+    uint32_t* msm_tickets = nullptr;  // last-workgroup-done counters of the MSM reduction (msm.hip), zero between launches
 };
 
 struct zg_bases {

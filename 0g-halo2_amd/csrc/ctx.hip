@@ -137,6 +137,7 @@ void zg_ctx_destroy(zg_ctx* ctx) {
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto& b : ctx->pool) (void)hipFree(b.p);
+    if (ctx->msm_tickets) (void)hipFree(ctx->msm_tickets);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
 // sum_k k*B_k = sum_k S_k with S_k = sum_{k' >= k} B_k' (the classic running sum of running sums), cut
 // into blocks of 256 buckets so that it parallelises (msm_bucket_scan / msm_bucket_sum / msm_finish).
 constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
+constexpr uint32_t MSM_MAX_BATCH = 4096;  // vectors per batched MSM call
 
 // All four reduction kernels are templated on L, the lanes per addition: 1 (throughput: least work), or 2 / 4
 // (field9.h `xadd<true>`, `xadd4`: seven / four dependent products per lane instead of fourteen; the
@@ -463,7 +464,8 @@ template <int L, uint32_t RB>
 __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __restrict__ sfx,
                                                                                    const XYZZ9* __restrict__ blk_p,
                                                                                    XYZZ9* __restrict__ blk_w,
-                                                                                   uint32_t nblk) {
+                                                                                   uint32_t nblk, uint32_t* __restrict__ tickets,
+                                                                                   XYZZ* __restrict__ out) {
     __shared__ XYZZ9 sh[RB];
     __shared__ XYZZ9 bs;
     const uint32_t j = threadIdx.x / L, role = threadIdx.x % L;
@@ -487,27 +489,24 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
     else sh[j] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * RB + j), bs);
     __syncthreads();
     for (uint32_t o = RB / 2; o > 0; o >>= 1) tree_step(o);
-    if (threadIdx.x == 0) st_xyzz9(blk_w + (size_t)b * nblk + blk, sh[0]);
-}
-
-// result = sum_blk W'_blk
-template <int L>
-__global__ __launch_bounds__(256 * L) void msm_finish_kernel(const XYZZ9* __restrict__ blk_w, uint32_t nblk,
-                                                                      XYZZ* __restrict__ out) {
-    __shared__ XYZZ9 sh[256];
-    const uint32_t j = threadIdx.x / L, role = threadIdx.x % L, b = blockIdx.x;
-    if (role == 0) sh[j] = j < nblk ? ld_xyzz9(blk_w + (size_t)b * nblk + j) : xyzz9_identity();
-    __syncthreads();
-    uint32_t span = 1;
-    while (span < nblk) span <<= 1;
-    for (uint32_t o = span / 2; o > 0; o >>= 1) {
-        if (j < o) {
-            if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(&sh[j], &sh[j + o], role));
-            else sh[j] = xyzz9_add(sh[j], sh[j + o]);
-        }
-        __syncthreads();
+    // result = sum_blk W'_blk, by whichever workgroup of the vector finishes last (a ticket per vector; every
+    // writer makes its W' visible device-wide before taking one, the last one re-reads them after its own)
+    __shared__ uint32_t ticket;
+    if (threadIdx.x == 0) {
+        st_xyzz9(blk_w + (size_t)b * nblk + blk, sh[0]);
+        __threadfence();
+        ticket = atomicAdd(tickets + b, 1u);
     }
-    if (threadIdx.x == 0) st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
+    __syncthreads();
+    if (ticket != nblk - 1) return;  // (uniform over the workgroup)
+    __threadfence();
+    if (role == 0) sh[j] = j < nblk ? ld_xyzz9(blk_w + (size_t)b * nblk + j) : xyzz9_identity();  // nblk <= RB
+    __syncthreads();
+    for (uint32_t o = span / 2; o > 0; o >>= 1) tree_step(o);
+    if (threadIdx.x == 0) {
+        st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
+        tickets[b] = 0;                                  // ready for the next launch on this stream
+    }
 }
 
 static uint32_t default_window_bits(size_t n) {
@@ -600,6 +599,11 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     const uint32_t nblk = (nb + rb - 1) / rb;
     ZG_REQUIRE(nblk <= 256 && nblk <= rb, ZG_ERR_UNSUPPORTED, "zg_msm: window_bits %u too large", c);
 
+    if (!ctx->msm_tickets) {  // one ticket counter per vector of a batch; the kernels leave them at zero
+        ZG_HIP(hipMalloc(&ctx->msm_tickets, MSM_MAX_BATCH * sizeof(uint32_t)));
+        ZG_HIP(hipMemset(ctx->msm_tickets, 0, MSM_MAX_BATCH * sizeof(uint32_t)));
+    }
+    ZG_REQUIRE(B <= MSM_MAX_BATCH, ZG_ERR_UNSUPPORTED, "zg_msm: batch of %u vectors", (unsigned)B);
     WsScope ws(ctx);
     uint32_t* dig = ws.get<uint32_t>((size_t)B * entries);
     uint32_t* cnt = ws.get<uint32_t>((size_t)B * W * (nb + 1));
@@ -665,7 +669,7 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
             ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<L, RB>), dim3(nblk, B), dim3(L * RB), 0,
                       partial, toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
             ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<L, RB>), dim3(nblk, B), dim3(L * RB), 0, sfx,
-                      blk_p, blk_w, nblk);
+                      blk_p, blk_w, nblk, ctx->msm_tickets, d_out);
         };
         using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>;
@@ -675,15 +679,13 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         else if (rb == 128 && lanes == 4) reduce(I4{}, std::integral_constant<uint32_t, 128>{});
         else if (rb == 128) reduce(I2{}, std::integral_constant<uint32_t, 128>{});
         else reduce(I2{}, std::integral_constant<uint32_t, MSM_RB>{});
-        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<2>, dim3(B), dim3(512), 0, blk_w, nblk, d_out);
     } else {
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<1>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
         ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
                   toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
         ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
-                  blk_w, nblk);
-        ZG_LAUNCH(ctx, "msm_finish", msm_bytes, msm_finish_kernel<1>, dim3(B), dim3(256), 0, blk_w, nblk, d_out);
+                  blk_w, nblk, ctx->msm_tickets, d_out);
     }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
