@@ -93,6 +93,10 @@ int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, ui
 int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag);
 int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe& theta, Fe* cin, Fe* ctab,
                          uint32_t n);
+int poly_blind_rows2(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols0, uint32_t tag0, uint32_t ncols1, uint32_t tag1,
+                     uint32_t row0, uint32_t nrows, uint64_t seed);
+int poly_permuted_finish(zg_ctx* ctx, const Fe* raw_in, const Fe* raw_tab, Fe* perm, uint32_t n, uint32_t usable,
+                         uint32_t nblind, uint32_t n_lookups, uint64_t seed, uint32_t tag_in, uint32_t tag_tab);
 int poly_to_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
 int poly_from_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count);
 int poly_from_raw_rows(zg_ctx* ctx, const Fe* src, size_t src_stride, Fe* dst, size_t dst_stride, uint32_t rows,
@@ -115,6 +119,10 @@ int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint
 // out[i] = sum_j horner in `v` over the polys listed (first listed = highest power), then out[0] -= sub
 int poly_horner_combine(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_list, uint32_t count,
                         const Fe& v, const Fe& sub, Fe* out, uint32_t n);
+constexpr uint32_t HC_MAX_SETS = 8;
+int poly_horner_combine_sets(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_lists, uint32_t list_stride,
+                             const uint32_t* counts, const Fe* subs, uint32_t nsets, const Fe& v, Fe* out, size_t out_stride,
+                             uint32_t n);
 size_t poly_kate_tmp_elems(uint32_t n, uint32_t batch);
 int poly_kate_division(zg_ctx* ctx, const Fe* a, size_t a_stride, const Fe* zs_host, Fe* q, size_t q_stride, Fe* tmp,
                        uint32_t n, uint32_t batch);

@@ -58,12 +58,15 @@ __host__ __device__ __forceinline__ Fe rand_fr(uint64_t seed, uint32_t tag, uint
     return Fr::from_raw(v);
 }
 
+// columns [0, ncols0) draw from tag0 (index c * nrows + j), columns [ncols0, ncols) from tag1 (index restarts)
 __global__ void blind_rows_kernel(Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
-                                  uint64_t seed, uint32_t tag) {
+                                  uint64_t seed, uint32_t tag0, uint32_t ncols0, uint32_t tag1) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ncols * nrows) return;
     uint32_t c = t / nrows, j = t % nrows;
-    stg(base + (size_t)c * col_stride + row0 + j, rand_fr(seed, tag, (uint64_t)c * nrows + j));
+    const bool second = c >= ncols0;
+    stg(base + (size_t)c * col_stride + row0 + j,
+        rand_fr(seed, second ? tag1 : tag0, (uint64_t)(second ? c - ncols0 : c) * nrows + j));
 }
 
 __global__ void random_kernel(Fe* out, uint32_t n, uint64_t seed, uint32_t tag) {
@@ -71,14 +74,18 @@ __global__ void random_kernel(Fe* out, uint32_t n, uint64_t seed, uint32_t tag) 
     if (i < n) stg(out + i, rand_fr(seed, tag, i));
 }
 
-int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
-                    uint64_t seed, uint32_t tag) {
-    uint32_t total = ncols * nrows;
+int poly_blind_rows2(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols0, uint32_t tag0, uint32_t ncols1, uint32_t tag1,
+                     uint32_t row0, uint32_t nrows, uint64_t seed) {
+    uint32_t total = (ncols0 + ncols1) * nrows;
     if (total == 0) return ZG_OK;
-    ZG_LAUNCH(ctx, "blind_rows", 0, blind_rows_kernel, dim3((total + 63) / 64), dim3(64), 0, base, col_stride, ncols,
-              row0, nrows, seed, tag);
+    ZG_LAUNCH(ctx, "blind_rows", 0, blind_rows_kernel, dim3((total + 63) / 64), dim3(64), 0, base, col_stride, ncols0 + ncols1,
+              row0, nrows, seed, tag0, ncols0, tag1);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
+}
+int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
+                    uint64_t seed, uint32_t tag) {
+    return poly_blind_rows2(ctx, base, col_stride, ncols, tag, 0, tag, row0, nrows, seed);
 }
 
 int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag) {
@@ -159,6 +166,34 @@ int poly_from_raw_rows(zg_ctx* ctx, const Fe* src, size_t src_stride, Fe* dst, s
     if (!rows || !len) return ZG_OK;
     ZG_LAUNCH(ctx, "from_raw", (double)rows * len * 64, from_raw_rows_kernel, dim3((len + 255) / 256, rows), dim3(256), 0, src,
               src_stride, dst, dst_stride, len);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+// lookup commit_permuted's last step in one launch: perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form) on
+// the usable rows [0, usable), blinding scalars on the rows after them (tag_in / tag_tab, index = l * nblind + j)
+__global__ __launch_bounds__(256) void permuted_finish_kernel(const Fe* __restrict__ raw_in, const Fe* __restrict__ raw_tab,
+                                                              Fe* __restrict__ perm, uint32_t n, uint32_t usable, uint32_t nblind,
+                                                              uint64_t seed, uint32_t tag_in, uint32_t tag_tab) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+    if (i >= usable + nblind) return;
+    Fe* a = perm + (size_t)(2 * l) * n;
+    Fe* t = a + n;
+    if (i < usable) {
+        stg(a + i, Fr::from_raw(ldg(raw_in + (size_t)l * n + i)));
+        stg(t + i, Fr::from_raw(ldg(raw_tab + (size_t)l * n + i)));
+    } else {
+        const uint64_t idx = (uint64_t)l * nblind + (i - usable);
+        stg(a + i, rand_fr(seed, tag_in, idx));
+        stg(t + i, rand_fr(seed, tag_tab, idx));
+    }
+}
+int poly_permuted_finish(zg_ctx* ctx, const Fe* raw_in, const Fe* raw_tab, Fe* perm, uint32_t n, uint32_t usable,
+                         uint32_t nblind, uint32_t n_lookups, uint64_t seed, uint32_t tag_in, uint32_t tag_tab) {
+    if (!n_lookups) return ZG_OK;
+    ZG_REQUIRE(usable + nblind <= n, ZG_ERR_INVALID_ARG, "poly_permuted_finish: %u + %u rows of %u", usable, nblind, n);
+    ZG_LAUNCH(ctx, "permuted_finish", (double)n_lookups * n * 128, permuted_finish_kernel, dim3((usable + nblind + 255) / 256, n_lookups),
+              dim3(256), 0, raw_in, raw_tab, perm, n, usable, nblind, seed, tag_in, tag_tab);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -739,6 +774,45 @@ int poly_horner_combine(zg_ctx* ctx, const Fe* polys, size_t stride, const uint3
                         const Fe& v, const Fe& sub, Fe* out, uint32_t n) {
     ZG_LAUNCH(ctx, "horner_combine", (double)(count + 1) * n * 32, horner_combine_kernel, dim3((n + 255) / 256), dim3(256),
               0, polys, stride, d_list, count, v, sub, out, n);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+// the same for up to HC_MAX_SETS lists at once (GWC: one list per opening point): set s = blockIdx.y reads
+// lists + s * list_stride and writes out + s * out_stride
+struct HornerSets {
+    uint32_t count[HC_MAX_SETS];
+    Fe sub[HC_MAX_SETS];
+};
+__global__ __launch_bounds__(256) void horner_combine_sets_kernel(const Fe* __restrict__ polys, size_t stride,
+                                                                  const uint32_t* __restrict__ lists, uint32_t list_stride,
+                                                                  HornerSets sets, Fe v, Fe* __restrict__ out, size_t out_stride,
+                                                                  uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (i >= n) return;
+    const uint32_t* list = lists + (size_t)s * list_stride;
+    const uint32_t count = sets.count[s];
+    Fe acc = fe_zero();
+    for (uint32_t j = 0; j < count; j++) acc = Fr::add(Fr::mul(acc, v), ldg(polys + (size_t)list[j] * stride + i));
+    if (i == 0) acc = Fr::sub(acc, sets.sub[s]);
+    stg(out + (size_t)s * out_stride + i, acc);
+}
+
+int poly_horner_combine_sets(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_lists, uint32_t list_stride,
+                             const uint32_t* counts, const Fe* subs, uint32_t nsets, const Fe& v, Fe* out, size_t out_stride,
+                             uint32_t n) {
+    if (!nsets) return ZG_OK;
+    ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "poly_horner_combine_sets: %u sets", nsets);
+    HornerSets sets;
+    memset(&sets, 0, sizeof(sets));
+    double total = 0;
+    for (uint32_t s = 0; s < nsets; s++) {
+        sets.count[s] = counts[s];
+        sets.sub[s] = subs[s];
+        total += counts[s] + 1;
+    }
+    ZG_LAUNCH(ctx, "horner_combine", total * n * 32, horner_combine_sets_kernel, dim3((n + 255) / 256, nsets), dim3(256), 0, polys,
+              stride, d_lists, list_stride, sets, v, out, out_stride, n);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

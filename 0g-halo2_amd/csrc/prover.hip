@@ -519,8 +519,8 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_TRY(dalloc(p, &p->perm_cos, (size_t)2 * NL * en));
     ZG_TRY(dalloc(p, &p->pin_c, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->ptab_c, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->cin, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->ctab, (size_t)NL * n));
+    ZG_TRY(dalloc(p, &p->cin, (size_t)2 * NL * n));  // compressed inputs, then compressed tables
+    p->ctab = p->cin + (size_t)NL * n;
     ZG_TRY(dalloc(p, &p->perm, (size_t)(2 * NL + 1) * n));  // + the vanishing argument's random polynomial
     ZG_TRY(dalloc(p, &p->zs, (size_t)(S + NL + 1) * n));
     const uint32_t mb = S + NL;
@@ -698,20 +698,17 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_TRY(poly_lookup_compress(ctx, p->dc, base_cols, theta, p->cin, p->ctab, n));
         // permute_expression_pair on the device: canonical keys, bitonic sort of inputs and tables,
         // scan-based construction of s' (sort.hip).  raw rows [0,NL) = inputs -> a', [NL,2NL) = tables.
-        ZG_TRY(poly_to_raw(ctx, p->cin, p->raw, (size_t)NL * n));
-        ZG_TRY(poly_to_raw(ctx, p->ctab, p->raw + (size_t)NL * n, (size_t)NL * n));
+        ZG_TRY(poly_to_raw(ctx, p->cin, p->raw, (size_t)2 * NL * n));  // (ctab follows cin)
         auto t_sort = clk::now();
         ZG_TRY(poly_sort_pad(ctx, p->raw, n, usable, 2 * NL));
         ZG_TRY(poly_sort_keys(ctx, p->raw, n, 2 * NL));
         ZG_TRY(poly_permute_pairs(ctx, p->raw, p->raw + (size_t)NL * n, p->sraw, n, usable, NL, p->sort_u32, p->sort_fe,
                                   p->d_err));
         // perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form) on the usable rows, then the blinding tail
-        ZG_TRY(poly_from_raw_rows(ctx, p->raw, n, p->perm, (size_t)2 * n, NL, usable));
-        ZG_TRY(poly_from_raw_rows(ctx, p->sraw, n, p->perm + n, (size_t)2 * n, NL, usable));
+        // (blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j)
+        ZG_TRY(poly_permuted_finish(ctx, p->raw, p->sraw, p->perm, n, usable, bf + 1, NL, seed, TAG_PERMUTED_INPUT,
+                                    TAG_PERMUTED_TABLE));
         p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
-        // blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j
-        ZG_TRY(poly_blind_rows(ctx, p->perm, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_INPUT));
-        ZG_TRY(poly_blind_rows(ctx, p->perm + n, (size_t)2 * n, NL, usable, bf + 1, seed, TAG_PERMUTED_TABLE));
         ZG_TRY(fork());
         ZG_TRY(msm_batch2_dev(ctx, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, n, p->xyzz));
         uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pinned_cap - 256);
@@ -745,8 +742,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         // all running products of the proof in one scan sequence; the S permutation sets are chained
         // through row n - bf - 1, the lookup products start from one
         ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, S + NL, S, n - bf - 1));
-        if (S) ZG_TRY(poly_blind_rows(ctx, pz, n, S, n - bf, bf, seed, TAG_PERM_Z));
-        if (NL) ZG_TRY(poly_blind_rows(ctx, lz, n, NL, n - bf, bf, seed, TAG_LOOKUP_Z));
+        ZG_TRY(poly_blind_rows2(ctx, pz, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf, seed));  // (lz follows pz)
         ZG_TRY(fork());
         if (have_random) {
             ZG_TRY(msm_batch_dev(ctx, p->gl, p->zs, n, S + NL, n, p->xyzz));
@@ -921,26 +917,32 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     {
         std::vector<char> done(oq.size(), 0);
         uint32_t npts = 0;
-        std::vector<uint32_t> list;
-        std::vector<Fe> open_points;
+        std::vector<uint32_t> lists, counts;  // list of point set s at lists[s * 512 ..]
+        std::vector<Fe> open_points, eval_batches;
         for (size_t first = 0; first < oq.size(); first++) {
             if (done[first]) continue;
             const uint32_t slot = oq[first].slot;
-            list.clear();
+            lists.resize((size_t)(npts + 1) * 512, 0);
+            uint32_t cnt = 0;
             Fe eval_batch = fe_zero();
             for (size_t j = first; j < oq.size(); j++) {
                 if (done[j] || oq[j].slot != slot) continue;
                 done[j] = 1;
-                list.push_back(oq[j].poly);
+                ZG_REQUIRE(cnt < 512, ZG_ERR_UNSUPPORTED, "zg_prover_prove: more than 512 polynomials opened at one point");
+                lists[(size_t)npts * 512 + cnt++] = oq[j].poly;
                 eval_batch = Fr::add(Fr::mul(eval_batch, v), oq[j].eval);
             }
-            ZG_REQUIRE(list.size() <= 512, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %zu polynomials opened at one point", list.size());
-            uint32_t* dl = p->d_idx + (size_t)npts * 512;
-            ZG_TRY(h2d(p, dl, list.data(), list.size() * 4));
-            Fe* batch = p->wpoly + (size_t)(2 * npts) * n;
-            ZG_TRY(poly_horner_combine(ctx, polys, n, dl, (uint32_t)list.size(), v, eval_batch, batch, n));
+            counts.push_back(cnt);
+            eval_batches.push_back(eval_batch);
             open_points.push_back(points[slot]);
             npts++;
+        }
+        // poly_batch of every point set in one launch: set s -> wpoly[2s]
+        ZG_TRY(h2d(p, p->d_idx, lists.data(), lists.size() * 4));
+        for (uint32_t s0 = 0; s0 < npts; s0 += HC_MAX_SETS) {
+            const uint32_t m = std::min<uint32_t>(HC_MAX_SETS, npts - s0);
+            ZG_TRY(poly_horner_combine_sets(ctx, polys, n, p->d_idx + (size_t)s0 * 512, 512, counts.data() + s0,
+                                            eval_batches.data() + s0, m, v, p->wpoly + (size_t)(2 * s0) * n, (size_t)2 * n, n));
         }
         // one batched kate_division: poly j at wpoly[2j], quotient at wpoly[2j+1]
         const Fe* op_pinned = (const Fe*)stage(p, open_points.data(), open_points.size() * sizeof(Fe));
