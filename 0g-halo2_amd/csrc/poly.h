@@ -90,7 +90,7 @@ enum {
 // ---- launch helpers (all asynchronous on ctx->stream) ----
 int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
                     uint64_t seed, uint32_t tag);
-int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag);
+int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag, Fe* out2 = nullptr);  // out2: a second copy
 int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe& theta, Fe* cin, Fe* ctab,
                          uint32_t n);
 int poly_blind_rows2(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols0, uint32_t tag0, uint32_t ncols1, uint32_t tag1,

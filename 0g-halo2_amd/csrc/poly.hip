@@ -69,9 +69,12 @@ __global__ void blind_rows_kernel(Fe* base, size_t col_stride, uint32_t ncols, u
         rand_fr(seed, second ? tag1 : tag0, (uint64_t)(second ? c - ncols0 : c) * nrows + j));
 }
 
-__global__ void random_kernel(Fe* out, uint32_t n, uint64_t seed, uint32_t tag) {
+__global__ void random_kernel(Fe* out, Fe* out2, uint32_t n, uint64_t seed, uint32_t tag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) stg(out + i, rand_fr(seed, tag, i));
+    if (i >= n) return;
+    const Fe v = rand_fr(seed, tag, i);
+    stg(out + i, v);
+    if (out2) stg(out2 + i, v);
 }
 
 int poly_blind_rows2(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols0, uint32_t tag0, uint32_t ncols1, uint32_t tag1,
@@ -88,8 +91,8 @@ int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, ui
     return poly_blind_rows2(ctx, base, col_stride, ncols, tag, 0, tag, row0, nrows, seed);
 }
 
-int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag) {
-    ZG_LAUNCH(ctx, "random_poly", (double)n * 32, random_kernel, dim3((n + 255) / 256), dim3(256), 0, out, n, seed, tag);
+int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag, Fe* out2) {
+    ZG_LAUNCH(ctx, "random_poly", (double)n * 32, random_kernel, dim3((n + 255) / 256), dim3(256), 0, out, out2, n, seed, tag);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

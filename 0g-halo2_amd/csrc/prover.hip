@@ -121,6 +121,8 @@ struct zg_prover {
     Fe *pin_c = nullptr, *ptab_c = nullptr;
     XYZZ* xyzz = nullptr;
     uint32_t* d_idx = nullptr;
+    std::map<uint32_t*, std::vector<uint32_t>> uploaded_lists;  // what h2d_list left at each destination
+    size_t inst_filled = 0;  // rows of inst_val that may be non-zero
     Fe* ktmp = nullptr;
     hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
     void* pinned = nullptr;
@@ -171,6 +173,17 @@ void* stage(zg_prover* p, const void* src, size_t bytes) {
     memcpy(dst, src, bytes);
     p->stage_off = off + bytes;
     return dst;
+}
+// Index lists that only depend on the circuit (which polynomial is opened where) come out the same for every
+// proof: upload one when its content differs from what that destination already holds.
+int h2d_list(zg_prover* p, uint32_t* d_dst, const std::vector<uint32_t>& list) {
+    std::vector<uint32_t>& held = p->uploaded_lists[d_dst];
+    if (held == list) return ZG_OK;
+    const void* s = stage(p, list.data(), list.size() * 4);
+    ZG_HIP(hipMemcpyAsync(d_dst, s ? s : list.data(), list.size() * 4, hipMemcpyHostToDevice, p->ctx->stream));
+    if (!s) ZG_HIP(hipStreamSynchronize(p->ctx->stream));  // (the source was pageable memory of the caller)
+    held = list;
+    return ZG_OK;
 }
 int h2d(zg_prover* p, void* d_dst, const void* src, size_t bytes) {
     const void* s = stage(p, src, bytes);
@@ -512,6 +525,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_TRY(dalloc(p, &p->lactive, (size_t)en));
     ZG_TRY(dalloc(p, &p->adv_val, (size_t)A * n));
     ZG_TRY(dalloc(p, &p->inst_val, (size_t)I * n));
+    if (I) ZG_HIP(hipMemset(p->inst_val, 0, (size_t)I * n * 32));  // rows past the instance stay zero (prove refills only what it must)
     ZG_TRY(dalloc(p, &p->adv_cos, (size_t)A * en));
     ZG_TRY(dalloc(p, &p->inst_cos, (size_t)I * en));
     ZG_TRY(dalloc(p, &p->pz_cos, (size_t)S * en));
@@ -531,8 +545,8 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_TRY(dalloc(p, &p->raw, (size_t)2 * NL * n));
     ZG_TRY(dalloc(p, &p->sraw, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->sort_fe, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->sort_u32, (size_t)2 * NL * n + 2 * NL + 2));
-    ZG_TRY(dalloc(p, &p->d_err, NL + 1));
+    ZG_TRY(dalloc(p, &p->sort_u32, (size_t)2 * NL * n + 3 * NL + 2));
+    p->d_err = p->sort_u32 + (size_t)2 * NL * n + 2 * NL;  // behind permute_pairs' scratch: zeroed by the same fill
     ZG_REQUIRE(NL <= 60, ZG_ERR_UNSUPPORTED, "zg_prover_create: %u lookups", NL);
     const uint32_t max_points = 4 + (uint32_t)(p->advice_queries.size() + p->fixed_queries.size());
     ZG_TRY(dalloc(p, &p->pw, (size_t)max_points * n + max_points));
@@ -657,10 +671,10 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     // vanishing::Argument::commit's random polynomial depends on no challenge: generate it now and
     // commit it inside the permuted-lookup batch (coefficient basis `g` next to `g_lagrange` vectors)
     Fe* random_row = p->perm + (size_t)(2 * NL) * n;
-    ZG_TRY(poly_random(ctx, random_row, n, seed, TAG_RANDOM_POLY));
-    ZG_HIP(hipMemcpyAsync(poly_at(p->ix_random), random_row, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
+    ZG_TRY(poly_random(ctx, random_row, n, seed, TAG_RANDOM_POLY, poly_at(p->ix_random)));
     if (I) {
-        ZG_HIP(hipMemsetAsync(p->inst_val, 0, (size_t)I * n * 32, st));
+        if (p->inst_filled > instance_len) ZG_HIP(hipMemsetAsync(p->inst_val, 0, (size_t)I * n * 32, st));  // (zeroed at create)
+        p->inst_filled = instance_len;
         for (uint32_t c = 0; c < I; c++) {
             for (size_t i = 0; i < instance_len; i++) tr.common_scalar(to_fe(&instance[c * instance_len + i]));
             if (instance_len)
@@ -857,7 +871,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         std::vector<uint32_t> list(Q);
         for (uint32_t i = 0; i < Q; i++) list[i] = p->ix_hpiece + (Q - 1 - i);
         uint32_t* dl = p->d_idx + (size_t)4 * (p->advice_queries.size() + p->fixed_queries.size() + P + 3 * S + 5 * NL + 4);
-        ZG_TRY(h2d(p, dl, list.data(), Q * 4));
+        ZG_TRY(h2d_list(p, dl, list));
         ZG_TRY(poly_horner_combine(ctx, polys, n, dl, Q, xn, fe_zero(), poly_at(p->ix_hpoly), n));
     }
     {
@@ -869,7 +883,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         idx[i] = evq[i].poly;
         idx[evq.size() + i] = evq[i].slot;
     }
-    ZG_TRY(h2d(p, p->d_idx, idx.data(), idx.size() * 4));
+    ZG_TRY(h2d_list(p, p->d_idx, idx));
     ZG_TRY(poly_dot(ctx, polys, n, n, p->d_idx, p->d_idx + evq.size(), p->pw, (uint32_t)evq.size(), p->evals));
     ZG_REQUIRE(evq.size() * sizeof(Fe) <= PIN_STAGE - PIN_EVALS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: too many evaluations");
     const Fe* ev = reinterpret_cast<const Fe*>((char*)p->pinned + PIN_EVALS);
@@ -938,10 +952,12 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
             npts++;
         }
         // poly_batch of every point set in one launch: set s -> wpoly[2s]
-        ZG_TRY(h2d(p, p->d_idx, lists.data(), lists.size() * 4));
+        // (their own region of d_idx, behind the evaluation lists: nothing else writes there between proofs)
+        uint32_t* d_lists = p->d_idx + (size_t)4 * (p->advice_queries.size() + p->fixed_queries.size() + P + 3 * S + 5 * NL + 4) + 64;
+        ZG_TRY(h2d_list(p, d_lists, lists));
         for (uint32_t s0 = 0; s0 < npts; s0 += HC_MAX_SETS) {
             const uint32_t m = std::min<uint32_t>(HC_MAX_SETS, npts - s0);
-            ZG_TRY(poly_horner_combine_sets(ctx, polys, n, p->d_idx + (size_t)s0 * 512, 512, counts.data() + s0,
+            ZG_TRY(poly_horner_combine_sets(ctx, polys, n, d_lists + (size_t)s0 * 512, 512, counts.data() + s0,
                                             eval_batches.data() + s0, m, v, p->wpoly + (size_t)(2 * s0) * n, (size_t)2 * n, n));
         }
         // one batched kate_division: poly j at wpoly[2j], quotient at wpoly[2j+1]

@@ -235,15 +235,20 @@ __global__ __launch_bounds__(256) void pp_build_kernel(const Fe* __restrict__ a,
 
 // a: [batch][n] sorted inputs, t: [batch][n] sorted tables (sentinel-padded beyond `usable`);
 // sprime: [batch][n] receives s' on rows < usable.  scratch_u32: 2*batch*n + 2*batch words;
-// scratch_fe: batch*n elements.  d_err: batch words, zeroed here; bit 0 = input missing from table.
+// scratch_fe: batch*n elements.  d_err: batch words, zeroed here (in the same fill as the scratch when it
+// is scratch_u32 + 2*batch*n + 2*batch); bit 0 = input missing from table.
 int poly_permute_pairs(zg_ctx* ctx, const Fe* a, const Fe* t, Fe* sprime, uint32_t n, uint32_t usable, uint32_t batch,
                        uint32_t* scratch_u32, Fe* scratch_fe, uint32_t* d_err) {
     if (!batch) return ZG_OK;
     uint32_t* repeated = scratch_u32;
     uint32_t* consumed = repeated + (size_t)batch * n;
     uint32_t* totals = consumed + (size_t)batch * n;
-    ZG_HIP(hipMemsetAsync(consumed, 0, (size_t)batch * n * 4, ctx->stream));
-    ZG_HIP(hipMemsetAsync(d_err, 0, (size_t)batch * 4, ctx->stream));
+    if (d_err == totals + 2 * batch) {  // the caller keeps the error words behind the scratch: one fill for all of it
+        ZG_HIP(hipMemsetAsync(consumed, 0, ((size_t)batch * n + 3 * batch) * 4, ctx->stream));
+    } else {
+        ZG_HIP(hipMemsetAsync(consumed, 0, (size_t)batch * n * 4, ctx->stream));
+        ZG_HIP(hipMemsetAsync(d_err, 0, (size_t)batch * 4, ctx->stream));
+    }
     dim3 g((usable + 255) / 256, batch);
     const double bytes = (double)batch * n * 96;
     ZG_LAUNCH(ctx, "permute_flags", bytes, pp_flags_kernel, g, dim3(256), 0, a, t, n, usable, repeated, consumed, d_err);
