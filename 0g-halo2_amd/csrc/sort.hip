@@ -98,6 +98,34 @@ __global__ __launch_bounds__(256) void sort_global_kernel(Fe* keys, uint32_t n, 
     }
 }
 
+// Stage B, all of a level's global strides (size/2 .. SORT_CH) in one launch: the keys that meet through
+// those strides differ only in the `nbits` index bits [log2 SORT_CH, log2 size); a workgroup takes all 2^nbits
+// values of those bits for a run of LW = SORT_CH >> nbits consecutive low indices (2^nbits coalesced
+// segments), so the strides become LDS strides LW << p.
+__global__ __launch_bounds__(SORT_NT) void sort_global_fused_kernel(Fe* keys, uint32_t n, uint32_t size, uint32_t nbits) {
+    __shared__ Fe sh[SORT_CH];
+    const uint32_t lw_len = SORT_CH >> nbits;
+    const uint32_t top = blockIdx.x >> nbits, r = blockIdx.x & ((1u << nbits) - 1u);
+    Fe* base = keys + (size_t)blockIdx.y * n + (size_t)top * size + (size_t)r * lw_len;
+    for (uint32_t e = threadIdx.x; e < SORT_CH; e += SORT_NT) {
+        const uint32_t hb = e / lw_len, lw = e % lw_len;
+        sh[e] = ldk(base + (size_t)hb * SORT_CH + lw);
+    }
+    __syncthreads();
+    const bool asc = (top & 1u) == 0;  // bit `size` of the global index
+    for (uint32_t stride = SORT_CH >> 1; stride >= lw_len; stride >>= 1) {
+        for (uint32_t t = threadIdx.x; t < SORT_CH / 2; t += SORT_NT) {
+            uint32_t i = 2 * t - (t & (stride - 1));
+            lds_cmpx(sh, i, i + stride, asc);
+        }
+        __syncthreads();
+    }
+    for (uint32_t e = threadIdx.x; e < SORT_CH; e += SORT_NT) {
+        const uint32_t hb = e / lw_len, lw = e % lw_len;
+        stk(base + (size_t)hb * SORT_CH + lw, sh[e]);
+    }
+}
+
 // Stage C: the remaining strides (< SORT_CH) of merge level `size`, chunk-local in LDS
 __global__ __launch_bounds__(SORT_NT) void sort_merge_local_kernel(Fe* keys, uint32_t n, uint32_t size) {
     __shared__ Fe sh[SORT_CH];
@@ -124,9 +152,16 @@ int poly_sort_keys(zg_ctx* ctx, Fe* keys, uint32_t n, uint32_t batch) {
     const double bytes = (double)batch * n * 64;
     ZG_LAUNCH(ctx, "sort_local", bytes, sort_local_kernel, dim3(chunks, batch), dim3(SORT_NT), 0, keys, n);
     for (uint32_t size = 2 * SORT_CH; size <= n; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride >= SORT_CH; stride >>= 1)
-            ZG_LAUNCH(ctx, "sort_global", bytes, sort_global_kernel, dim3((n / 2 + 255) / 256, batch), dim3(256), 0, keys, n,
-                      size, stride);
+        uint32_t nbits = 0;
+        while ((SORT_CH << nbits) < size) nbits++;
+        if (nbits <= 10) {  // (SORT_CH >> nbits >= 1)
+            ZG_LAUNCH(ctx, "sort_global", bytes, sort_global_fused_kernel, dim3(chunks, batch), dim3(SORT_NT), 0, keys, n, size,
+                      nbits);
+        } else {
+            for (uint32_t stride = size >> 1; stride >= SORT_CH; stride >>= 1)
+                ZG_LAUNCH(ctx, "sort_global", bytes, sort_global_kernel, dim3((n / 2 + 255) / 256, batch), dim3(256), 0, keys, n,
+                          size, stride);
+        }
         ZG_LAUNCH(ctx, "sort_merge_local", bytes, sort_merge_local_kernel, dim3(chunks, batch), dim3(SORT_NT), 0, keys, n,
                   size);
     }
