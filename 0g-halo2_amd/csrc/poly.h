@@ -120,6 +120,10 @@ int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint
 int poly_horner_combine(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_list, uint32_t count,
                         const Fe& v, const Fe& sub, Fe* out, uint32_t n);
 constexpr uint32_t HC_MAX_SETS = 8;
+constexpr uint32_t FESET_MAX = 8;
+struct FeSet {  // a few field elements passed by value in kernel arguments (opening points)
+    Fe v[FESET_MAX];
+};
 int poly_horner_combine_sets(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_lists, uint32_t list_stride,
                              const uint32_t* counts, const Fe* subs, uint32_t nsets, const Fe& v, Fe* out, size_t out_stride,
                              uint32_t n);

@@ -707,11 +707,11 @@ int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en) {
 
 // ------------------------------------------------------------------ eval_polynomial
 // pow[p][i] = x_p^i : lane computes x^(i0) by square-and-multiply, then a strip of 16 products
-__global__ __launch_bounds__(256) void powers_kernel(const Fe* __restrict__ points, uint32_t n, Fe* __restrict__ pw) {
+__global__ __launch_bounds__(256) void powers_kernel(FeSet points, uint32_t n, Fe* __restrict__ pw) {
     constexpr uint32_t CH = 16;
     uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * CH;
     if (i0 >= n) return;
-    Fe x = ldg(points + blockIdx.y);
+    Fe x = points.v[blockIdx.y];
     Fe cur = Fr::pow_u64(x, i0);
     Fe* out = pw + (size_t)blockIdx.y * n;
     for (uint32_t j = 0; j < CH && i0 + j < n; j++) {
@@ -722,11 +722,14 @@ __global__ __launch_bounds__(256) void powers_kernel(const Fe* __restrict__ poin
 
 int poly_powers(zg_ctx* ctx, const Fe* points_host, uint32_t npoints, uint32_t n, Fe* d_pow) {
     if (!npoints) return ZG_OK;
-    // the points ride at the head of the table's own allocation (caller reserves npoints extra entries)
-    Fe* d_pts = d_pow + (size_t)npoints * n;
-    ZG_HIP(hipMemcpyAsync(d_pts, points_host, npoints * sizeof(Fe), hipMemcpyHostToDevice, ctx->stream));
-    ZG_LAUNCH(ctx, "powers", (double)npoints * n * 32, powers_kernel, dim3((n + 256 * 16 - 1) / (256 * 16), npoints),
-              dim3(256), 0, d_pts, n, d_pow);
+    for (uint32_t p0 = 0; p0 < npoints; p0 += FESET_MAX) {  // (the points travel in the kernel arguments)
+        const uint32_t m = npoints - p0 < FESET_MAX ? npoints - p0 : FESET_MAX;
+        FeSet pts;
+        memset(&pts, 0, sizeof(pts));
+        for (uint32_t j = 0; j < m; j++) pts.v[j] = points_host[p0 + j];
+        ZG_LAUNCH(ctx, "powers", (double)m * n * 32, powers_kernel, dim3((n + 256 * 16 - 1) / (256 * 16), m), dim3(256), 0, pts, n,
+                  d_pow + (size_t)p0 * n);
+    }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -826,9 +829,10 @@ int poly_horner_combine_sets(zg_ctx* ctx, const Fe* polys, size_t stride, const 
 // z^256 per block), then q_i = local_i + z^(block_end - i) * carry.  Batched over (polynomial, point).
 constexpr uint32_t KD_BLOCK = 256;
 
-__global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const Fe* __restrict__ a, size_t a_stride,
-                                                            const Fe* __restrict__ zs, Fe* __restrict__ loc,
-                                                            Fe* __restrict__ heads, uint32_t n, uint32_t nblk) {
+// (the opening points travel in the kernel arguments: FeSet, at most FESET_MAX of them per launch)
+__global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const Fe* __restrict__ a, size_t a_stride, FeSet zs,
+                                                            Fe* __restrict__ loc, Fe* __restrict__ heads, uint32_t n,
+                                                            uint32_t nblk) {
     __shared__ Fe sh[KD_BLOCK];
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     const uint32_t i = blk * KD_BLOCK + tid;
@@ -836,7 +840,7 @@ __global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const Fe* __restrict
     Fe v = (i + 1 < n) ? ldg(ap + i + 1) : fe_zero();
     sh[tid] = v;
     __syncthreads();
-    Fe w = ldg(zs + b);  // z^off
+    Fe w = zs.v[b];  // z^off
     for (uint32_t off = 1; off < KD_BLOCK; off <<= 1) {
         Fe t = fe_zero();
         const bool has = tid + off < KD_BLOCK;
@@ -851,16 +855,18 @@ __global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const Fe* __restrict
 }
 
 // heads[blk] <- sum_{blk' > blk} heads[blk'] * (z^256)^(blk' - blk - 1): the carry entering block blk from above
-__global__ __launch_bounds__(1024) void kd_heads_kernel(Fe* __restrict__ heads, const Fe* __restrict__ zs, uint32_t nblk) {
+__global__ __launch_bounds__(1024) void kd_heads_kernel(Fe* __restrict__ heads, FeSet zs, uint32_t nblk) {
     __shared__ Fe sh[1024];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
     Fe* hp = heads + (size_t)b * nblk;
     sh[tid] = tid < nblk ? ldg(hp + tid) : fe_zero();
     __syncthreads();
-    Fe w = Fr::pow_u64(ldg(zs + b), KD_BLOCK);
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
+    Fe w = Fr::pow_u64(zs.v[b], KD_BLOCK);
+    uint32_t span = 64;  // (entries at and beyond nblk are zero: the scan only has to span the block heads)
+    while (span < nblk) span <<= 1;
+    for (uint32_t off = 1; off < span; off <<= 1) {
         Fe t = fe_zero();
-        const bool has = tid + off < 1024;
+        const bool has = tid + off < span;
         if (has) t = sh[tid + off];
         __syncthreads();
         if (has) sh[tid] = Fr::add(sh[tid], Fr::mul(w, t));
@@ -872,15 +878,14 @@ __global__ __launch_bounds__(1024) void kd_heads_kernel(Fe* __restrict__ heads, 
     if (tid < nblk) stg(hp + tid, carry);
 }
 
-__global__ __launch_bounds__(KD_BLOCK) void kd_apply_kernel(const Fe* __restrict__ loc, const Fe* __restrict__ heads,
-                                                            const Fe* __restrict__ zs, Fe* __restrict__ q, size_t q_stride,
-                                                            uint32_t n, uint32_t nblk) {
+__global__ __launch_bounds__(KD_BLOCK) void kd_apply_kernel(const Fe* __restrict__ loc, const Fe* __restrict__ heads, FeSet zs,
+                                                            Fe* __restrict__ q, size_t q_stride, uint32_t n, uint32_t nblk) {
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     const uint32_t i = blk * KD_BLOCK + tid;
     if (i >= n) return;
     Fe v = ldg(loc + (size_t)b * n + i);
     Fe carry = ldg(heads + (size_t)b * nblk + blk);
-    if (!fe_is_zero(carry)) v = Fr::add(v, Fr::mul(Fr::pow_u64(ldg(zs + b), KD_BLOCK - tid), carry));
+    if (!fe_is_zero(carry)) v = Fr::add(v, Fr::mul(Fr::pow_u64(zs.v[b], KD_BLOCK - tid), carry));
     stg(q + (size_t)b * q_stride + i, v);
 }
 
@@ -895,16 +900,20 @@ int poly_kate_division(zg_ctx* ctx, const Fe* a, size_t a_stride, const Fe* zs_h
     if (!batch || !n) return ZG_OK;
     const uint32_t nblk = (n + KD_BLOCK - 1) / KD_BLOCK;
     ZG_REQUIRE(nblk <= 1024, ZG_ERR_UNSUPPORTED, "kate division: n=%u > 2^18 not built", n);
-    Fe* loc = tmp;
-    Fe* heads = loc + (size_t)batch * n;
-    Fe* zs = heads + (size_t)batch * nblk;
-    ZG_HIP(hipMemcpyAsync(zs, zs_host, batch * sizeof(Fe), hipMemcpyHostToDevice, ctx->stream));
-    const double bytes = (double)batch * n * 64;
-    ZG_LAUNCH(ctx, "kate_local", bytes, kd_local_kernel, dim3(nblk, batch), dim3(KD_BLOCK), 0, a, a_stride, zs, loc, heads,
-              n, nblk);
-    ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(batch), dim3(1024), 0, heads, zs, nblk);
-    ZG_LAUNCH(ctx, "kate_apply", bytes, kd_apply_kernel, dim3(nblk, batch), dim3(KD_BLOCK), 0, loc, heads, zs, q, q_stride,
-              n, nblk);
+    for (uint32_t b0 = 0; b0 < batch; b0 += FESET_MAX) {
+        const uint32_t m = batch - b0 < FESET_MAX ? batch - b0 : FESET_MAX;
+        Fe* loc = tmp;
+        Fe* heads = loc + (size_t)m * n;
+        FeSet zs;
+        memset(&zs, 0, sizeof(zs));
+        for (uint32_t j = 0; j < m; j++) zs.v[j] = zs_host[b0 + j];
+        const double bytes = (double)m * n * 64;
+        ZG_LAUNCH(ctx, "kate_local", bytes, kd_local_kernel, dim3(nblk, m), dim3(KD_BLOCK), 0, a + (size_t)b0 * a_stride, a_stride,
+                  zs, loc, heads, n, nblk);
+        ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(m), dim3(1024), 0, heads, zs, nblk);
+        ZG_LAUNCH(ctx, "kate_apply", bytes, kd_apply_kernel, dim3(nblk, m), dim3(KD_BLOCK), 0, loc, heads, zs,
+                  q + (size_t)b0 * q_stride, q_stride, n, nblk);
+    }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -747,7 +747,6 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
 
     // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
     Fe* pz = p->zs;
-    Fe* lz = p->zs + (size_t)S * n;
     if (S) ZG_TRY(poly_perm_terms(ctx, p->dc, base_cols, p->sigma_val, p->omega_tw, beta, gamma, p->num, p->den, n));
     // (a'_l / s'_l are interleaved in `perm`: two views with a stride of two columns)
     ZG_TRY(poly_lookup_terms(ctx, p->cin, p->ctab, p->perm, p->perm + n, (size_t)2 * n, beta, gamma, p->num + (size_t)S * n,
