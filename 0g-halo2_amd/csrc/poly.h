@@ -90,9 +90,11 @@ enum {
 // ---- launch helpers (all asynchronous on ctx->stream) ----
 int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
                     uint64_t seed, uint32_t tag);
-int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag, Fe* out2 = nullptr);  // out2: a second copy
+int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag, Fe* out2 = nullptr);
+int poly_random_and_blind(zg_ctx* ctx, Fe* out, Fe* out2, uint32_t n, uint64_t seed, uint32_t tag, Fe* base, size_t col_stride,
+                          uint32_t ncols, uint32_t row0, uint32_t nrows, uint32_t blind_tag);  // out2: a second copy
 int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe& theta, Fe* cin, Fe* ctab,
-                         uint32_t n);
+                         uint32_t n, Fe* raw_in = nullptr, Fe* raw_tab = nullptr, uint32_t usable = 0);
 int poly_blind_rows2(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols0, uint32_t tag0, uint32_t ncols1, uint32_t tag1,
                      uint32_t row0, uint32_t nrows, uint64_t seed);
 int poly_permuted_finish(zg_ctx* ctx, const Fe* raw_in, const Fe* raw_tab, Fe* perm, uint32_t n, uint32_t usable,

@@ -91,6 +91,31 @@ int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, ui
     return poly_blind_rows2(ctx, base, col_stride, ncols, tag, 0, tag, row0, nrows, seed);
 }
 
+// The two draws a proof starts with, in one launch: the vanishing argument's random polynomial (n values,
+// written to out and out2) and the blinding rows of the advice columns.
+__global__ void random_and_blind_kernel(Fe* out, Fe* out2, uint32_t n, uint64_t seed, uint32_t tag, Fe* base, size_t col_stride,
+                                        uint32_t ncols, uint32_t row0, uint32_t nrows, uint32_t blind_tag) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const Fe v = rand_fr(seed, tag, i);
+        stg(out + i, v);
+        if (out2) stg(out2 + i, v);
+        return;
+    }
+    i -= n;
+    if (i >= ncols * nrows) return;
+    const uint32_t c = i / nrows, j = i % nrows;
+    stg(base + (size_t)c * col_stride + row0 + j, rand_fr(seed, blind_tag, (uint64_t)c * nrows + j));
+}
+int poly_random_and_blind(zg_ctx* ctx, Fe* out, Fe* out2, uint32_t n, uint64_t seed, uint32_t tag, Fe* base, size_t col_stride,
+                          uint32_t ncols, uint32_t row0, uint32_t nrows, uint32_t blind_tag) {
+    const uint32_t total = n + ncols * nrows;
+    ZG_LAUNCH(ctx, "random_poly", (double)n * 32, random_and_blind_kernel, dim3((total + 255) / 256), dim3(256), 0, out, out2, n, seed,
+              tag, base, col_stride, ncols, row0, nrows, blind_tag);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag, Fe* out2) {
     ZG_LAUNCH(ctx, "random_poly", (double)n * 32, random_kernel, dim3((n + 255) / 256), dim3(256), 0, out, out2, n, seed, tag);
     ZG_HIP(hipGetLastError());
@@ -127,8 +152,10 @@ __device__ __forceinline__ Fe eval_poly(const DevCircuit& c, const Cols& cols, z
 }
 
 // lookup::Argument::commit_permuted `compress_expressions`: theta-fold of the input / table tuples
+// raw_in / raw_tab (optional): the same values as canonical integers -- the sort keys of permute_expression_pair --
+// with the all-ones sentinel on the rows from `usable` on (sorts last; real keys are < r < 2^254)
 __global__ __launch_bounds__(256) void lookup_compress_kernel(DevCircuit c, Cols cols, Fe theta, Fe* cin, Fe* ctab,
-                                                              uint32_t n) {
+                                                              uint32_t n, Fe* raw_in, Fe* raw_tab, uint32_t usable) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t l = blockIdx.y;
     if (row >= n) return;
@@ -140,13 +167,25 @@ __global__ __launch_bounds__(256) void lookup_compress_kernel(DevCircuit c, Cols
     }
     stg(cin + (size_t)l * n + row, ai);
     stg(ctab + (size_t)l * n + row, ti);
+    if (raw_in) {
+        Fe ra, rt;
+        if (row < usable) {
+            ra = Fr::to_raw(ai);
+            rt = Fr::to_raw(ti);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) ra.l[j] = rt.l[j] = 0xffffffffu;
+        }
+        stg(raw_in + (size_t)l * n + row, ra);
+        stg(raw_tab + (size_t)l * n + row, rt);
+    }
 }
 
 int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe& theta, Fe* cin, Fe* ctab,
-                         uint32_t n) {
+                         uint32_t n, Fe* raw_in, Fe* raw_tab, uint32_t usable) {
     if (c.n_lookups == 0) return ZG_OK;
     ZG_LAUNCH(ctx, "lookup_compress", (double)c.n_lookups * n * 64, lookup_compress_kernel,
-              dim3((n + 255) / 256, c.n_lookups), dim3(256), 0, c, cols, theta, cin, ctab, n);
+              dim3((n + 255) / 256, c.n_lookups), dim3(256), 0, c, cols, theta, cin, ctab, n, raw_in, raw_tab, usable);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -671,7 +671,10 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     // vanishing::Argument::commit's random polynomial depends on no challenge: generate it now and
     // commit it inside the permuted-lookup batch (coefficient basis `g` next to `g_lagrange` vectors)
     Fe* random_row = p->perm + (size_t)(2 * NL) * n;
-    ZG_TRY(poly_random(ctx, random_row, n, seed, TAG_RANDOM_POLY, poly_at(p->ix_random)));
+    // (the same launch draws the blinding rows of the advice columns: commit_lagrange's input below)
+    Fe* adv = reinterpret_cast<Fe*>(d_advice);
+    ZG_TRY(poly_random_and_blind(ctx, random_row, poly_at(p->ix_random), n, seed, TAG_RANDOM_POLY, adv, n, A, usable, bf + 1,
+                                 TAG_ADVICE_BLIND));
     if (I) {
         if (p->inst_filled > instance_len) ZG_HIP(hipMemsetAsync(p->inst_val, 0, (size_t)I * n * 32, st));  // (zeroed at create)
         p->inst_filled = instance_len;
@@ -682,9 +685,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         }
     }
 
-    // ---- advice: blind, commit (Lagrange basis)
-    Fe* adv = reinterpret_cast<Fe*>(d_advice);
-    if (A) ZG_TRY(poly_blind_rows(ctx, adv, n, A, usable, bf + 1, seed, TAG_ADVICE_BLIND));
+    // ---- advice: commit (Lagrange basis)
     ZG_TRY(fork());
     if (I) {
         ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
@@ -709,12 +710,11 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     Jac random_commit;
     bool have_random = false;
     if (NL) {
-        ZG_TRY(poly_lookup_compress(ctx, p->dc, base_cols, theta, p->cin, p->ctab, n));
-        // permute_expression_pair on the device: canonical keys, bitonic sort of inputs and tables,
-        // scan-based construction of s' (sort.hip).  raw rows [0,NL) = inputs -> a', [NL,2NL) = tables.
-        ZG_TRY(poly_to_raw(ctx, p->cin, p->raw, (size_t)2 * NL * n));  // (ctab follows cin)
+        // permute_expression_pair on the device: canonical keys (written by the compression kernel itself, with
+        // the sentinel padding), bitonic sort of inputs and tables, scan-based construction of s' (sort.hip).
+        // raw rows [0,NL) = inputs -> a', [NL,2NL) = tables.
+        ZG_TRY(poly_lookup_compress(ctx, p->dc, base_cols, theta, p->cin, p->ctab, n, p->raw, p->raw + (size_t)NL * n, usable));
         auto t_sort = clk::now();
-        ZG_TRY(poly_sort_pad(ctx, p->raw, n, usable, 2 * NL));
         ZG_TRY(poly_sort_keys(ctx, p->raw, n, 2 * NL));
         ZG_TRY(poly_permute_pairs(ctx, p->raw, p->raw + (size_t)NL * n, p->sraw, n, usable, NL, p->sort_u32, p->sort_fe,
                                   p->d_err));
