@@ -61,8 +61,8 @@ def throughput_form(n):
     return bool(re.search(r"<(1|false)[,>]", n))
 
 
-fin_t = [n for n in disp if n.startswith("msm_finish_kernel") and throughput_form(n)]
-fin_l = [n for n in disp if n.startswith("msm_finish_kernel") and not throughput_form(n)]
+fin_t = [n for n in disp if n.startswith("msm_bucket_sum_kernel") and throughput_form(n)]
+fin_l = [n for n in disp if n.startswith("msm_bucket_sum_kernel") and not throughput_form(n)]
 nt = sum(len(disp[n]) for n in fin_t) // 5
 nl = sum(len(disp[n]) for n in fin_l) // 5
 thr = lat = 0.0
