@@ -516,8 +516,9 @@ static uint32_t default_window_bits(size_t n) {
     }
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
-    // measured inside the full proof (tools/sweep_c.sh): k=14 -> 13, k=15 -> 13, k=17 -> 15
-    int c = lg >= 15 ? (int)lg - 2 : (int)lg - 1;
+    // measured inside the full proof (tools/sweep_c.sh): k=14 -> 12, k=15 -> 13, k=17 -> 15.  (One less and
+    // every bucket holds enough entries to count as hot -- a cliff, not a slope: 1.36 -> 1.89 ms/proof at k=14.)
+    int c = lg >= 14 ? (int)lg - 2 : (int)lg - 1;
     if (c < 4) c = 4;
     if (c > (int)MSM_MAX_C) c = MSM_MAX_C;
     return (uint32_t)c;
