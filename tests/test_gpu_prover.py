@@ -67,6 +67,20 @@ def test_single_stream_schedule_gives_the_same_bytes(ctx, zg, orc):
     prover.close()
 
 
+def test_prover_reuse_with_a_shorter_instance(ctx, zg, orc):
+    """The instance column lives on the device between proofs and only its first rows are refilled: a proof
+    with fewer instance values after one with more must see zeros behind them (bytes == oracle each time; the
+    shorter statement is not satisfied, which changes no code path of the prover)."""
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 7)
+    adv = asg.advice_values()
+    full, none = asg.instance_values(ilen), asg.instance_values(0)
+    for inst, seed in ((full, 3), (none, 4), (full, 5)):
+        st, want, _ = orc.create_proof(pk, adv, inst, seed)
+        assert st == 0
+        assert prover.prove(adv, inst, seed) == want
+    prover.close()
+
+
 def test_lookup_failure_is_constraint_system_failure(ctx, zg, orc):
     cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 5)
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
