@@ -773,20 +773,22 @@ int poly_powers(zg_ctx* ctx, const Fe* points_host, uint32_t npoints, uint32_t n
     return ZG_OK;
 }
 
-// out[j] = <poly_j, pow_{point_j}> : one workgroup per (poly, point) pair
-__global__ __launch_bounds__(256) void dot_kernel(const Fe* __restrict__ polys, size_t stride, uint32_t n,
-                                                  const uint32_t* __restrict__ poly_idx,
-                                                  const uint32_t* __restrict__ point_idx, const Fe* __restrict__ pw,
-                                                  Fe* __restrict__ out) {
-    __shared__ Fe sh[256];
+// out[j] = <poly_j, pow_{point_j}> : one 1024-lane workgroup per (poly, point) pair (a few dozen pairs per
+// proof: the wide workgroup is what keeps a lone proof from waiting on 64 products per lane)
+constexpr uint32_t DOT_NT = 1024;
+__global__ __launch_bounds__(DOT_NT) void dot_kernel(const Fe* __restrict__ polys, size_t stride, uint32_t n,
+                                                     const uint32_t* __restrict__ poly_idx,
+                                                     const uint32_t* __restrict__ point_idx, const Fe* __restrict__ pw,
+                                                     Fe* __restrict__ out) {
+    __shared__ Fe sh[DOT_NT];
     const uint32_t j = blockIdx.x, tid = threadIdx.x;
     const Fe* p = polys + (size_t)poly_idx[j] * stride;
     const Fe* w = pw + (size_t)point_idx[j] * n;
     Fe acc = fe_zero();
-    for (uint32_t i = tid; i < n; i += 256) acc = Fr::add(acc, Fr::mul(ldg(p + i), ldg(w + i)));
+    for (uint32_t i = tid; i < n; i += DOT_NT) acc = Fr::add(acc, Fr::mul(ldg(p + i), ldg(w + i)));
     sh[tid] = acc;
     __syncthreads();
-    for (uint32_t off = 128; off > 0; off >>= 1) {
+    for (uint32_t off = DOT_NT / 2; off > 0; off >>= 1) {
         if (tid < off) sh[tid] = Fr::add(sh[tid], sh[tid + off]);
         __syncthreads();
     }
@@ -796,7 +798,7 @@ __global__ __launch_bounds__(256) void dot_kernel(const Fe* __restrict__ polys, 
 int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint32_t* d_poly_idx,
              const uint32_t* d_point_idx, const Fe* d_pow, uint32_t count, Fe* d_out) {
     if (!count) return ZG_OK;
-    ZG_LAUNCH(ctx, "eval_dot", (double)count * n * 64, dot_kernel, dim3(count), dim3(256), 0, polys, stride, n, d_poly_idx,
+    ZG_LAUNCH(ctx, "eval_dot", (double)count * n * 64, dot_kernel, dim3(count), dim3(DOT_NT), 0, polys, stride, n, d_poly_idx,
               d_point_idx, d_pow, d_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;

@@ -12,7 +12,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 # a proof starts at random_kernel (vanishing argument's random polynomial is generated first)
-starts = [i for i, r in enumerate(rows) if r[2].startswith("random_kernel")]
+starts = [i for i, r in enumerate(rows) if r[2].startswith("random_")]
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 i0 = starts[-which - 1]
 i1 = starts[-which]
