@@ -364,7 +364,7 @@ __global__ __launch_bounds__(GP_BLOCK) void gp_local_kernel(const Fe* __restrict
 __global__ __launch_bounds__(1024) void gp_totals_kernel(Fe* __restrict__ totn, Fe* __restrict__ totd,
                                                          const Fe* __restrict__ locn, const Fe* __restrict__ locd,
                                                          Fe* __restrict__ tinv, Fe* __restrict__ zlast, uint32_t n,
-                                                         uint32_t nblk, uint32_t last) {
+                                                         uint32_t nblk, uint32_t last, uint32_t defer_inverse) {
     __shared__ Fe shn[1024], shd[1024];
     const uint32_t tid = threadIdx.x, b = blockIdx.x;
     Fe* tn = totn + (size_t)b * nblk;
@@ -403,10 +403,12 @@ __global__ __launch_bounds__(1024) void gp_totals_kernel(Fe* __restrict__ totn, 
     shd[tid] = ed;
     __syncthreads();
     if (tid == 0) {
-        Fe ti = Fr::inv(total_d);
+        // defer_inverse: the host inverts T (tinv[b] <- T, zlast[b] <- the product without 1/T); a lone lane
+        // spends ~0.1 ms on it, the host a few microseconds -- worth a round trip when one proof is all there is
+        Fe ti = defer_inverse ? total_d : Fr::inv(total_d);
         stg(tinv + b, ti);
         // z(last) for z0 = 1: N(last-1) * D'(last) / T
-        Fe v = ti;
+        Fe v = defer_inverse ? Fr::one() : ti;
         if (last < n) {
             uint32_t lb = last / GP_BLOCK;
             v = Fr::mul(v, Fr::mul(ldg(locd + (size_t)b * n + last), shd[lb]));
@@ -423,15 +425,19 @@ __global__ __launch_bounds__(GP_BLOCK) void gp_apply_kernel(const Fe* __restrict
                                                             const Fe* __restrict__ totn, const Fe* __restrict__ totd,
                                                             const Fe* __restrict__ tinv, const Fe* __restrict__ zlast,
                                                             const Fe* __restrict__ z0, Fe* __restrict__ z, uint32_t n,
-                                                            uint32_t nblk, uint32_t chain) {
+                                                            uint32_t nblk, uint32_t chain, FeSet host_tinv, uint32_t use_host) {
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     const uint32_t i = blk * GP_BLOCK + tid;
     if (i >= n) return;
     // start value: z0[b] (if given) times the chained last values of the products before b
+    // (use_host: 1/T arrives in the kernel arguments and zlast still lacks that factor)
     Fe c = z0 ? ldg(z0 + b) : Fr::one();
     if (b < chain)
-        for (uint32_t s = 0; s < b; s++) c = Fr::mul(c, ldg(zlast + s));
-    Fe v = Fr::mul(c, ldg(tinv + b));
+        for (uint32_t s = 0; s < b; s++) {
+            c = Fr::mul(c, ldg(zlast + s));
+            if (use_host) c = Fr::mul(c, host_tinv.v[s]);
+        }
+    Fe v = Fr::mul(c, use_host ? host_tinv.v[b] : ldg(tinv + b));
     v = Fr::mul(v, Fr::mul(ldg(locd + (size_t)b * n + i), ldg(totd + (size_t)b * nblk + blk)));
     if (i > 0) {
         uint32_t pb = (i - 1) / GP_BLOCK;
@@ -460,10 +466,35 @@ int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0
     const double bytes = (double)batch * n * 96;
     ZG_LAUNCH(ctx, "grand_product_local", bytes, gp_local_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, num, den, locn,
               locd, totn, totd, n, nblk);
+    // latency configuration: the host inverts the totals (one shared inversion) between the two launches
+    const bool host_inv = ctx->msm_pair && batch <= FESET_MAX;
     ZG_LAUNCH(ctx, "grand_product_totals", bytes, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
-              tinv, zlast, n, nblk, last);
+              tinv, zlast, n, nblk, last, host_inv ? 1u : 0u);
+    FeSet inv_set;
+    memset(&inv_set, 0, sizeof(inv_set));
+    if (host_inv) {
+        ZG_TRY(pinned_reserve(ctx, 4096));
+        Fe* h = reinterpret_cast<Fe*>(ctx->pinned);
+        ZG_HIP(hipMemcpyAsync(h, tinv, batch * sizeof(Fe), hipMemcpyDeviceToHost, ctx->stream));
+        ZG_HIP(hipStreamSynchronize(ctx->stream));
+        // Montgomery's trick: prefix products, one inversion, walk back (a zero total inverts to zero, as Fr::inv does)
+        Fe pre[FESET_MAX], acc = Fr::one();
+        for (uint32_t b = 0; b < batch; b++) {
+            pre[b] = acc;
+            if (!fe_is_zero(h[b])) acc = Fr::mul(acc, h[b]);
+        }
+        acc = Fr::inv(acc);
+        for (uint32_t b = batch; b-- > 0;) {
+            if (fe_is_zero(h[b])) {
+                inv_set.v[b] = fe_zero();
+                continue;
+            }
+            inv_set.v[b] = Fr::mul(acc, pre[b]);
+            acc = Fr::mul(acc, h[b]);
+        }
+    }
     ZG_LAUNCH(ctx, "grand_product_apply", bytes, gp_apply_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, locn, locd, totn,
-              totd, tinv, zlast, d_z0, z, n, nblk, chain);
+              totd, tinv, zlast, d_z0, z, n, nblk, chain, inv_set, host_inv ? 1u : 0u);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
