@@ -640,7 +640,8 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     {
         const int spare = (int)(c * W) - 1 - 254;  // 2^(cW-1) / 2^254
         if (spare >= 1) tbits = (uint32_t)spare;   // 2^spare * (2^254 / r) - 1 >= 2^spare with 2^254/r ~ 1.32
-        if (tbits > 6) tbits = 6;
+        if (tbits > 10) tbits = 10;  // (c = 12, W = 22 leaves 9 spare bits: the top window then spreads over ~1500 buckets;
+                                     // capped at 6 it spread over ~200, each just past the hot-bucket threshold)
     }
     if (const char* e = getenv("ZG_MSM_BALANCE")) tbits = atoi(e) ? tbits : 0;
     ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, c,
@@ -660,7 +661,9 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                   bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
                   toff, ttotal, sorted, max_tasks, partial);
     }
-    const dim3 hgrid(max_heavy < 2048 ? max_heavy : 2048, B);
+    // hot buckets are few (repeated or tiny scalars put one or two per window at most); the kernel strides over
+    // the list, so a small grid serves any count -- and costs microseconds, not tens of them, when there are none
+    const dim3 hgrid(max_heavy < 48 ? max_heavy : 48, B);
     if (ctx->msm_pair) {  // several lanes per addition: shorter dependent chains in the reduction
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<2>, hgrid, dim3(512), 0, partial, toff, hlist, nheavy, max_tasks,
                   max_heavy, c, hsum);
