@@ -99,8 +99,9 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; j++) l[j] = s.l[j];
     l[8] = 0;
-    // top window non-zero <=> s >= 2^(c*(W-1))
-    const uint32_t top_lo = c * (windows - 1);
+    // top window non-zero after recoding <=> (about) s >= 2^(c*(W-1) - 1): the bit below the top window carries into
+    // it (a third of uniformly random scalars sits in [2^251, 2^252) for c = 12 and would all meet in bucket 1)
+    const uint32_t top_lo = c * (windows - 1) - 1;
     bool large = false;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -650,6 +651,23 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
               ttotal, hmap, hlist, nheavy, max_heavy, off);
+    if (getenv("ZG_MSM_DEBUG")) {  // tuning aid: hot buckets and tasks per vector
+        std::vector<uint32_t> hn(B), tt(B);
+        ZG_HIP(hipStreamSynchronize(ctx->stream));
+        ZG_HIP(hipMemcpy(hn.data(), nheavy, B * 4, hipMemcpyDeviceToHost));
+        ZG_HIP(hipMemcpy(tt.data(), ttotal, B * 4, hipMemcpyDeviceToHost));
+        for (uint32_t b = 0; b < B; b++) {
+            fprintf(stderr, "zg_msm: vector %u of %u: n=%u c=%u windows=%u tasks=%u hot buckets=%u", b, B, N, c, W, tt[b], hn[b]);
+            for (uint32_t h = 0; h < hn[b] && h < 4 && h < max_heavy; h++) {
+                uint32_t k = 0, t0 = 0, t1 = 0;
+                ZG_HIP(hipMemcpy(&k, hlist + (size_t)b * max_heavy + h, 4, hipMemcpyDeviceToHost));
+                ZG_HIP(hipMemcpy(&t0, toff + (size_t)b * (nb + 2) + k, 4, hipMemcpyDeviceToHost));
+                ZG_HIP(hipMemcpy(&t1, toff + (size_t)b * (nb + 2) + k + 1, 4, hipMemcpyDeviceToHost));
+                fprintf(stderr, "  [bucket %u: %u tasks]", k, t1 - t0);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted);
     if (ctx->msm_pair) {
