@@ -102,6 +102,10 @@ struct zg_bases {
     uint32_t c = 0;        // window bits
     uint32_t windows = 0;  // ceil(255 / c)
     zg::Affine* table = nullptr;  // [windows][n]: 2^(c*w) * P_i, affine
+    // the same table for the running sums Q_i = P_0 + ... + P_i (built on demand by bases_enable_runs): a scalar
+    // vector with long constant runs is multiplied as sum_i (s_i - s_{i+1}) Q_i, whose coefficients vanish inside runs
+    zg::Affine* run_table = nullptr;
+    std::mutex mu;
 };
 
 namespace zg {

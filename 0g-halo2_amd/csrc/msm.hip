@@ -28,6 +28,8 @@ namespace zg {
 
 int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t batch, size_t n, XYZZ* d_out);
+int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
 
 constexpr uint32_t MSM_K = 16;       // max points per accumulate task
 constexpr uint32_t MSM_MAX_C = 16;
@@ -88,13 +90,47 @@ __global__ void msm_table_kernel(const Affine* __restrict__ bases, Affine* __res
 // non-zero) are shifted by a pseudo-random multiple t*r, t < 2^tbits, chosen so that the sum still
 // fits below 2^(cW-1) (no carry out of the top window).  Small / sparse scalars are left alone so
 // that their zero windows stay zero.
+// Run form (bit b of run_mask): entry i stands for the coefficient s_i - s_{i+1} (s_n = 0) of the running base sum
+// Q_i = P_0 + ... + P_i (summation by parts: sum_i s_i P_i = sum_i (s_i - s_{i+1}) Q_i), taken as -(s_{i+1} - s_i)
+// with the point negated when that is the smaller integer -- columns that stay constant over long stretches
+// (grand products over padded rows) leave almost no entries.
 __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n,
                                                          uint32_t c, uint32_t windows, uint32_t tbits,
-                                                         uint32_t* __restrict__ dig) {
+                                                         uint32_t* __restrict__ dig, uint64_t run_mask) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
-    Fe s = Fr::to_raw(ld_fe_g(scalars + (size_t)b * stride + i));
+    Fe s = ld_fe_g(scalars + (size_t)b * stride + i);
+    uint32_t flip = 0;  // the whole scalar negated: every digit's sign flips
+    if (b < 64 && ((run_mask >> b) & 1ull)) {
+        if (i + 1 < n) s = Fr::sub(s, ld_fe_g(scalars + (size_t)b * stride + i + 1));
+        s = Fr::to_raw(s);
+        // |s| as the smaller of s and r - s
+        Fe neg;
+        uint32_t ps[8], pr[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            ps[j] = s.l[j];
+            pr[j] = FrParams::p(j);
+        }
+        uint32_t nl[8];
+        sub8(nl, pr, ps);  // r - s (s < r)
+#pragma unroll
+        for (int j = 0; j < 8; j++) neg.l[j] = nl[j];
+        bool smaller = false;  // neg < s ?
+        for (int j = 7; j >= 0; j--) {
+            if (neg.l[j] != s.l[j]) {
+                smaller = neg.l[j] < s.l[j];
+                break;
+            }
+        }
+        if (smaller && !fe_is_zero(s)) {
+            s = neg;
+            flip = 1u << 31;
+        }
+    } else {
+        s = Fr::to_raw(s);
+    }
     uint32_t l[9];
 #pragma unroll
     for (int j = 0; j < 8; j++) l[j] = s.l[j];
@@ -140,7 +176,7 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ 
         have = have >= c ? have - c : 0;
         carry = d > nb ? 1u : 0u;
         uint32_t k = carry ? (1u << c) - d : d;
-        db[(size_t)w * n] = k | (carry << 31);
+        db[(size_t)w * n] = k ? (k | ((carry << 31) ^ flip)) : 0u;
     }
 }
 
@@ -282,13 +318,16 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table,
     uint32_t c, uint32_t windows, uint32_t n,
     const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
-    const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ9* __restrict__ partial) {
+    const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ9* __restrict__ partial,
+    const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = PAIR ? lane >> 1 : lane;
     const bool role_a = !PAIR || (lane & 1u) == 0;
     uint32_t b = blockIdx.y;
     if (t >= ttotal[b]) return;
-    const Affine* table = b < split ? table_a : table_b;  // vectors >= split use the second base set
+    const bool runs = b < 64 && ((run_mask >> b) & 1ull);  // (entries then name running base sums)
+    // vectors >= split use the second base set
+    const Affine* table = b < split ? (runs ? run_a : table_a) : (runs ? run_b : table_b);
     const uint32_t nb = 1u << (c - 1);
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     // largest k with to[k] <= t  (to is non-decreasing, to[nb+1] = total > t)
@@ -556,6 +595,66 @@ int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t wi
     return ZG_OK;
 }
 
+void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
+
+// Running sums Q_i = P_0 + ... + P_i of the registered points and their window table (once per base set; the
+// sums are a sequential chain, so the host adds them up -- one mixed addition per point -- and normalises them
+// with a single inversion).
+int bases_enable_runs(zg_ctx* ctx, zg_bases* b) {
+    std::lock_guard<std::mutex> lock(b->mu);
+    if (b->run_table) return ZG_OK;
+    const size_t n = b->n;
+    std::vector<Affine> pts(n);
+    ZG_HIP(hipMemcpy(pts.data(), b->table, n * sizeof(Affine), hipMemcpyDeviceToHost));  // window 0: P_i * 2^5
+    const Fe un = Fq::inv(Fq9Params::c261_fe());
+    std::vector<XYZZ> sums(n);
+    XYZZ acc = xyzz_identity();
+    for (size_t i = 0; i < n; i++) {
+        Affine p;
+        p.x = Fq::mul(pts[i].x, un);
+        p.y = Fq::mul(pts[i].y, un);
+        if (!affine_is_identity(p)) acc = xyzz_madd(acc, p);
+        sums[i] = acc;
+    }
+    std::vector<zg_g1> norm(n);
+    xyzz_batch_normalise(sums.data(), n, norm.data());
+    for (size_t i = 0; i < n; i++) {
+        Jac j;
+        memcpy(&j, &norm[i], sizeof(Jac));
+        if (jac_is_identity(j)) {
+            pts[i].x = fe_zero();
+            pts[i].y = fe_zero();
+        } else {
+            pts[i].x = j.x;
+            pts[i].y = j.y;
+        }
+    }
+    Affine* d_sums = nullptr;
+    Affine* table = nullptr;
+    ZG_HIP(hipMalloc(&d_sums, n * sizeof(Affine)));
+    hipError_t e = hipMalloc(&table, (size_t)b->windows * n * sizeof(Affine));
+    if (e != hipSuccess) {
+        (void)hipFree(d_sums);
+        set_error("bases_enable_runs: hipMalloc(%zu) failed: %s", (size_t)b->windows * n * sizeof(Affine), hipGetErrorString(e));
+        return ZG_ERR_OOM;
+    }
+    e = hipMemcpy(d_sums, pts.data(), n * sizeof(Affine), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(msm_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, d_sums, table, (uint32_t)n,
+                           b->c, b->windows);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_sums);
+    if (e != hipSuccess) {
+        (void)hipFree(table);
+        set_error("bases_enable_runs: %s", hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    b->run_table = table;
+    return ZG_OK;
+}
+
 int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch,
                   size_t n, XYZZ* d_out) {
     return msm_batch2_dev(ctx, bases, nullptr, batch, d_scalars, stride, batch, n, d_out);
@@ -565,6 +664,19 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
 // length and window size, e.g. ParamsKZG::g_lagrange and ::g) in ONE launch sequence.
 int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t batch, size_t n, XYZZ* d_out) {
+    return msm_batch3_dev(ctx, bases, bases_b, split, d_scalars, stride, batch, n, d_out, 0);
+}
+
+// ... and the vectors named by run_mask (bit b, b < 64) are multiplied in the run form (msm_digits_kernel); their
+// base set must have its running-sum table (bases_enable_runs).
+int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask) {
+    if (batch < 64) run_mask &= (1ull << batch) - 1ull;
+    const uint64_t mask_a = split >= 64 ? ~0ull : (1ull << split) - 1ull;
+    const Affine* run_a = bases->run_table;
+    const Affine* run_b = bases_b ? bases_b->run_table : bases->run_table;
+    ZG_REQUIRE((run_mask & mask_a) == 0 || run_a != nullptr, ZG_ERR_INVALID_ARG, "zg_msm: run form asked for bases without a running-sum table");
+    ZG_REQUIRE((run_mask & ~mask_a) == 0 || run_b != nullptr, ZG_ERR_INVALID_ARG, "zg_msm: run form asked for bases without a running-sum table");
     if (bases_b)
         ZG_REQUIRE(bases_b->n == bases->n && bases_b->c == bases->c, ZG_ERR_INVALID_ARG,
                    "zg_msm: the two base sets differ in length or window size");
@@ -646,7 +758,7 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     }
     if (const char* e = getenv("ZG_MSM_BALANCE")) tbits = atoi(e) ? tbits : 0;
     ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, c,
-              W, tbits, dig);
+              W, tbits, dig, run_mask);
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
@@ -673,11 +785,11 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     if (ctx->msm_pair) {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<true>, dim3((2 * max_tasks + 255) / 256, B), dim3(256),
                   0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask);
     } else {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<false>, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
                   bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask);
     }
     // hot buckets are few (repeated or tiny scalars put one or two per window at most); the kernel strides over
     // the list, so a small grid serves any count -- and costs microseconds, not tens of them, when there are none
@@ -767,6 +879,7 @@ void zg_bases_free(zg_bases* b) {
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
     (void)hipFree(b->table);
+    if (b->run_table) (void)hipFree(b->run_table);
     delete b;
 }
 

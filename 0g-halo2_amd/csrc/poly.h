@@ -155,6 +155,9 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
                   XYZZ* d_out);
 int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t batch, size_t n, XYZZ* d_out);
+int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
+int bases_enable_runs(zg_ctx* ctx, zg_bases* b);  // running-sum table for the run form (idempotent)
 int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t window_bits, zg_bases** out);
 void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
 

@@ -508,6 +508,8 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_HIP(hipMemcpyAsync(d, g_lagrange, (size_t)n * sizeof(Affine), hipMemcpyHostToDevice, st));
         ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->gl));
     }
+    static const bool run_form = !(getenv("ZG_MSM_RUNS") && atoi(getenv("ZG_MSM_RUNS")) == 0);  // A/B knob
+    if (run_form && p->sets + p->NL > 0) ZG_TRY(bases_enable_runs(ctx, p->gl));
 
     // ---- slabs
     const uint32_t F = p->F, A = p->A, I = p->I, P = p->P, NL = p->NL, S = p->sets, Q = p->qpd;
@@ -756,12 +758,15 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         // through row n - bf - 1, the lookup products start from one
         ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, S + NL, S, n - bf - 1));
         ZG_TRY(poly_blind_rows2(ctx, pz, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf, seed));  // (lz follows pz)
+        // The products stay constant wherever a row changes nothing (every padding row of the circuit): they are
+        // committed in the run form, sum_i (z_i - z_{i+1}) Q_i over the running sums Q of g_lagrange.
+        const uint64_t z_runs = p->gl->run_table && S + NL < 64 ? (1ull << (S + NL)) - 1ull : 0ull;
         ZG_TRY(fork());
         if (have_random) {
-            ZG_TRY(msm_batch_dev(ctx, p->gl, p->zs, n, S + NL, n, p->xyzz));
+            ZG_TRY(msm_batch3_dev(ctx, p->gl, nullptr, S + NL, p->zs, n, S + NL, n, p->xyzz, z_runs));
         } else {  // no lookups: the random polynomial rides here instead (row S+NL of zs)
             ZG_HIP(hipMemcpyAsync(p->zs + (size_t)(S + NL) * n, random_row, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
-            ZG_TRY(msm_batch2_dev(ctx, p->gl, p->g, S + NL, p->zs, n, S + NL + 1, n, p->xyzz));
+            ZG_TRY(msm_batch3_dev(ctx, p->gl, p->g, S + NL, p->zs, n, S + NL + 1, n, p->xyzz, z_runs));
         }
         const uint32_t npts = S + NL + (have_random ? 0 : 1);
         ZG_TRY(fetch_points(p, npts, pts));
