@@ -726,7 +726,9 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
                                     TAG_PERMUTED_TABLE));
         p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
         ZG_TRY(fork());
-        ZG_TRY(msm_batch2_dev(ctx, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, n, p->xyzz));
+        // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
+        const uint64_t sorted_runs = p->gl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
+        ZG_TRY(msm_batch3_dev(ctx, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, n, p->xyzz, sorted_runs));
         uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pinned_cap - 256);
         ZG_HIP(hipMemcpyAsync(h_err, p->d_err, NL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
