@@ -412,16 +412,20 @@ __global__ __launch_bounds__(256 * L) void msm_heavy_kernel(const XYZZ9* __restr
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         const uint32_t k = hlist[(size_t)b * max_heavy + h];
         const uint32_t t0 = to[k], t1 = to[k + 1];
+        uint32_t span = 32;  // slots in use: most hot buckets are barely past the threshold, few hold hundreds of partials
+        while (span < t1 - t0 && span < 256) span <<= 1;
         if constexpr (L > 1) {
             if (role == 0) sh[j] = xyzz9_identity();
-            for (uint32_t t = t0 + j; t < t1; t += 256) xstore<true>(&sh[j], xaddl<L>(&sh[j], pp + t, role));
+            if (j < span)
+                for (uint32_t t = t0 + j; t < t1; t += span) xstore<true>(&sh[j], xaddl<L>(&sh[j], pp + t, role));
         } else {  // (one lane per addition: the running sum stays in registers)
             XYZZ9 acc = xyzz9_identity();
-            for (uint32_t t = t0 + j; t < t1; t += 256) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
+            if (j < span)
+                for (uint32_t t = t0 + j; t < t1; t += span) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
             sh[j] = acc;
         }
         __syncthreads();
-        for (uint32_t o = 128; o > 0; o >>= 1) {
+        for (uint32_t o = span / 2; o > 0; o >>= 1) {
             if (j < o) {
                 if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(&sh[j], &sh[j + o], role));
                 else sh[j] = xyzz9_add(sh[j], sh[j + o]);
