@@ -709,7 +709,11 @@ int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         // lanes per addition when the block totals fit (c <= 13), else 128-bucket blocks with two
         static const int rb_env = getenv("ZG_MSM_RB") ? atoi(getenv("ZG_MSM_RB")) : 0;
         static const int lanes_env = getenv("ZG_MSM_LANES") ? atoi(getenv("ZG_MSM_LANES")) : 0;
-        uint32_t want = rb_env == 64 || rb_env == 128 || rb_env == 256 ? (uint32_t)rb_env : (nb + 63) / 64 <= 64 ? 64u : 128u;
+        // (64-bucket blocks only while each gets a CU to itself: tools/chain_probe.hip, 3.9 us per dependent addition
+        //  against 6.3 us once two workgroups share a CU and 4.3 us for two lanes on 128-bucket blocks)
+        const uint32_t nblk64 = (nb + 63) / 64;
+        const bool quad_fits = nblk64 <= 64 && (uint64_t)nblk64 * B <= (uint64_t)ctx->num_cus;
+        uint32_t want = rb_env == 64 || rb_env == 128 || rb_env == 256 ? (uint32_t)rb_env : quad_fits ? 64u : 128u;
         if ((nb + want - 1) / want <= want) rb = want;
         lanes = lanes_env == 2 || lanes_env == 4 ? lanes_env : rb == 64 ? 4 : 2;
         if (rb > 128) lanes = 2;  // (4 lanes x 256 buckets would exceed a workgroup)
