@@ -171,6 +171,34 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
     // barriers), one radix-2 stage at the end when the count is odd.
     auto at = [&](uint32_t sub, uint32_t e) { return COLS ? (e << log_cnt) + sub : (sub << log_m) + e; };
     uint32_t st = 0;
+    // Zero padding (coeff_to_extended: n coefficients in an 8n-point transform): rows j1 >= nz_rows of every
+    // column are zero.  While they start within the first quarter, the first radix-2^2 group of a column has
+    // one non-zero input at most -- three products instead of four where there is one, none where there is none.
+    if (FIRST && COLS && log_m >= 2) {
+        const uint32_t nz_rows = (a.in_len + N2 - 1) >> a.log_n2;
+        const uint32_t quarter = M >> 2, half = M >> 1;
+        if (nz_rows <= quarter) {
+            for (uint32_t g = tid; g < tile / 4; g += NT) {
+                const uint32_t sub = g & (cnt - 1), i = g >> log_cnt;  // (one block at this stage: e0 = i)
+                if (i >= nz_rows) continue;  // four zeros in, four zeros out: the tile already holds them
+                const uint32_t i0 = at(sub, i), i1 = at(sub, i + quarter), i2 = at(sub, i + half), i3 = at(sub, i + half + quarter);
+                const Fe x0 = ldx(i0);
+                Fe a2 = x0;
+                if (i != 0) a2 = Fr::mul(x0, ldt(i));
+                stx(i2, a2);
+                if (i != 0) {
+                    const Fe w = ldt(i << 1);
+                    stx(i1, Fr::mul(x0, w));
+                    stx(i3, Fr::mul(a2, w));
+                } else {
+                    stx(i1, x0);
+                    stx(i3, a2);
+                }
+            }
+            __syncthreads();
+            st = 2;
+        }
+    }
     for (; st + 1 < log_m; st += 2) {
         const uint32_t log_half = log_m - st - 1, log_q = log_half - 1;
         const uint32_t half = 1u << log_half, quarter = 1u << log_q;
