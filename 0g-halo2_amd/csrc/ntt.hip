@@ -649,11 +649,24 @@ int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t lo
     return ntt_batch_to_dev(ctx, d_a, d_a, stride, batch, log_n, omega, divisor);
 }
 
+int coeff_to_coset_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, uint32_t in_len, Fe* d_out, size_t out_stride,
+                       size_t batch, uint32_t ext_k, bool hat, int zeta_pow);
+int coset_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat, int zeta_pow);
+
 // hat: the evaluations come out multiplied by 2^5, i.e. in the 2^261 Montgomery form evaluate_h's
 // nine-limb arithmetic works in (the factor rides on the coset constants: one extra product for the
 // entries with j % 3 == 0, n of the 8n loaded)
 int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
                           size_t batch, uint32_t k, uint32_t ext_k, bool hat) {
+    return coeff_to_coset_dev(ctx, d_in, in_stride, 1u << k, d_out, out_stride, batch, ext_k, hat, 1);
+}
+
+// The general form: `in_len` coefficients (<= 2^ext_k) evaluated on the coset zeta^zeta_pow * <omega_(2^ext_k)>
+// (zeta_pow = 1: EvaluationDomain's own coset; 2: the second coset of the prover's split extended domain).
+int coeff_to_coset_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, uint32_t in_len, Fe* d_out, size_t out_stride,
+                       size_t batch, uint32_t ext_k, bool hat, int zeta_pow) {
+    ZG_REQUIRE(zeta_pow == 1 || zeta_pow == 2, ZG_ERR_INVALID_ARG, "coeff_to_coset: zeta power %d", zeta_pow);
+    ZG_REQUIRE(in_len <= (1u << ext_k), ZG_ERR_INVALID_ARG, "coeff_to_coset: %u coefficients for 2^%u points", in_len, ext_k);
     ZG_TRY(ensure_lds_attr());
     WsScope ws(ctx);
     NttPlan p;
@@ -662,12 +675,12 @@ int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_o
     p.batch = batch;
     p.log_n = ext_k;
     p.omega = host_domain_omega(ext_k);
-    p.in_len = 1u << k;
+    p.in_len = in_len;
     p.out_len = 1u << ext_k;
     p.coset_in = 1;
     p.zin0 = Fr::one();
-    p.zin1 = fr_zeta();
-    p.zin2 = Fr::sqr(fr_zeta());
+    p.zin1 = zeta_pow == 1 ? fr_zeta() : Fr::sqr(fr_zeta());   // shift^1
+    p.zin2 = zeta_pow == 1 ? Fr::sqr(fr_zeta()) : fr_zeta();   // shift^2 (zeta^4 = zeta)
     if (hat) {
         const Fe c32 = Fr::from_u64(32);
         p.coset_in = 2;
@@ -690,6 +703,11 @@ int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_o
 int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len,
                           Fe* d_out, bool unhat) {
     (void)k;
+    return coset_to_coeff_dev(ctx, d_evals, ext_k, out_len, d_out, unhat, 1);
+}
+
+int coset_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat, int zeta_pow) {
+    ZG_REQUIRE(zeta_pow == 1 || zeta_pow == 2, ZG_ERR_INVALID_ARG, "coset_to_coeff: zeta power %d", zeta_pow);
     ZG_TRY(ensure_lds_attr());
     WsScope ws(ctx);
     size_t n = (size_t)1 << ext_k;
@@ -705,8 +723,8 @@ int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, 
     p.scale_out = true;
     p.scale = Fr::inv(Fr::from_u64((uint64_t)n * (unhat ? 32u : 1u)));
     p.coset_out = true;
-    p.zout1 = Fr::sqr(fr_zeta());  // zeta^-1
-    p.zout2 = fr_zeta();           // zeta^-2
+    p.zout1 = zeta_pow == 1 ? Fr::sqr(fr_zeta()) : fr_zeta();  // shift^-1
+    p.zout2 = zeta_pow == 1 ? fr_zeta() : Fr::sqr(fr_zeta());  // shift^-2
     Fe* tmp = nullptr;
     if (ntt_needs_tmp(ext_k)) {
         tmp = ws.get<Fe>(n);

@@ -150,6 +150,13 @@ int ntt_batch_to_dev(zg_ctx* ctx, const Fe* d_in, Fe* d_out, size_t stride, size
 int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
                           size_t batch, uint32_t k, uint32_t ext_k, bool hat);
 int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat);
+int coeff_to_coset_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, uint32_t in_len, Fe* d_out, size_t out_stride,
+                       size_t batch, uint32_t ext_k, bool hat, int zeta_pow);
+int coset_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat, int zeta_pow);
+// split extended domain (prover.hip): the pieces of the interpolation between its two cosets
+int poly_fold(zg_ctx* ctx, const Fe* a, uint32_t len, uint32_t parts, const Fe& e, Fe* out);  // out[r] = sum_q a[r + q*len] e^q
+int poly_diff_scale(zg_ctx* ctx, const Fe* u, const Fe& cu, const Fe* v, const Fe& scale, Fe* out, uint32_t len);  // (u*cu - v)*scale
+int poly_split_combine(zg_ctx* ctx, Fe* h, const Fe* b, uint32_t len, const Fe& c1, uint32_t hi_at);  // h[j] -= c1 b[j]; h[hi_at + j] = b[j]
 // from msm.hip
 int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch, size_t n,
                   XYZZ* d_out);

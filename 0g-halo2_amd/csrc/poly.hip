@@ -1027,4 +1027,40 @@ int poly_scale(zg_ctx* ctx, const Fe* in, Fe* out, size_t count, const Fe& facto
     return ZG_OK;
 }
 
+// ---- interpolation across the two cosets of the split extended domain (prover.hip)
+__global__ void fold_kernel(const Fe* a, uint32_t len, uint32_t parts, Fe e, Fe* out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= len) return;
+    Fe acc = ldg(a + (size_t)(parts - 1) * len + r);
+    for (uint32_t q = parts - 1; q-- > 0;) acc = Fr::add(Fr::mul(acc, e), ldg(a + (size_t)q * len + r));
+    stg(out + r, acc);
+}
+int poly_fold(zg_ctx* ctx, const Fe* a, uint32_t len, uint32_t parts, const Fe& e, Fe* out) {
+    ZG_REQUIRE(parts >= 1 && len >= 1, ZG_ERR_INVALID_ARG, "poly_fold: %u parts of %u", parts, len);
+    ZG_LAUNCH(ctx, "fold", (double)(parts + 1) * len * 32, fold_kernel, dim3((len + 255) / 256), dim3(256), 0, a, len, parts, e, out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+__global__ void diff_scale_kernel(const Fe* u, Fe cu, const Fe* v, Fe scale, Fe* out, uint32_t len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) stg(out + i, Fr::mul(Fr::sub(Fr::mul(ldg(u + i), cu), ldg(v + i)), scale));
+}
+int poly_diff_scale(zg_ctx* ctx, const Fe* u, const Fe& cu, const Fe* v, const Fe& scale, Fe* out, uint32_t len) {
+    ZG_LAUNCH(ctx, "diff_scale", (double)len * 96, diff_scale_kernel, dim3((len + 255) / 256), dim3(256), 0, u, cu, v, scale, out, len);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+__global__ void split_combine_kernel(Fe* h, const Fe* b, uint32_t len, Fe c1, uint32_t hi_at) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    const Fe bj = ldg(b + j);
+    stg(h + j, Fr::sub(ldg(h + j), Fr::mul(c1, bj)));
+    stg(h + hi_at + j, bj);
+}
+int poly_split_combine(zg_ctx* ctx, Fe* h, const Fe* b, uint32_t len, const Fe& c1, uint32_t hi_at) {
+    ZG_LAUNCH(ctx, "split_combine", (double)len * 128, split_combine_kernel, dim3((len + 255) / 256), dim3(256), 0, h, b, len, c1, hi_at);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 }  // namespace zg

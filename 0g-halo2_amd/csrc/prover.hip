@@ -97,25 +97,37 @@ struct zg_prover {
     zg_poly* gate_uni = nullptr;
     Fe* uni_coef = nullptr;
     uint32_t* gate_slab = nullptr;  // per gate: index of its U(fixed cell) coset in gate_slabs, or 0xffffffff
-    Fe* gate_slabs = nullptr;
     struct SlabJob { uint32_t gate, query, first, count; };
     std::vector<SlabJob> slab_jobs;  // filled when the gates are factored, run once the fixed cosets exist
     bool own_bases = true;  // false: tables shared with other provers of the same device
     Fe vk_repr{};
     Fe omega{}, omega_inv{}, ifft_div{};
     // pk-derived, resident
-    Fe *fixed_val = nullptr, *sigma_val = nullptr, *fixed_cos = nullptr, *sigma_cos = nullptr;
-    Fe *l0 = nullptr, *llast = nullptr, *lactive = nullptr, *t_eval = nullptr, *omega_tw = nullptr, *ext_tw = nullptr;
+    Fe *fixed_val = nullptr, *sigma_val = nullptr, *omega_tw = nullptr;
+    // The extended domain evaluate_h works on.  Either EvaluationDomain's own coset zeta * <omega_(2^ext_k)> (8n points
+    // for degree 6), or -- split -- two cosets that together hold just the (degree - 1) * n points the quotient needs:
+    // zeta * <omega_(m1 n)> and zeta^2 * <omega_(m2 n)>, m1 + m2 = degree - 1 (4n + n).  Every coset slab exists per part.
+    struct Dom {
+        uint32_t ek = 0, en = 0;
+        int zpow = 1;  // the coset shift is zeta^zpow
+        Fe *fixed_cos = nullptr, *sigma_cos = nullptr, *l0 = nullptr, *llast = nullptr, *lactive = nullptr,
+           *gate_slabs = nullptr, *t_eval = nullptr, *ext_tw = nullptr;                                   // proving key
+        Fe *adv_cos = nullptr, *inst_cos = nullptr, *pz_cos = nullptr, *lz_cos = nullptr, *perm_cos = nullptr,
+           *h = nullptr;                                                                                   // per proof
+    };
+    Dom dom[3];               // [0]: the single coset; [1], [2]: the two parts of the split domain (when it applies)
+    uint32_t nparts = 1;      // 1, or 3 when the split domain is prepared too
+    bool last_split = false;  // which of the two the last proof used (zg_prover_fetch)
+    Fe* split_tmp = nullptr;  // interpolation between the two parts: 3 * dom[2].en elements
     // coefficient-form slab [n_polys][n]
     Fe* polys = nullptr;
     uint32_t n_polys = 0;
     uint32_t ix_fixed = 0, ix_sigma = 0, ix_adv = 0, ix_inst = 0, ix_pz = 0, ix_lz = 0, ix_perm = 0, ix_random = 0,
              ix_hpiece = 0, ix_hpoly = 0;
     // per-proof buffers
-    Fe *adv_val = nullptr, *inst_val = nullptr, *adv_cos = nullptr, *inst_cos = nullptr, *pz_cos = nullptr,
-       *lz_cos = nullptr, *perm_cos = nullptr;
+    Fe *adv_val = nullptr, *inst_val = nullptr;
     Fe *cin = nullptr, *ctab = nullptr, *perm = nullptr /* [2NL][n]: a'_l, s'_l */, *zs = nullptr /* [sets+NL][n] */;
-    Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *h = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr,
+    Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr,
        *raw = nullptr, *sraw = nullptr, *sort_fe = nullptr;
     uint32_t *sort_u32 = nullptr, *d_err = nullptr;
     Fe *pin_c = nullptr, *ptab_c = nullptr;
@@ -520,19 +532,43 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_TRY(dalloc(p, &p->polys, (size_t)p->n_polys * n));
     ZG_TRY(dalloc(p, &p->fixed_val, (size_t)F * n));
     ZG_TRY(dalloc(p, &p->sigma_val, (size_t)P * n));
-    ZG_TRY(dalloc(p, &p->fixed_cos, (size_t)F * en));
-    ZG_TRY(dalloc(p, &p->sigma_cos, (size_t)P * en));
-    ZG_TRY(dalloc(p, &p->l0, (size_t)en));
-    ZG_TRY(dalloc(p, &p->llast, (size_t)en));
-    ZG_TRY(dalloc(p, &p->lactive, (size_t)en));
+    // parts of the extended domain
+    {
+        static const bool split_env = !(getenv("ZG_SPLIT_DOMAIN") && atoi(getenv("ZG_SPLIT_DOMAIN")) == 0);  // A/B knob
+        uint32_t m1 = 1;
+        while (m1 * 2 <= Q) m1 *= 2;
+        const uint32_t m2 = Q - m1;
+        const bool split = split_env && p->hat && m2 != 0 && (m2 & (m2 - 1)) == 0 && (m1 + m2) * n < en;
+        auto log2u = [](uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; };
+        // The single coset serves the latency configuration (a lone proof pays for the extra launches of the split
+        // form in its h phase: 0.72 -> 0.93 ms), the split one the throughput configuration (-5 % ms/proof); both sets
+        // of proving-key cosets are kept (+60 % of 0.2 GB per prover) and zg_prover_set_overlap picks.
+        p->nparts = 1;
+        p->dom[0].ek = p->ext_k; p->dom[0].en = en; p->dom[0].zpow = 1;
+        if (split) {
+            p->nparts = 3;
+            p->dom[1].ek = p->k + log2u(m1); p->dom[1].en = n * m1; p->dom[1].zpow = 1;
+            p->dom[2].ek = p->k + log2u(m2); p->dom[2].en = n * m2; p->dom[2].zpow = 2;
+            ZG_TRY(dalloc(p, &p->split_tmp, (size_t)3 * p->dom[2].en));
+        }
+    }
+    for (uint32_t di = 0; di < p->nparts; di++) {
+        zg_prover::Dom& d = p->dom[di];
+        ZG_TRY(dalloc(p, &d.fixed_cos, (size_t)F * d.en));
+        ZG_TRY(dalloc(p, &d.sigma_cos, (size_t)P * d.en));
+        ZG_TRY(dalloc(p, &d.l0, (size_t)d.en));
+        ZG_TRY(dalloc(p, &d.llast, (size_t)d.en));
+        ZG_TRY(dalloc(p, &d.lactive, (size_t)d.en));
+        ZG_TRY(dalloc(p, &d.adv_cos, (size_t)A * d.en));
+        ZG_TRY(dalloc(p, &d.inst_cos, (size_t)I * d.en));
+        ZG_TRY(dalloc(p, &d.pz_cos, (size_t)S * d.en));
+        ZG_TRY(dalloc(p, &d.lz_cos, (size_t)NL * d.en));
+        ZG_TRY(dalloc(p, &d.perm_cos, (size_t)2 * NL * d.en));
+        ZG_TRY(dalloc(p, &d.h, (size_t)d.en));
+    }
     ZG_TRY(dalloc(p, &p->adv_val, (size_t)A * n));
     ZG_TRY(dalloc(p, &p->inst_val, (size_t)I * n));
     if (I) ZG_HIP(hipMemset(p->inst_val, 0, (size_t)I * n * 32));  // rows past the instance stay zero (prove refills only what it must)
-    ZG_TRY(dalloc(p, &p->adv_cos, (size_t)A * en));
-    ZG_TRY(dalloc(p, &p->inst_cos, (size_t)I * en));
-    ZG_TRY(dalloc(p, &p->pz_cos, (size_t)S * en));
-    ZG_TRY(dalloc(p, &p->lz_cos, (size_t)NL * en));
-    ZG_TRY(dalloc(p, &p->perm_cos, (size_t)2 * NL * en));
     ZG_TRY(dalloc(p, &p->pin_c, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->ptab_c, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->cin, (size_t)2 * NL * n));  // compressed inputs, then compressed tables
@@ -543,7 +579,6 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_TRY(dalloc(p, &p->num, (size_t)mb * n));
     ZG_TRY(dalloc(p, &p->den, (size_t)mb * n));
     ZG_TRY(dalloc(p, &p->tmp, poly_grand_product_tmp_elems(n, mb)));
-    ZG_TRY(dalloc(p, &p->h, (size_t)en));
     ZG_TRY(dalloc(p, &p->raw, (size_t)2 * NL * n));
     ZG_TRY(dalloc(p, &p->sraw, (size_t)NL * n));
     ZG_TRY(dalloc(p, &p->sort_fe, (size_t)NL * n));
@@ -566,20 +601,26 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_HIP(hipMemcpyAsync(p->fixed_val, fixed_values, (size_t)F * n * 32, hipMemcpyHostToDevice, st));
         Fe* fp = p->polys + (size_t)p->ix_fixed * n;
         ZG_TRY(ntt_batch_to_dev(ctx, p->fixed_val, fp, n, F, p->k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, fp, n, p->fixed_cos, en, F, p->k, p->ext_k, p->hat));
+        for (uint32_t di = 0; di < p->nparts; di++) {
+            zg_prover::Dom& d = p->dom[di];
+            ZG_TRY(coeff_to_coset_dev(ctx, fp, n, n, d.fixed_cos, d.en, F, d.ek, p->hat, d.zpow));
+        }
     }
     if (p->hat) {
         // a gate factor that is a polynomial in a FIXED cell (a merged selector) does not depend on the
         // witness: its coset is part of the proving key here, as the unmerged selector's would have been
         std::vector<uint32_t> slab_of(cs->n_gates ? cs->n_gates : 1, 0xffffffffu);
         ZG_TRY(dalloc(p, &p->gate_slab, slab_of.size()));
-        ZG_TRY(dalloc(p, &p->gate_slabs, std::max<size_t>(1, p->slab_jobs.size() * (size_t)en)));
-        for (size_t j = 0; j < p->slab_jobs.size(); j++) {
-            const auto& job = p->slab_jobs[j];
-            const zg_query q = cs->queries[job.query];
-            ZG_TRY(poly_gate_factor(ctx, p->fixed_cos + (size_t)q.column * en, (uint32_t)(q.rotation * (int32_t)(en / n)), en,
-                                    p->uni_coef + job.first, job.count, p->gate_slabs + j * (size_t)en));
-            slab_of[job.gate] = (uint32_t)j;
+        for (uint32_t di = 0; di < p->nparts; di++) {
+            zg_prover::Dom& d = p->dom[di];
+            ZG_TRY(dalloc(p, &d.gate_slabs, std::max<size_t>(1, p->slab_jobs.size() * (size_t)d.en)));
+            for (size_t j = 0; j < p->slab_jobs.size(); j++) {
+                const auto& job = p->slab_jobs[j];
+                const zg_query q = cs->queries[job.query];
+                ZG_TRY(poly_gate_factor(ctx, d.fixed_cos + (size_t)q.column * d.en, (uint32_t)(q.rotation * (int32_t)(d.en / n)),
+                                        d.en, p->uni_coef + job.first, job.count, d.gate_slabs + j * (size_t)d.en));
+                slab_of[job.gate] = (uint32_t)j;
+            }
         }
         ZG_HIP(hipMemcpyAsync(p->gate_slab, slab_of.data(), slab_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         ZG_HIP(hipStreamSynchronize(st));
@@ -588,7 +629,10 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_HIP(hipMemcpyAsync(p->sigma_val, sigma_values, (size_t)P * n * 32, hipMemcpyHostToDevice, st));
         Fe* sp = p->polys + (size_t)p->ix_sigma * n;
         ZG_TRY(ntt_batch_to_dev(ctx, p->sigma_val, sp, n, P, p->k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, sp, n, p->sigma_cos, en, P, p->k, p->ext_k, p->hat));
+        for (uint32_t di = 0; di < p->nparts; di++) {
+            zg_prover::Dom& d = p->dom[di];
+            ZG_TRY(coeff_to_coset_dev(ctx, sp, n, n, d.sigma_cos, d.en, P, d.ek, p->hat, d.zpow));
+        }
     }
     {
         WsScope ws(ctx);
@@ -597,27 +641,32 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         if (ws.failed) return ZG_ERR_OOM;
         ZG_TRY(poly_l_cosets_init(ctx, t3, t3 + n, t3 + 2 * n, n, p->bf));
         ZG_TRY(ntt_batch_dev(ctx, t3, n, 3, p->k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(ctx, t3, n, p->l0, en, 1, p->k, p->ext_k, p->hat));
-        ZG_TRY(coeff_to_extended_dev(ctx, t3 + n, n, p->llast, en, 1, p->k, p->ext_k, p->hat));
-        ZG_TRY(coeff_to_extended_dev(ctx, t3 + 2 * n, n, lblind, en, 1, p->k, p->ext_k, p->hat));
-        ZG_TRY(poly_lactive(ctx, p->lactive, p->llast, lblind, en, p->hat));
+        for (uint32_t di = 0; di < p->nparts; di++) {
+            zg_prover::Dom& d = p->dom[di];
+            ZG_TRY(coeff_to_coset_dev(ctx, t3, n, n, d.l0, d.en, 1, d.ek, p->hat, d.zpow));
+            ZG_TRY(coeff_to_coset_dev(ctx, t3 + n, n, n, d.llast, d.en, 1, d.ek, p->hat, d.zpow));
+            ZG_TRY(coeff_to_coset_dev(ctx, t3 + 2 * n, n, n, lblind, d.en, 1, d.ek, p->hat, d.zpow));
+            ZG_TRY(poly_lactive(ctx, d.lactive, d.llast, lblind, d.en, p->hat));
+        }
         ZG_HIP(hipStreamSynchronize(st));
     }
-    // t_evaluations of EvaluationDomain: ((zeta * ext_omega^i)^n - 1)^-1, one period
-    {
-        uint32_t t_len = 1u << (p->ext_k - p->k);
+    // t_evaluations of EvaluationDomain: ((shift * ext_omega^i)^n - 1)^-1, one period, per part of the domain
+    ZG_TRY(get_twiddles(ctx, p->k, p->omega, &p->omega_tw));
+    for (uint32_t di = 0; di < p->nparts; di++) {
+        zg_prover::Dom& d = p->dom[di];
+        uint32_t t_len = 1u << (d.ek - p->k);
         std::vector<Fe> te(t_len);
-        Fe ext_omega = host_domain_omega(p->ext_k);
-        Fe cur = Fr::pow_u64(fr_zeta(), n), step = Fr::pow_u64(ext_omega, n);
+        Fe ext_omega = host_domain_omega(d.ek);
+        const Fe shift = d.zpow == 1 ? fr_zeta() : Fr::sqr(fr_zeta());
+        Fe cur = Fr::pow_u64(shift, n), step = Fr::pow_u64(ext_omega, n);
         for (uint32_t i = 0; i < t_len; i++) {
             te[i] = Fr::inv(Fr::sub(cur, Fr::one()));
             if (p->hat) te[i] = Fr::mul(te[i], Fr9Params::c261_fe());
             cur = Fr::mul(cur, step);
         }
-        ZG_TRY(dalloc(p, &p->t_eval, t_len));
-        ZG_HIP(hipMemcpy(p->t_eval, te.data(), t_len * sizeof(Fe), hipMemcpyHostToDevice));
-        ZG_TRY(get_twiddles(ctx, p->k, p->omega, &p->omega_tw));
-        ZG_TRY(get_twiddles(ctx, p->ext_k, ext_omega, &p->ext_tw));
+        ZG_TRY(dalloc(p, &d.t_eval, t_len));
+        ZG_HIP(hipMemcpy(d.t_eval, te.data(), t_len * sizeof(Fe), hipMemcpyHostToDevice));
+        ZG_TRY(get_twiddles(ctx, d.ek, ext_omega, &d.ext_tw));
     }
     ZG_HIP(hipStreamSynchronize(st));
     *out = guard.release();
@@ -632,9 +681,12 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     zg_ctx* ctx = p->ctx;
     ZG_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const uint32_t n = p->n, en = p->en, k = p->k, ek = p->ext_k, bf = p->bf, usable = p->usable;
+    const uint32_t n = p->n, k = p->k, ek = p->ext_k, bf = p->bf, usable = p->usable;
     const uint32_t F = p->F, A = p->A, I = p->I, P = p->P, NL = p->NL, S = p->sets, Q = p->qpd;
     (void)F;
+    // extended-domain parts of this proof: the split pair in the throughput configuration, the single coset otherwise
+    const bool split = p->nparts == 3 && !p->use_side;
+    const uint32_t dlo = split ? 1u : 0u, dhi = split ? 3u : 1u;
     Fe* polys = p->polys;
     auto poly_at = [&](uint32_t ix) { return polys + (size_t)ix * n; };
     EvmTranscript tr;
@@ -691,13 +743,15 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     ZG_TRY(fork());
     if (I) {
         ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_inst), n, p->inst_cos, en, I, k, ek, p->hat));
+        for (uint32_t di = dlo; di < dhi; di++)
+            ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_inst), n, n, p->dom[di].inst_cos, p->dom[di].en, I, p->dom[di].ek, p->hat, p->dom[di].zpow));
     }
     if (A) {
         ZG_TRY(msm_batch_dev(ctx, p->gl, adv, n, A, n, p->xyzz));
         ZG_TRY(fetch_points(p, A, pts));
         ZG_TRY(ntt_batch_to_dev(sx, adv, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_adv), n, p->adv_cos, en, A, k, ek, p->hat));
+        for (uint32_t di = dlo; di < dhi; di++)
+            ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_adv), n, n, p->dom[di].adv_cos, p->dom[di].en, A, p->dom[di].ek, p->hat, p->dom[di].zpow));
         ZG_TRY(wait_points(p, A, pts));
         for (auto& q : pts) tr.write_point(q);
     }
@@ -733,7 +787,8 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_HIP(hipMemcpyAsync(h_err, p->d_err, NL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
         ZG_TRY(ntt_batch_to_dev(sx, p->perm, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
-        ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_perm), n, p->perm_cos, en, 2 * NL, k, ek, p->hat));
+        for (uint32_t di = dlo; di < dhi; di++)
+            ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_perm), n, n, p->dom[di].perm_cos, p->dom[di].en, 2 * NL, p->dom[di].ek, p->hat, p->dom[di].zpow));
         ZG_TRY(wait_points(p, 2 * NL + 1, pts));
         for (uint32_t l = 0; l < NL; l++)
             if (h_err[l]) {
@@ -773,8 +828,11 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         const uint32_t npts = S + NL + (have_random ? 0 : 1);
         ZG_TRY(fetch_points(p, npts, pts));
         ZG_TRY(ntt_batch_to_dev(sx, p->zs, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
-        if (S) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_pz), n, p->pz_cos, en, S, k, ek, p->hat));
-        if (NL) ZG_TRY(coeff_to_extended_dev(sx, poly_at(p->ix_lz), n, p->lz_cos, en, NL, k, ek, p->hat));
+        for (uint32_t di = dlo; di < dhi; di++) {
+            const zg_prover::Dom& d = p->dom[di];
+            if (S) ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_pz), n, n, d.pz_cos, d.en, S, d.ek, p->hat, d.zpow));
+            if (NL) ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_lz), n, n, d.lz_cos, d.en, NL, d.ek, p->hat, d.zpow));
+        }
         ZG_TRY(wait_points(p, npts, pts));
         for (uint32_t i = 0; i < S + NL; i++) tr.write_point(pts[i]);
         if (!have_random) {
@@ -793,22 +851,23 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     const Fe y = tr.squeeze();
     lap(2);
 
-    // ---- evaluate_h (+ division by X^n - 1), back to coefficients, h pieces
-    {
+    // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
+    for (uint32_t di = dlo; di < dhi; di++) {
+        const zg_prover::Dom& d = p->dom[di];
         EvalHArgs a;
         memset(&a, 0, sizeof(a));
         a.c = p->dc;
-        a.cols.fixed = p->fixed_cos; a.cols.advice = p->adv_cos; a.cols.instance = p->inst_cos;
-        a.cols.log_size = ek; a.cols.rot_scale = (int32_t)(en / n);
-        a.sigma_cos = p->sigma_cos; a.pz_cos = p->pz_cos; a.lz_cos = p->lz_cos;
+        a.cols.fixed = d.fixed_cos; a.cols.advice = d.adv_cos; a.cols.instance = d.inst_cos;
+        a.cols.log_size = d.ek; a.cols.rot_scale = (int32_t)(d.en / n);
+        a.sigma_cos = d.sigma_cos; a.pz_cos = d.pz_cos; a.lz_cos = d.lz_cos;
         // perm_cos is interleaved, [2l] = a'_l and [2l+1] = s'_l: two views with a stride of two slabs
-        a.pin_cos = p->perm_cos; a.ptab_cos = p->perm_cos + en; a.perm_stride = (size_t)2 * en;
-        a.l0 = p->l0; a.llast = p->llast; a.lactive = p->lactive;
-        a.ext_tw = p->hat ? p->ext_tw + en : p->ext_tw;  // (the twiddle table's second half is the 2^261 form)
-        a.t_eval = p->t_eval; a.t_mask = (1u << (ek - k)) - 1;
+        a.pin_cos = d.perm_cos; a.ptab_cos = d.perm_cos + d.en; a.perm_stride = (size_t)2 * d.en;
+        a.l0 = d.l0; a.llast = d.llast; a.lactive = d.lactive;
+        a.ext_tw = p->hat ? d.ext_tw + d.en : d.ext_tw;  // (the twiddle table's second half is the 2^261 form)
+        a.t_eval = d.t_eval; a.t_mask = (1u << (d.ek - k)) - 1;
         a.last_rot = -(int32_t)(bf + 1);
         a.y = y; a.beta = beta; a.gamma = gamma; a.theta = theta;
-        a.delta_start = Fr::mul(beta, fr_zeta()); a.delta = fr_delta();
+        a.delta_start = Fr::mul(beta, d.zpow == 1 ? fr_zeta() : Fr::sqr(fr_zeta())); a.delta = fr_delta();  // beta * coset shift
         a.hat = p->hat;
         a.monos_hat = p->monos_hat;
         a.gates_hat = p->gates_hat;
@@ -816,16 +875,36 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         a.gate_uni = p->gate_uni;
         a.uni_coef = p->uni_coef;
         a.gate_slab = p->gate_slab;
-        a.gate_slabs = p->gate_slabs;
+        a.gate_slabs = d.gate_slabs;
         if (p->hat) {
             const Fe c261 = Fr9Params::c261_fe();
             for (Fe* cst : {&a.y, &a.beta, &a.gamma, &a.theta, &a.delta_start, &a.delta}) *cst = Fr::mul(*cst, c261);
         }
-        a.h = p->h;
-        ZG_TRY(poly_evaluate_h(ctx, a, en));
+        a.h = d.h;
+        ZG_TRY(poly_evaluate_h(ctx, a, d.en));
     }
     p->have_last = true;
-    ZG_TRY(extended_to_coeff_dev(ctx, p->h, k, ek, (size_t)Q * n, poly_at(p->ix_hpiece), p->hat));
+    p->last_split = split;
+    if (!split) {
+        ZG_TRY(extended_to_coeff_dev(ctx, p->dom[0].h, k, ek, (size_t)Q * n, poly_at(p->ix_hpiece), p->hat));
+    } else {
+        // h = A + (X^L1 - c1) B:  A (degree < L1) from the first coset, where X^L1 = c1 = shift1^L1;  B (degree < L2)
+        // from the second, where X^L1 = c2 and X^L2 = e are constants too:  B = (h - A) / (c2 - c1) there, with A
+        // folded modulo X^L2 - e before it is evaluated on those L2 points.
+        const zg_prover::Dom &d1 = p->dom[1], &d2 = p->dom[2];
+        const uint32_t L1 = d1.en, L2 = d2.en;
+        const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
+        const Fe c1 = Fr::pow_u64(zeta, L1), c2 = Fr::pow_u64(zeta2, L1), e = Fr::pow_u64(zeta2, L2);
+        Fe* hp = poly_at(p->ix_hpiece);
+        Fe *fold = p->split_tmp, *a2 = fold + L2, *bc = a2 + L2;
+        ZG_TRY(coset_to_coeff_dev(ctx, d1.h, d1.ek, L1, hp, p->hat, 1));               // A, in place of the low pieces
+        ZG_TRY(poly_fold(ctx, hp, L2, L1 / L2, e, fold));                               // A mod (X^L2 - e)
+        ZG_TRY(coeff_to_coset_dev(ctx, fold, L2, L2, a2, L2, 1, d2.ek, false, 2));      // A on the second coset
+        const Fe unhat = p->hat ? Fr::inv(Fr::from_u64(32)) : Fr::one();
+        ZG_TRY(poly_diff_scale(ctx, d2.h, unhat, a2, Fr::inv(Fr::sub(c2, c1)), a2, L2));  // B on the second coset
+        ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2));                   // B
+        ZG_TRY(poly_split_combine(ctx, hp, bc, L2, c1, L1));                            // h = A - c1 B + X^L1 B
+    }
     ZG_TRY(msm_batch_dev(ctx, p->g, poly_at(p->ix_hpiece), n, Q, n, p->xyzz));
     ZG_TRY(fetch_points(p, Q, pts));
     ZG_TRY(wait_points(p, Q, pts));
@@ -1022,7 +1101,7 @@ int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, siz
     size_t count = 0;
     const size_t n = p->n;
     switch (what) {
-        case 0: src = p->h; count = p->en; break;
+        case 0: src = p->dom[0].h; count = p->en; break;
         case 1: ZG_REQUIRE(index < p->sets, ZG_ERR_INVALID_ARG, "zg_prover_fetch: set %u", index);
                 src = p->zs + (size_t)index * n; count = n; break;
         case 2: ZG_REQUIRE(index < p->NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
@@ -1036,6 +1115,16 @@ int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, siz
     }
     ZG_REQUIRE(cap_elems >= count, ZG_ERR_INVALID_ARG, "zg_prover_fetch: need %zu elements", count);
     ZG_HIP(hipSetDevice(p->ctx->device));
+    if (what == 0 && p->last_split) {  // split domain: h on EvaluationDomain's coset, from its coefficients
+        WsScope ws(p->ctx);
+        Fe* tmp = ws.get<Fe>(count);
+        if (!tmp) return ZG_ERR_OOM;
+        const Fe* hp = p->polys + (size_t)p->ix_hpiece * n;
+        ZG_TRY(coeff_to_coset_dev(p->ctx, hp, (size_t)p->qpd * n, (uint32_t)(p->qpd * n), tmp, count, 1, p->ext_k, false, 1));
+        ZG_HIP(hipStreamSynchronize(p->ctx->stream));
+        ZG_HIP(hipMemcpy(out, tmp, count * 32, hipMemcpyDeviceToHost));
+        return ZG_OK;
+    }
     if (what == 0 && p->hat) {  // h on the coset is kept as x * 2^261: hand back the library form
         WsScope ws(p->ctx);
         Fe* tmp = ws.get<Fe>(count);

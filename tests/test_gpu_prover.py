@@ -232,7 +232,10 @@ def test_real_wnn_circuit_tiny_proof_bytes_match_oracle(ctx, zg, orc):
     cs, asg, ilen, scores, pk, prover = _real_model(orc, zg, ctx, wnn_model.MNIST_TINY)
     assert scores == [9, 6, 13, 10, 17, 10, 9, 26, 11, 16]
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
-    for seed in (1, 99):
+    # both configurations: overlap on = one 8n-point coset, two lanes per EC addition; overlap off (the bench's
+    # throughput form) = the split 4n + n extended domain, one lane per addition
+    for seed, overlap in ((1, True), (99, False), (7, True)):
+        prover.set_overlap(overlap)
         got = prover.prove(adv, inst, seed)
         st, want, _ = orc.create_proof(pk, adv, inst, seed)
         assert st == 0 and got == want
