@@ -45,41 +45,28 @@ if old:
         if os.path.exists(f):
             os.remove(f)
 
-# VALU wave-instructions per proof: the run holds throughput- and latency-configuration proofs; the MSM kernels
-# are attributed by their template instantiation (<1, ..> / <false> = throughput), everything else is shared
-acc, disp = defaultdict(float), defaultdict(set)
-for r in csv.DictReader(open(valu)):
-    if r["Counter_Name"] != "SQ_INSTS_VALU":
-        continue
+# VALU wave-instructions per proof: the single-stream run is cut into proofs at the kernel every proof starts with
+# (random_and_blind); a proof is a throughput-configuration one when its MSM reduction ran in the one-lane form
+rows = [r for r in csv.DictReader(open(valu)) if r["Counter_Name"] == "SQ_INSTS_VALU"]
+rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+proofs, cur = [], None
+for r in rows:
     n = re.sub(r"^(void )?zg::", "", r["Kernel_Name"]).split("(")[0]
-    acc[n] += float(r["Counter_Value"])
-    disp[n].add(r["Dispatch_Id"])
-setup = {"msm_table_kernel", "srs_kernel", "twiddle_kernel", "l_init_kernel", "lactive_kernel", "gate_factor9_kernel"}
-
-
-def throughput_form(n):
-    return bool(re.search(r"<(1|false)[,>]", n))
-
-
-fin_t = [n for n in disp if n.startswith("msm_bucket_sum_kernel") and throughput_form(n)]
-fin_l = [n for n in disp if n.startswith("msm_bucket_sum_kernel") and not throughput_form(n)]
-nt = sum(len(disp[n]) for n in fin_t) // 5
-nl = sum(len(disp[n]) for n in fin_l) // 5
-thr = lat = 0.0
-per = {}
-for n, v in acc.items():
-    if n in setup:
-        continue
-    if n.startswith("msm_") and "<" in n:
-        if throughput_form(n):
-            thr += v / nt
-            per[n] = v / nt
-        else:
-            lat += v / nl
-    else:
-        thr += v / (nt + nl)
-        lat += v / (nt + nl)
-        per[n] = v / (nt + nl)
+    if n.startswith("random_"):
+        cur = defaultdict(float)
+        proofs.append(cur)
+    if cur is not None:
+        cur[n] += float(r["Counter_Value"])
+proofs = [q for q in proofs if any(k.startswith("msm_bucket_sum_kernel") for k in q)]  # (complete ones)
+thr_proofs = [q for q in proofs if any(re.match(r"msm_bucket_sum_kernel<1,", k) for k in q)]
+lat_proofs = [q for q in proofs if q not in thr_proofs]
+nt, nl = len(thr_proofs), len(lat_proofs)
+per = defaultdict(float)
+for q in thr_proofs:
+    for k, v in q.items():
+        per[k] += v / nt
+thr = sum(per.values())
+lat = sum(sum(q.values()) for q in lat_proofs) / max(nl, 1)
 p = os.path.join(dst, "pmc_traffic.json")
 d = json.load(open(p))
 d["valu"] = {
