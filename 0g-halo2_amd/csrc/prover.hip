@@ -559,11 +559,13 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_TRY(dalloc(p, &d.l0, (size_t)d.en));
         ZG_TRY(dalloc(p, &d.llast, (size_t)d.en));
         ZG_TRY(dalloc(p, &d.lactive, (size_t)d.en));
-        ZG_TRY(dalloc(p, &d.adv_cos, (size_t)A * d.en));
-        ZG_TRY(dalloc(p, &d.inst_cos, (size_t)I * d.en));
-        ZG_TRY(dalloc(p, &d.pz_cos, (size_t)S * d.en));
-        ZG_TRY(dalloc(p, &d.lz_cos, (size_t)NL * d.en));
-        ZG_TRY(dalloc(p, &d.perm_cos, (size_t)2 * NL * d.en));
+        // (one block, in the order of the coefficient slab: advice, instance, permutation z, lookup z, a'/s' -- the
+        //  split form transforms all of them in one batch)
+        ZG_TRY(dalloc(p, &d.adv_cos, (size_t)(A + I + S + NL + 2 * NL) * d.en));
+        d.inst_cos = d.adv_cos + (size_t)A * d.en;
+        d.pz_cos = d.inst_cos + (size_t)I * d.en;
+        d.lz_cos = d.pz_cos + (size_t)S * d.en;
+        d.perm_cos = d.lz_cos + (size_t)NL * d.en;
         ZG_TRY(dalloc(p, &d.h, (size_t)d.en));
     }
     ZG_TRY(dalloc(p, &p->adv_val, (size_t)A * n));
@@ -743,14 +745,14 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     ZG_TRY(fork());
     if (I) {
         ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi; di++)
+        for (uint32_t di = dlo; di < dhi && !split; di++)
             ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_inst), n, n, p->dom[di].inst_cos, p->dom[di].en, I, p->dom[di].ek, p->hat, p->dom[di].zpow));
     }
     if (A) {
         ZG_TRY(msm_batch_dev(ctx, p->gl, adv, n, A, n, p->xyzz));
         ZG_TRY(fetch_points(p, A, pts));
         ZG_TRY(ntt_batch_to_dev(sx, adv, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi; di++)
+        for (uint32_t di = dlo; di < dhi && !split; di++)
             ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_adv), n, n, p->dom[di].adv_cos, p->dom[di].en, A, p->dom[di].ek, p->hat, p->dom[di].zpow));
         ZG_TRY(wait_points(p, A, pts));
         for (auto& q : pts) tr.write_point(q);
@@ -787,7 +789,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_HIP(hipMemcpyAsync(h_err, p->d_err, NL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
         ZG_TRY(ntt_batch_to_dev(sx, p->perm, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi; di++)
+        for (uint32_t di = dlo; di < dhi && !split; di++)
             ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_perm), n, n, p->dom[di].perm_cos, p->dom[di].en, 2 * NL, p->dom[di].ek, p->hat, p->dom[di].zpow));
         ZG_TRY(wait_points(p, 2 * NL + 1, pts));
         for (uint32_t l = 0; l < NL; l++)
@@ -828,7 +830,7 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         const uint32_t npts = S + NL + (have_random ? 0 : 1);
         ZG_TRY(fetch_points(p, npts, pts));
         ZG_TRY(ntt_batch_to_dev(sx, p->zs, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi; di++) {
+        for (uint32_t di = dlo; di < dhi && !split; di++) {
             const zg_prover::Dom& d = p->dom[di];
             if (S) ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_pz), n, n, d.pz_cos, d.en, S, d.ek, p->hat, d.zpow));
             if (NL) ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_lz), n, n, d.lz_cos, d.en, NL, d.ek, p->hat, d.zpow));
@@ -851,6 +853,15 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     const Fe y = tr.squeeze();
     lap(2);
 
+    // (split form: nothing overlaps in the throughput configuration, so every witness polynomial goes to both cosets
+    //  here, in one batch per coset, instead of phase by phase)
+    if (split) {
+        ZG_REQUIRE(p->ix_inst == p->ix_adv + A && p->ix_pz == p->ix_inst + I && p->ix_lz == p->ix_pz + S && p->ix_perm == p->ix_lz + NL,
+                   ZG_ERR_INVALID_ARG, "zg_prover_prove: coefficient slab out of order");
+        for (uint32_t di = dlo; di < dhi; di++)
+            ZG_TRY(coeff_to_coset_dev(ctx, poly_at(p->ix_adv), n, n, p->dom[di].adv_cos, p->dom[di].en, A + I + S + NL + 2 * NL,
+                                      p->dom[di].ek, p->hat, p->dom[di].zpow));
+    }
     // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
     for (uint32_t di = dlo; di < dhi; di++) {
         const zg_prover::Dom& d = p->dom[di];
