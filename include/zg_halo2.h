@@ -100,7 +100,7 @@ size_t zg_bases_len(const zg_bases *b);
 uint32_t zg_bases_window_bits(const zg_bases *b);
 
 /* Form of the MSM bucket reduction on this context: latency = 1 (default) spends two lanes per EC addition
- * -- shortest dependent chain, for a lone MSM or proof; latency = 0 spends one lane per addition, the
+ * (four in the suffix scan) -- shortest dependent chain, for a lone MSM or proof; latency = 0 spends one lane per addition, the
  * form for many MSMs in flight.  Results are identical.
  * zg_prover_set_overlap sets it together with the prover's own scheduling. */
 int zg_ctx_set_msm_latency(zg_ctx *ctx, int latency);
@@ -262,7 +262,10 @@ int zg_prover_phase_ms(const zg_prover *p, double *out, size_t cap);
 /* Scheduling of one proof on its GPU.  enable = 1 (default): the coefficient / coset transforms run on a
  * second HIP stream beside the commitment MSMs -- lowest latency for a lone proof.  enable = 0: one
  * stream per proof -- the throughput configuration when many provers share the GPU (other proofs fill
- * the gaps, and every extra stream costs a hardware queue).  Proof bytes do not depend on it. */
+ * the gaps, and every extra stream costs a hardware queue); in this form the quotient is also computed on a
+ * split extended domain (4n + n points instead of EvaluationDomain's 8n for a degree-6 circuit: the same
+ * polynomial h from fewer evaluations) and the MSM reductions spend one lane per EC addition.  Proof bytes do
+ * not depend on it. */
 int zg_prover_set_overlap(zg_prover *p, int enable);
 
 /* Stand-alone building blocks of the above (device pointers, context stream), exposed for tests. */
