@@ -67,6 +67,21 @@ def test_single_stream_schedule_gives_the_same_bytes(ctx, zg, orc):
     prover.close()
 
 
+@pytest.mark.parametrize("force_degree,parts", [(None, "one coset: 4n is exact"), (6, "4n + n"), (7, "4n + 2n"), (8, "one coset: 7 is no sum of two powers of two")])
+def test_split_extended_domain_gives_the_same_bytes(ctx, zg, orc, force_degree, parts):
+    """Throughput form (overlap off): the quotient comes from two cosets holding (degree - 1) * n points
+    between them instead of one coset of 2^ext_k; same polynomial, same proof bytes."""
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 7, force_degree=force_degree)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    st, want, _ = orc.create_proof(pk, adv, inst, 11)
+    assert st == 0
+    for overlap in (False, True):
+        prover.set_overlap(overlap)
+        assert prover.prove(adv, inst, 11) == want, parts
+    assert orc.verify_proof_pairing(pk, inst, want) == 1
+    prover.close()
+
+
 def test_prover_reuse_with_a_shorter_instance(ctx, zg, orc):
     """The instance column lives on the device between proofs and only its first rows are refilled: a proof
     with fewer instance values after one with more must see zeros behind them (bytes == oracle each time; the
@@ -200,7 +215,8 @@ def test_circuit_variants_match_oracle(ctx, zg, orc, kind):
     pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
     prover = zg.Prover(ctx, img, fixed, sigma, params.g_np(), params.g_lagrange_np(), vk_repr)
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
-    for seed in (1, 2):
+    for seed, overlap in ((1, True), (2, False)):  # (latency form, then the throughput form with its split domain)
+        prover.set_overlap(overlap)
         st, want, _ = orc.create_proof(pk, adv, inst, seed)
         assert st == 0
         got = prover.prove(adv, inst, seed)
