@@ -321,8 +321,10 @@ def main():
             "data": ("checked-in model + benches/example_image_7.png (fixtures from the reference checkout), "
                      "seeded SRS" if args.model != "large" else "synthetic (seeded stand-in model), seeded SRS"),
             "config": {"workload": f"full create_proof of zero_g's WnnCircuit for {circuit.model_name} on "
-                                   f"example_image_7.png (6 advice, 23 fixed, 12 gates, 4 lookups, 8 equality columns, "
-                                   f"degree 6), k={circuit.k}, extended domain 2^{job.cs.extended_k()}, proof {len(job.last)} B"
+                                   f"example_image_7.png ({job.cs.n_advice} advice, {job.cs.n_fixed} fixed, {len(job.cs.gates)} gates, "
+                                   f"{len(job.cs.lookups)} lookups, {len(job.cs.perm_columns)} equality columns, degree {job.cs.degree()}), "
+                                   f"k={circuit.k}, EvaluationDomain's extended domain 2^{job.cs.extended_k()} (the throughput form "
+                                   f"takes the same quotient from {job.cs.degree() - 1}n points on two cosets), proof {len(job.last)} B"
                                    + (" [seeded stand-in model: the file is absent from the reference]"
                                       if args.model == "large" else ""),
                        "class_scores": circuit.scores,
