@@ -36,6 +36,12 @@ void set_error(const char* fmt, ...);
         if (_s != ZG_OK) return _s; \
     } while (0)
 
+// First statement of an entry point that works on a context: takes the context lock for the rest of the call
+// and makes its device current on the calling thread.
+#define ZG_ENTER(ctxp)                                            \
+    std::lock_guard<std::recursive_mutex> _zg_lock((ctxp)->mu); \
+    ZG_HIP(hipSetDevice((ctxp)->device))
+
 #define ZG_REQUIRE(cond, status, ...)   \
     do {                                \
         if (!(cond)) {                  \
@@ -69,17 +75,30 @@ struct TwiddleKey {
 
 }  // namespace zg
 
+namespace zg {
+// What the contexts of one device share: NTT twiddle tables (omega^i, i < 2^log_n, per (log_n, omega); they live in
+// HBM until the last context of the device is destroyed) and the once-per-device kernel attributes.
+struct DeviceState {
+    std::mutex mu;
+    std::map<TwiddleKey, Fe*> twiddles;
+    int refs = 0;
+    bool msm_attrs = false, ntt_attrs = false;  // hipFuncSetAttribute is per device; set under `mu`
+};
+DeviceState& device_state(int device);
+}  // namespace zg
+
 struct zg_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 256;
     std::vector<zg::WsBlock> pool;
-    // omega^i, i < 2^log_n, per (log_n, omega): NTT twiddles live in HBM for the context lifetime
-    std::map<zg::TwiddleKey, zg::Fe*> twiddles;
     // pinned host staging for small D2H results
     void* pinned = nullptr;
     size_t pinned_cap = 0;
-    std::mutex mu;
+    // Every extern "C" entry that takes this context (or a prover / base set created on it) holds `mu` for the
+    // whole call: calls on one context serialise, calls on different contexts run concurrently.  Recursive
+    // because entry points are built from one another (zg_msm -> zg_msm_batch -> zg_msm_finish).
+    std::recursive_mutex mu;
     // optional per-kernel HIP-event timing (zg_ctx_profile_*): events bracket every launch
     bool profiling = false;
     std::string prof_filter;  // when non-empty only launches of this kernel are bracketed
@@ -97,7 +116,8 @@ struct zg_ctx {
 };
 
 struct zg_bases {
-    zg_ctx* ctx = nullptr;
+    zg_ctx* ctx = nullptr;  // the context that registered the set (its stream built the tables)
+    int device = 0;         // any context of this device may multiply against the tables (read-only)
     size_t n = 0;
     uint32_t c = 0;        // window bits
     uint32_t windows = 0;  // ceil(255 / c)

@@ -78,6 +78,15 @@ zg_ctx::ProfRec* prof_slot(zg_ctx* ctx, const char* name, double algo_bytes) {
     return &ctx->prof.back();  // (valid until the next slot is taken: the launch macro uses it at once)
 }
 
+DeviceState& device_state(int device) {
+    static std::mutex table_mu;
+    static std::map<int, DeviceState*> table;  // entries are never removed: references stay valid
+    std::lock_guard<std::mutex> lock(table_mu);
+    DeviceState*& d = table[device];
+    if (!d) d = new DeviceState();
+    return *d;
+}
+
 Fe host_domain_omega(uint32_t log_n) {
     Fe w = fr_root_of_unity();
     for (uint32_t i = log_n; i < FR_S; i++) w = Fr::sqr(w);
@@ -118,6 +127,11 @@ int zg_ctx_create(int device_id, zg_ctx** out) {
         delete ctx;
         return ZG_ERR_HIP;
     }
+    {
+        DeviceState& ds = device_state(device_id);
+        std::lock_guard<std::mutex> lock(ds.mu);
+        ds.refs++;
+    }
     *out = ctx;
     return ZG_OK;
 }
@@ -130,12 +144,19 @@ void zg_ctx_destroy(zg_ctx* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    {
+        DeviceState& ds = device_state(ctx->device);
+        std::lock_guard<std::mutex> lock(ds.mu);
+        if (--ds.refs == 0) {  // last context of the device: the shared twiddle tables go with it
+            for (auto& kv : ds.twiddles) (void)hipFree(kv.second);
+            ds.twiddles.clear();
+        }
+    }
     for (auto& r : ctx->prof) {
         (void)hipEventDestroy(r.e0);
         (void)hipEventDestroy(r.e1);
     }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
-    for (auto& kv : ctx->twiddles) (void)hipFree(kv.second);
     for (auto& b : ctx->pool) (void)hipFree(b.p);
     if (ctx->msm_tickets) (void)hipFree(ctx->msm_tickets);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -145,6 +166,7 @@ void zg_ctx_destroy(zg_ctx* ctx) {
 
 int zg_ctx_sync(zg_ctx* ctx) {
     ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_sync: ctx is null");
+    ZG_ENTER(ctx);
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->side) ZG_HIP(hipStreamSynchronize(ctx->side->stream));
     return ZG_OK;
@@ -154,6 +176,7 @@ void* zg_ctx_stream(zg_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
 int zg_ctx_profile_enable(zg_ctx* ctx, int on) {
     ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_profile_enable: ctx is null");
+    ZG_ENTER(ctx);
     ctx->profiling = on != 0;
     if (ctx->side) ctx->side->profiling = ctx->profiling;
     return ZG_OK;
@@ -161,6 +184,7 @@ int zg_ctx_profile_enable(zg_ctx* ctx, int on) {
 
 int zg_ctx_profile_filter(zg_ctx* ctx, const char* kernel_name) {
     ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_profile_filter: ctx is null");
+    ZG_ENTER(ctx);
     ctx->prof_filter = kernel_name ? kernel_name : "";
     if (ctx->side) ctx->side->prof_filter = ctx->prof_filter;
     return ZG_OK;
@@ -169,6 +193,7 @@ int zg_ctx_profile_filter(zg_ctx* ctx, const char* kernel_name) {
 // Synchronises, folds the recorded launches into per-kernel totals and clears the log.
 int zg_ctx_profile_collect(zg_ctx* ctx, zg_kernel_stat* out, size_t cap, size_t* count) {
     ZG_REQUIRE(ctx && count, ZG_ERR_INVALID_ARG, "zg_ctx_profile_collect: null argument");
+    ZG_ENTER(ctx);
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<zg_kernel_stat> acc;
     if (ctx->side) {  // fold the side stream's launches in

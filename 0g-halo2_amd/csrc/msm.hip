@@ -30,6 +30,8 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                    size_t stride, size_t batch, size_t n, XYZZ* d_out);
 int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
+int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
 
 constexpr uint32_t MSM_K = 16;       // max points per accumulate task
 constexpr uint32_t MSM_MAX_C = 16;
@@ -94,16 +96,21 @@ __global__ void msm_table_kernel(const Affine* __restrict__ bases, Affine* __res
 // Q_i = P_0 + ... + P_i (summation by parts: sum_i s_i P_i = sum_i (s_i - s_{i+1}) Q_i), taken as -(s_{i+1} - s_i)
 // with the point negated when that is the smaller integer -- columns that stay constant over long stretches
 // (grand products over padded rows) leave almost no entries.
-__global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t n,
+// Vector b of a batch is vector j = b % per of group b / per (a group = the commitments of one proof of a
+// lock-step batch): it starts at scalars + (b / per) * outer + j * stride, and j decides base set and run form.
+__global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t per,
+                                                         size_t outer, uint32_t n,
                                                          uint32_t c, uint32_t windows, uint32_t tbits,
                                                          uint32_t* __restrict__ dig, uint64_t run_mask) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
-    Fe s = ld_fe_g(scalars + (size_t)b * stride + i);
+    const uint32_t j = b % per;
+    const Fe* sv = scalars + (size_t)(b / per) * outer + (size_t)j * stride;
+    Fe s = ld_fe_g(sv + i);
     uint32_t flip = 0;  // the whole scalar negated: every digit's sign flips
-    if (b < 64 && ((run_mask >> b) & 1ull)) {
-        if (i + 1 < n) s = Fr::sub(s, ld_fe_g(scalars + (size_t)b * stride + i + 1));
+    if (j < 64 && ((run_mask >> j) & 1ull)) {
+        if (i + 1 < n) s = Fr::sub(s, ld_fe_g(sv + i + 1));
         s = Fr::to_raw(s);
         // |s| as the smaller of s and r - s
         Fe neg;
@@ -319,15 +326,16 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     uint32_t c, uint32_t windows, uint32_t n,
     const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
     const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ9* __restrict__ partial,
-    const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask) {
+    const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask, uint32_t per) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = PAIR ? lane >> 1 : lane;
     const bool role_a = !PAIR || (lane & 1u) == 0;
     uint32_t b = blockIdx.y;
     if (t >= ttotal[b]) return;
-    const bool runs = b < 64 && ((run_mask >> b) & 1ull);  // (entries then name running base sums)
+    const uint32_t vj = b % per;                             // position of the vector inside its group
+    const bool runs = vj < 64 && ((run_mask >> vj) & 1ull);  // (entries then name running base sums)
     // vectors >= split use the second base set
-    const Affine* table = b < split ? (runs ? run_a : table_a) : (runs ? run_b : table_b);
+    const Affine* table = vj < split ? (runs ? run_a : table_a) : (runs ? run_b : table_b);
     const uint32_t nb = 1u << (c - 1);
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     // largest k with to[k] <= t  (to is non-decreasing, to[nb+1] = total > t)
@@ -575,6 +583,7 @@ int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t wi
     uint32_t windows = (255 + c - 1) / c;
     zg_bases* b = new zg_bases();
     b->ctx = ctx;
+    b->device = ctx->device;
     b->n = n;
     b->c = c;
     b->windows = windows;
@@ -675,7 +684,20 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
 // base set must have its running-sum table (bases_enable_runs).
 int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask) {
-    if (batch < 64) run_mask &= (1ull << batch) - 1ull;
+    return msm_batch4_dev(ctx, bases, bases_b, split, d_scalars, stride, 0, 0, batch, n, d_out, run_mask);
+}
+
+// ... and the batch may be `batch / per` groups of `per` vectors each (the same commitments of several proofs):
+// vector v = group * per + j lives at d_scalars + group * outer + j * stride; split and run_mask go by j.
+// per = 0: one group (v = j).
+int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
+                   size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask) {
+    if (per == 0) {
+        per = batch ? batch : 1;
+        outer = 0;
+    }
+    ZG_REQUIRE(batch % per == 0, ZG_ERR_INVALID_ARG, "zg_msm: batch %zu is no multiple of the group size %zu", batch, per);
+    if (per < 64) run_mask &= (1ull << per) - 1ull;
     const uint64_t mask_a = split >= 64 ? ~0ull : (1ull << split) - 1ull;
     const Affine* run_a = bases->run_table;
     const Affine* run_b = bases_b ? bases_b->run_table : bases->run_table;
@@ -747,11 +769,14 @@ int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     XYZZ9* hsum = ws.get<XYZZ9>((size_t)B * max_heavy);
     if (ws.failed) return ZG_ERR_OOM;
 
-    static bool lds_attr = false;
-    if (!lds_attr) {
-        ZG_HIP(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ZG_HIP(hipFuncSetAttribute((const void*)msm_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        lds_attr = true;
+    {   // dynamic LDS above 64 KB is an opt-in per function AND per device
+        DeviceState& ds = device_state(ctx->device);
+        std::lock_guard<std::mutex> lock(ds.mu);
+        if (!ds.msm_attrs) {
+            ZG_HIP(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            ZG_HIP(hipFuncSetAttribute((const void*)msm_scan_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            ds.msm_attrs = true;
+        }
     }
     // algorithmic bytes of one MSM: n * (32 B scalar + 64 B base) in, 96 B out.  Every
     // stage kernel processes the same B MSMs per launch, so each is charged the same figure.
@@ -765,8 +790,8 @@ int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                                      // capped at 6 it spread over ~200, each just past the hot-bucket threshold)
     }
     if (const char* e = getenv("ZG_MSM_BALANCE")) tbits = atoi(e) ? tbits : 0;
-    ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, N, c,
-              W, tbits, dig, run_mask);
+    ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
+              (uint32_t)per, outer, N, c, W, tbits, dig, run_mask);
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
@@ -793,11 +818,11 @@ int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     if (ctx->msm_pair) {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<true>, dim3((2 * max_tasks + 255) / 256, B), dim3(256),
                   0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per);
     } else {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<false>, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
                   bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per);
     }
     // hot buckets are few (repeated or tiny scalars put one or two per window at most); the kernel strides over
     // the list, so a small grid serves any count -- and costs microseconds, not tens of them, when there are none
@@ -868,13 +893,13 @@ extern "C" {
 
 int zg_bases_register_dev(zg_ctx* ctx, const void* d_bases, size_t n, uint32_t window_bits, zg_bases** out) {
     ZG_REQUIRE(ctx && d_bases && out, ZG_ERR_INVALID_ARG, "zg_bases_register_dev: null argument");
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     return bases_register_dev(ctx, (const Affine*)d_bases, n, window_bits, out);
 }
 
 int zg_bases_register(zg_ctx* ctx, const zg_g1_affine* bases, size_t n, uint32_t window_bits, zg_bases** out) {
     ZG_REQUIRE(ctx && bases && out, ZG_ERR_INVALID_ARG, "zg_bases_register: null argument");
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
     Affine* d = ws.get<Affine>(n ? n : 1);
     if (!d) return ZG_ERR_OOM;
@@ -884,8 +909,8 @@ int zg_bases_register(zg_ctx* ctx, const zg_g1_affine* bases, size_t n, uint32_t
 
 void zg_bases_free(zg_bases* b) {
     if (!b) return;
-    (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipSetDevice(b->device);
+    (void)hipDeviceSynchronize();  // any context of the device may have been reading the tables
     (void)hipFree(b->table);
     if (b->run_table) (void)hipFree(b->run_table);
     delete b;
@@ -897,15 +922,15 @@ uint32_t zg_bases_window_bits(const zg_bases* b) { return b ? b->c : 0; }
 int zg_msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const void* d_scalars, size_t stride_elems,
                      size_t batch, size_t n, void* d_out_xyzz) {
     ZG_REQUIRE(ctx && bases && d_scalars && d_out_xyzz, ZG_ERR_INVALID_ARG, "zg_msm_batch_dev: null argument");
-    ZG_REQUIRE(bases->ctx == ctx, ZG_ERR_INVALID_ARG, "zg_msm_batch_dev: bases belong to another context");
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_REQUIRE(bases->device == ctx->device, ZG_ERR_INVALID_ARG, "zg_msm_batch_dev: bases live on another device");
+    ZG_ENTER(ctx);
     return msm_batch_dev(ctx, bases, (const Fe*)d_scalars, stride_elems, batch, n, (XYZZ*)d_out_xyzz);
 }
 
 int zg_msm_finish(zg_ctx* ctx, const void* d_xyzz, size_t batch, zg_g1* out) {
     ZG_REQUIRE(ctx && d_xyzz && out, ZG_ERR_INVALID_ARG, "zg_msm_finish: null argument");
     if (batch == 0) return ZG_OK;
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     ZG_TRY(pinned_reserve(ctx, batch * sizeof(XYZZ)));
     ZG_HIP(hipMemcpyAsync(ctx->pinned, d_xyzz, batch * sizeof(XYZZ), hipMemcpyDeviceToHost, ctx->stream));
     ZG_HIP(hipStreamSynchronize(ctx->stream));
@@ -916,10 +941,10 @@ int zg_msm_finish(zg_ctx* ctx, const void* d_xyzz, size_t batch, zg_g1* out) {
 int zg_msm_batch(zg_ctx* ctx, const zg_bases* bases, const zg_fr* const* scalars, size_t batch, size_t n,
                  zg_g1* out) {
     ZG_REQUIRE(ctx && bases && out && (scalars || batch == 0), ZG_ERR_INVALID_ARG, "zg_msm_batch: null argument");
-    ZG_REQUIRE(bases->ctx == ctx, ZG_ERR_INVALID_ARG, "zg_msm_batch: bases belong to another context");
+    ZG_REQUIRE(bases->device == ctx->device, ZG_ERR_INVALID_ARG, "zg_msm_batch: bases live on another device");
     ZG_REQUIRE(n <= bases->n, ZG_ERR_INVALID_ARG, "zg_msm_batch: %zu scalars for %zu bases", n, bases->n);
     if (batch == 0) return ZG_OK;
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
     Fe* d = ws.get<Fe>(batch * (n ? n : 1));
     XYZZ* r = ws.get<XYZZ>(batch);
@@ -934,6 +959,7 @@ int zg_msm_batch(zg_ctx* ctx, const zg_bases* bases, const zg_fr* const* scalars
 
 int zg_ctx_set_msm_latency(zg_ctx* ctx, int latency) {
     ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_set_msm_latency: ctx is null");
+    ZG_ENTER(ctx);
     ctx->msm_pair = latency != 0;
     return ZG_OK;
 }

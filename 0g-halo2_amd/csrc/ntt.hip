@@ -30,7 +30,7 @@
 // so the default stays with the packed back end.
 #include <cstdlib>
 
-#include "common.h"
+#include "poly.h"
 #include "field9.h"
 
 namespace zg {
@@ -41,6 +41,10 @@ struct NttArgs {
     const Fe* tw;       // omega^i, i < N; entries [N, 2N) hold omega^i * 2^5 (the 2^261 Montgomery form)
     size_t in_stride;   // elements between consecutive batch arrays
     size_t out_stride;
+    // groups (poly.h Grouping): array v of the batch sits at (v / per) * outer + (v % per) * stride; a flat side has
+    // per = 0xffffffff (v / per = 0)
+    uint32_t in_per, out_per;
+    size_t in_outer, out_outer;
     uint32_t log_n, log_n1, log_n2;
     uint32_t in_len;    // FIRST pass: input entries beyond in_len read as zero
     uint32_t out_len;   // LAST pass: entries >= out_len are not written
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
     if ((nblk & 7u) == 0) bid = (bid & 7u) * (nblk >> 3) + (bid >> 3);
     const uint32_t base = bid << log_cnt;  // first column (COLS) or first row (!COLS)
 
-    const Fe* in = a.in + (size_t)blockIdx.y * a.in_stride;
-    Fe* out = a.out + (size_t)blockIdx.y * a.out_stride;
+    const Fe* in = a.in + (size_t)(blockIdx.y / a.in_per) * a.in_outer + (size_t)(blockIdx.y % a.in_per) * a.in_stride;
+    Fe* out = a.out + (size_t)(blockIdx.y / a.out_per) * a.out_outer + (size_t)(blockIdx.y % a.out_per) * a.out_stride;
 
     // stage the sub-transform twiddles omega_M^t = omega^(t * N/M)
     {
@@ -338,8 +342,8 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) 
     if ((nblk & 7u) == 0) bid = (bid & 7u) * (nblk >> 3) + (bid >> 3);
     const uint32_t base = bid << log_cnt;
 
-    const Fe* in = a.in + (size_t)blockIdx.y * a.in_stride;
-    Fe* out = a.out + (size_t)blockIdx.y * a.out_stride;
+    const Fe* in = a.in + (size_t)(blockIdx.y / a.in_per) * a.in_outer + (size_t)(blockIdx.y % a.in_per) * a.in_stride;
+    Fe* out = a.out + (size_t)(blockIdx.y / a.out_per) * a.out_outer + (size_t)(blockIdx.y % a.out_per) * a.out_stride;
     const Fe* tw9 = a.tw + ((size_t)1 << a.log_n);  // omega^i * 2^5
 
     const uint32_t tw_shift = a.log_n - log_m;
@@ -447,12 +451,16 @@ __global__ void twiddle_kernel(Fe* tw, Fe omega, uint32_t n) {
     }
 }
 
+// One table per (device, log_n, omega), shared by every context of the device.  The table is complete (the
+// creating stream is drained) before its pointer is published, so that another context's stream may read it.
 int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out) {
     TwiddleKey key;
     key.log_n = log_n;
     memcpy(key.omega.data(), &omega, 32);
-    auto it = ctx->twiddles.find(key);
-    if (it != ctx->twiddles.end()) {
+    DeviceState& ds = device_state(ctx->device);
+    std::lock_guard<std::mutex> lock(ds.mu);
+    auto it = ds.twiddles.find(key);
+    if (it != ds.twiddles.end()) {
         *out = it->second;
         return ZG_OK;
     }
@@ -462,8 +470,14 @@ int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out) {
     uint32_t threads = 256, per = 16;
     uint32_t blocks = (n + threads * per - 1) / (threads * per);
     hipLaunchKernelGGL(twiddle_kernel, dim3(blocks), dim3(threads), 0, ctx->stream, tw, omega, n);
-    ZG_HIP(hipGetLastError());
-    ctx->twiddles[key] = tw;
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(tw);
+        set_error("get_twiddles: %s", hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    ds.twiddles[key] = tw;
     *out = tw;
     return ZG_OK;
 }
@@ -477,6 +491,7 @@ struct NttPlan {
     uint32_t log_n;
     Fe omega;
     uint32_t in_len, out_len;
+    Grouping grp;           // how the caller's arrays are laid out (the workspace between the passes is flat)
     uint32_t coset_in = 0;  // 0 none, 1 zeta^(j%3) on j%3 != 0, 2 all entries (zin0 too)
     bool coset_out = false, scale_out = false;
     Fe zin0, zin1, zin2, zout1, zout2, scale;
@@ -514,6 +529,7 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         if (p.scale_out) a.scale = Fr::mul(p.scale, c261);
     }
     const uint32_t N = 1u << p.log_n;
+    const uint32_t gper = p.grp.per ? p.grp.per : 0xffffffffu;
     // algorithmic bytes of a transform: input entries read + output entries written
     const double pass_bytes = (double)p.batch * ((double)p.in_len + (double)p.out_len) * 32.0;
     dim3 block(T / 4);
@@ -524,6 +540,7 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.log_n2 = p.log_n;
         a.in = p.in; a.in_stride = p.in_stride;
         a.out = p.out; a.out_stride = p.out_stride;
+        a.in_per = a.out_per = gper; a.in_outer = p.grp.in_outer; a.out_outer = p.grp.out_outer;
         size_t lds = (size_t)(T + (NINE && LOG_T > 10 ? 0 : N / 2)) * ELEM;
         if (NINE)
             ZG_LAUNCH(ctx, "ntt_single", pass_bytes, (ntt9_pass_kernel<LOG_T, false, true>),
@@ -540,6 +557,8 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
     {   // pass 1: in -> tmp
         a.in = p.in; a.in_stride = p.in_stride;
         a.out = tmp; a.out_stride = tmp_stride;
+        a.in_per = gper; a.in_outer = p.grp.in_outer;
+        a.out_per = 0xffffffffu; a.out_outer = 0;
         uint32_t cnt = T / N1;
         size_t lds = (size_t)(T + (NINE && LOG_T > 10 ? 0 : N1 / 2)) * ELEM;
         if (NINE)
@@ -553,6 +572,8 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
     {   // pass 2: tmp -> out
         a.in = tmp; a.in_stride = tmp_stride;
         a.out = p.out; a.out_stride = p.out_stride;
+        a.in_per = 0xffffffffu; a.in_outer = 0;
+        a.out_per = gper; a.out_outer = p.grp.out_outer;
         uint32_t cnt = T / N2;
         if (cnt > N1) cnt = N1;
         size_t lds = (size_t)(T + (NINE && LOG_T > 10 ? 0 : N2 / 2)) * ELEM;
@@ -585,9 +606,10 @@ int ntt_run(zg_ctx* ctx, const NttPlan& p, Fe* tmp, size_t tmp_stride) {
     return launch_passes<11, false>(ctx, p, tw, tmp, tmp_stride);
 }
 
-static bool g_lds_attr_done = false;
-static int ensure_lds_attr() {
-    if (g_lds_attr_done) return ZG_OK;
+static int ensure_lds_attr(zg_ctx* ctx) {
+    DeviceState& ds = device_state(ctx->device);
+    std::lock_guard<std::mutex> lock(ds.mu);
+    if (ds.ntt_attrs) return ZG_OK;
     // tiles above 64 KB need the opt-in dynamic LDS limit
     const int big = 160 * 1024;
     ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<11, true, true>,
@@ -612,7 +634,7 @@ static int ensure_lds_attr() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
     ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<10, false, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    g_lds_attr_done = true;
+    ds.ntt_attrs = true;
     return ZG_OK;
 }
 
@@ -621,10 +643,11 @@ static int ensure_lds_attr() {
 // d_out <- NTT(d_in), both [batch][stride]; d_out may be d_in.  (The first pass reads d_in, the last one writes
 // d_out: a caller that needs the input afterwards saves itself a copy.)
 int ntt_batch_to_dev(zg_ctx* ctx, const Fe* d_in, Fe* d_out, size_t stride, size_t batch, uint32_t log_n, const Fe& omega,
-                     const Fe* divisor) {
-    ZG_TRY(ensure_lds_attr());
+                     const Fe* divisor, const Grouping* grp) {
+    ZG_TRY(ensure_lds_attr(ctx));
     WsScope ws(ctx);
     NttPlan p;
+    if (grp) p.grp = *grp;
     p.in = d_in; p.in_stride = stride;
     p.out = d_out; p.out_stride = stride;
     p.batch = batch;
@@ -649,27 +672,25 @@ int ntt_batch_dev(zg_ctx* ctx, Fe* d_a, size_t stride, size_t batch, uint32_t lo
     return ntt_batch_to_dev(ctx, d_a, d_a, stride, batch, log_n, omega, divisor);
 }
 
-int coeff_to_coset_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, uint32_t in_len, Fe* d_out, size_t out_stride,
-                       size_t batch, uint32_t ext_k, bool hat, int zeta_pow);
-int coset_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat, int zeta_pow);
 
 // hat: the evaluations come out multiplied by 2^5, i.e. in the 2^261 Montgomery form evaluate_h's
 // nine-limb arithmetic works in (the factor rides on the coset constants: one extra product for the
 // entries with j % 3 == 0, n of the 8n loaded)
 int coeff_to_extended_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, Fe* d_out, size_t out_stride,
                           size_t batch, uint32_t k, uint32_t ext_k, bool hat) {
-    return coeff_to_coset_dev(ctx, d_in, in_stride, 1u << k, d_out, out_stride, batch, ext_k, hat, 1);
+    return coeff_to_coset_dev(ctx, d_in, in_stride, 1u << k, d_out, out_stride, batch, ext_k, hat, 1, nullptr);
 }
 
 // The general form: `in_len` coefficients (<= 2^ext_k) evaluated on the coset zeta^zeta_pow * <omega_(2^ext_k)>
 // (zeta_pow = 1: EvaluationDomain's own coset; 2: the second coset of the prover's split extended domain).
 int coeff_to_coset_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, uint32_t in_len, Fe* d_out, size_t out_stride,
-                       size_t batch, uint32_t ext_k, bool hat, int zeta_pow) {
+                       size_t batch, uint32_t ext_k, bool hat, int zeta_pow, const Grouping* grp) {
     ZG_REQUIRE(zeta_pow == 1 || zeta_pow == 2, ZG_ERR_INVALID_ARG, "coeff_to_coset: zeta power %d", zeta_pow);
     ZG_REQUIRE(in_len <= (1u << ext_k), ZG_ERR_INVALID_ARG, "coeff_to_coset: %u coefficients for 2^%u points", in_len, ext_k);
-    ZG_TRY(ensure_lds_attr());
+    ZG_TRY(ensure_lds_attr(ctx));
     WsScope ws(ctx);
     NttPlan p;
+    if (grp) p.grp = *grp;
     p.in = d_in; p.in_stride = in_stride;
     p.out = d_out; p.out_stride = out_stride;
     p.batch = batch;
@@ -703,19 +724,21 @@ int coeff_to_coset_dev(zg_ctx* ctx, const Fe* d_in, size_t in_stride, uint32_t i
 int extended_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t k, uint32_t ext_k, size_t out_len,
                           Fe* d_out, bool unhat) {
     (void)k;
-    return coset_to_coeff_dev(ctx, d_evals, ext_k, out_len, d_out, unhat, 1);
+    return coset_to_coeff_dev(ctx, d_evals, ext_k, out_len, d_out, unhat, 1, 1, 0, 0);
 }
 
-int coset_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat, int zeta_pow) {
+// `batch` arrays: evaluations at d_evals + b * in_stride (in_stride = 0: 2^ext_k), coefficients to d_out + b * out_stride
+int coset_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t ext_k, size_t out_len, Fe* d_out, bool unhat, int zeta_pow,
+                       size_t batch, size_t in_stride, size_t out_stride) {
     ZG_REQUIRE(zeta_pow == 1 || zeta_pow == 2, ZG_ERR_INVALID_ARG, "coset_to_coeff: zeta power %d", zeta_pow);
-    ZG_TRY(ensure_lds_attr());
+    ZG_TRY(ensure_lds_attr(ctx));
     WsScope ws(ctx);
     size_t n = (size_t)1 << ext_k;
     ZG_REQUIRE(out_len <= n, ZG_ERR_INVALID_ARG, "extended_to_coeff: out_len %zu > 2^%u", out_len, ext_k);
     NttPlan p;
-    p.in = d_evals; p.in_stride = n;
-    p.out = d_out; p.out_stride = out_len;
-    p.batch = 1;
+    p.in = d_evals; p.in_stride = in_stride ? in_stride : n;
+    p.out = d_out; p.out_stride = out_stride ? out_stride : out_len;
+    p.batch = batch;
     p.log_n = ext_k;
     p.omega = Fr::inv(host_domain_omega(ext_k));
     p.in_len = (uint32_t)n;
@@ -727,7 +750,7 @@ int coset_to_coeff_dev(zg_ctx* ctx, Fe* d_evals, uint32_t ext_k, size_t out_len,
     p.zout2 = zeta_pow == 1 ? fr_zeta() : Fr::sqr(fr_zeta());  // shift^-2
     Fe* tmp = nullptr;
     if (ntt_needs_tmp(ext_k)) {
-        tmp = ws.get<Fe>(n);
+        tmp = ws.get<Fe>(batch * n);
         if (!tmp) return ZG_ERR_OOM;
     } else if (d_out != d_evals) {
         // single pass reads everything before it writes: fine for distinct or equal buffers
@@ -752,7 +775,7 @@ int zg_ntt_batch_dev(zg_ctx* ctx, void* d_a, size_t stride_elems, size_t batch, 
     ZG_REQUIRE(ctx && d_a && omega, ZG_ERR_INVALID_ARG, "zg_ntt_batch_dev: null argument");
     ZG_REQUIRE(stride_elems >= ((size_t)1 << log_n) || batch <= 1, ZG_ERR_INVALID_ARG,
                "zg_ntt_batch_dev: stride %zu < 2^%u", stride_elems, log_n);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     Fe om = to_fe(omega), dv;
     if (divisor) dv = to_fe(divisor);
     return ntt_batch_dev(ctx, (Fe*)d_a, stride_elems, batch, log_n, om, divisor ? &dv : nullptr);
@@ -763,7 +786,7 @@ int zg_intt_batch(zg_ctx* ctx, zg_fr* const* a, size_t batch, uint32_t log_n, co
     ZG_REQUIRE(ctx && omega_inv && (a || batch == 0), ZG_ERR_INVALID_ARG, "zg_ntt: null argument");
     ZG_REQUIRE(log_n <= 22, ZG_ERR_UNSUPPORTED, "zg_ntt: log_n %u > 22 not built", log_n);
     if (batch == 0) return ZG_OK;
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
     size_t n = (size_t)1 << log_n;
     Fe* d = ws.get<Fe>(batch * n);
@@ -800,7 +823,7 @@ int zg_coeff_to_extended_batch_dev(zg_ctx* ctx, const void* d_coeffs, size_t in_
                                    uint32_t ext_k) {
     ZG_REQUIRE(ctx && d_coeffs && d_out, ZG_ERR_INVALID_ARG, "zg_coeff_to_extended: null argument");
     ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_coeff_to_extended: k=%u ext_k=%u", k, ext_k);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     return coeff_to_extended_dev(ctx, (const Fe*)d_coeffs, in_stride_elems, (Fe*)d_out,
                                  out_stride_elems, batch, k, ext_k, false);
 }
@@ -808,7 +831,7 @@ int zg_coeff_to_extended_batch_dev(zg_ctx* ctx, const void* d_coeffs, size_t in_
 int zg_coeff_to_extended(zg_ctx* ctx, const zg_fr* coeffs, uint32_t k, uint32_t ext_k, zg_fr* out) {
     ZG_REQUIRE(ctx && coeffs && out, ZG_ERR_INVALID_ARG, "zg_coeff_to_extended: null argument");
     ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_coeff_to_extended: k=%u ext_k=%u", k, ext_k);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
     size_t n = (size_t)1 << k, en = (size_t)1 << ext_k;
     Fe* din = ws.get<Fe>(n);
@@ -825,7 +848,7 @@ int zg_extended_to_coeff_dev(zg_ctx* ctx, void* d_evals, uint32_t k, uint32_t ex
                              void* d_out) {
     ZG_REQUIRE(ctx && d_evals && d_out, ZG_ERR_INVALID_ARG, "zg_extended_to_coeff: null argument");
     ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_extended_to_coeff: k=%u ext_k=%u", k, ext_k);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     return extended_to_coeff_dev(ctx, (Fe*)d_evals, k, ext_k, out_len, (Fe*)d_out, false);
 }
 
@@ -833,7 +856,7 @@ int zg_extended_to_coeff(zg_ctx* ctx, zg_fr* evals, uint32_t k, uint32_t ext_k, 
                          zg_fr* out) {
     ZG_REQUIRE(ctx && evals && out, ZG_ERR_INVALID_ARG, "zg_extended_to_coeff: null argument");
     ZG_REQUIRE(k <= ext_k && ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_extended_to_coeff: k=%u ext_k=%u", k, ext_k);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
     size_t en = (size_t)1 << ext_k;
     ZG_REQUIRE(out_len <= en, ZG_ERR_INVALID_ARG, "zg_extended_to_coeff: out_len too large");

@@ -41,7 +41,7 @@ using namespace zg;
 extern "C" int zg_params_new_dev(zg_ctx* ctx, uint32_t k, const zg_fr* s, void* d_g, void* d_g_lagrange) {
     ZG_REQUIRE(ctx && s && d_g && d_g_lagrange, ZG_ERR_INVALID_ARG, "zg_params_new_dev: null argument");
     ZG_REQUIRE(k <= 24, ZG_ERR_UNSUPPORTED, "zg_params_new_dev: k=%u > 24", k);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     Fe sv;
     memcpy(&sv, s, 32);
     uint32_t n = 1u << k;
@@ -56,7 +56,7 @@ extern "C" int zg_params_new_dev(zg_ctx* ctx, uint32_t k, const zg_fr* s, void* 
 extern "C" int zg_params_new(zg_ctx* ctx, uint32_t k, const zg_fr* s, zg_g1_affine* g, zg_g1_affine* g_lagrange) {
     ZG_REQUIRE(ctx && s && g && g_lagrange, ZG_ERR_INVALID_ARG, "zg_params_new: null argument");
     ZG_REQUIRE(k <= 24, ZG_ERR_UNSUPPORTED, "zg_params_new: k=%u > 24", k);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
     size_t n = (size_t)1 << k;
     Affine* dg = ws.get<Affine>(n);

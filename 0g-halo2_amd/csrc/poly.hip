@@ -28,96 +28,104 @@ __device__ __forceinline__ void stg(Fe* p, const Fe& v) {
 }
 
 // ------------------------------------------------------------------ blinding scalars
-__host__ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-    return z ^ (z >> 31);
-}
+// rand_fr(key, tag, index): ChaCha20 (RFC 7539: 32-byte key, 32-bit block counter, 96-bit nonce) keystream with
+// nonce = (tag, index_lo, index_hi) and block counter = attempt; a 64-byte block offers two 254-bit candidates
+// (words 0-7, then 8-15, top word masked to 30 bits); the first one below r is taken.  Upstream draws these
+// scalars from OsRng (/root/reference/src/wnn.rs:256): a caller that passes 32 fresh random bytes per proof gets
+// 256-bit keyed blinding; the test checker restates the same function for byte parity.
+__host__ __device__ __forceinline__ uint32_t rotl32(uint32_t x, int sft) { return (x << sft) | (x >> (32 - sft)); }
+#define ZG_QR(a, b, c, d)                       \
+    do {                                        \
+        a += b; d ^= a; d = rotl32(d, 16);      \
+        c += d; b ^= c; b = rotl32(b, 12);      \
+        a += b; d ^= a; d = rotl32(d, 8);       \
+        c += d; b ^= c; b = rotl32(b, 7);       \
+    } while (0)
 
-// SplitMix64 stream keyed by (seed, tag, index); rejection-sample a canonical value < r
-__host__ __device__ __forceinline__ Fe rand_fr(uint64_t seed, uint32_t tag, uint64_t index) {
-    uint64_t st = mix64(seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(tag + 1)) ^
-                  mix64(index + 0xd1b54a32d192ed03ULL * (uint64_t)(tag + 1));
+__host__ __device__ inline Fe rand_fr(const uint32_t* key, uint32_t tag, uint64_t index) {
     Fe v;
-    for (;;) {
-        for (int i = 0; i < 4; i++) {
-            st += 0x9e3779b97f4a7c15ULL;
-            uint64_t w = mix64(st);
-            v.l[2 * i] = (uint32_t)w;
-            v.l[2 * i + 1] = (uint32_t)(w >> 32);
+    for (uint32_t attempt = 0;; attempt++) {
+        uint32_t x0 = 0x61707865u, x1 = 0x3320646eu, x2 = 0x79622d32u, x3 = 0x6b206574u;
+        uint32_t x4 = key[0], x5 = key[1], x6 = key[2], x7 = key[3], x8 = key[4], x9 = key[5], x10 = key[6], x11 = key[7];
+        uint32_t x12 = attempt, x13 = tag, x14 = (uint32_t)index, x15 = (uint32_t)(index >> 32);
+        for (int r = 0; r < 10; r++) {
+            ZG_QR(x0, x4, x8, x12);
+            ZG_QR(x1, x5, x9, x13);
+            ZG_QR(x2, x6, x10, x14);
+            ZG_QR(x3, x7, x11, x15);
+            ZG_QR(x0, x5, x10, x15);
+            ZG_QR(x1, x6, x11, x12);
+            ZG_QR(x2, x7, x8, x13);
+            ZG_QR(x3, x4, x9, x14);
         }
-        v.l[7] &= 0x3fffffffu;
-        bool lt = false;
-        for (int i = 7; i >= 0; i--) {
-            uint32_t p = FrParams::p(i);
-            if (v.l[i] < p) { lt = true; break; }
-            if (v.l[i] > p) break;
+        for (int half = 0; half < 2; half++) {
+            if (half == 0) {
+                v.l[0] = x0 + 0x61707865u; v.l[1] = x1 + 0x3320646eu; v.l[2] = x2 + 0x79622d32u; v.l[3] = x3 + 0x6b206574u;
+                v.l[4] = x4 + key[0]; v.l[5] = x5 + key[1]; v.l[6] = x6 + key[2]; v.l[7] = x7 + key[3];
+            } else {
+                v.l[0] = x8 + key[4]; v.l[1] = x9 + key[5]; v.l[2] = x10 + key[6]; v.l[3] = x11 + key[7];
+                v.l[4] = x12 + attempt; v.l[5] = x13 + tag; v.l[6] = x14 + (uint32_t)index; v.l[7] = x15 + (uint32_t)(index >> 32);
+            }
+            v.l[7] &= 0x3fffffffu;
+            bool lt = false;
+            for (int i = 7; i >= 0; i--) {
+                uint32_t p = FrParams::p(i);
+                if (v.l[i] < p) { lt = true; break; }
+                if (v.l[i] > p) break;
+            }
+            if (lt) return Fr::from_raw(v);
         }
-        if (lt) break;
     }
-    return Fr::from_raw(v);
 }
 
-// columns [0, ncols0) draw from tag0 (index c * nrows + j), columns [ncols0, ncols) from tag1 (index restarts)
-__global__ void blind_rows_kernel(Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
-                                  uint64_t seed, uint32_t tag0, uint32_t ncols0, uint32_t tag1) {
+// proof b = blockIdx.y: columns [0, ncols0) draw from tag0 (index c * nrows + j), columns [ncols0, ncols) from tag1
+// (index restarts)
+__global__ void blind_rows_kernel(const ProofConst* __restrict__ pc, Fe* base, size_t base_bs, size_t col_stride,
+                                  uint32_t ncols, uint32_t row0, uint32_t nrows, uint32_t tag0, uint32_t ncols0, uint32_t tag1) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.y;
     if (t >= ncols * nrows) return;
     uint32_t c = t / nrows, j = t % nrows;
     const bool second = c >= ncols0;
-    stg(base + (size_t)c * col_stride + row0 + j,
-        rand_fr(seed, second ? tag1 : tag0, (uint64_t)(second ? c - ncols0 : c) * nrows + j));
+    stg(base + (size_t)b * base_bs + (size_t)c * col_stride + row0 + j,
+        rand_fr(pc[b].key, second ? tag1 : tag0, (uint64_t)(second ? c - ncols0 : c) * nrows + j));
 }
 
-__global__ void random_kernel(Fe* out, Fe* out2, uint32_t n, uint64_t seed, uint32_t tag) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const Fe v = rand_fr(seed, tag, i);
-    stg(out + i, v);
-    if (out2) stg(out2 + i, v);
-}
-
-int poly_blind_rows2(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols0, uint32_t tag0, uint32_t ncols1, uint32_t tag1,
-                     uint32_t row0, uint32_t nrows, uint64_t seed) {
+int poly_blind_rows2(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, Fe* base, size_t base_bs, size_t col_stride,
+                     uint32_t ncols0, uint32_t tag0, uint32_t ncols1, uint32_t tag1, uint32_t row0, uint32_t nrows) {
     uint32_t total = (ncols0 + ncols1) * nrows;
-    if (total == 0) return ZG_OK;
-    ZG_LAUNCH(ctx, "blind_rows", 0, blind_rows_kernel, dim3((total + 63) / 64), dim3(64), 0, base, col_stride, ncols0 + ncols1,
-              row0, nrows, seed, tag0, ncols0, tag1);
+    if (total == 0 || nb == 0) return ZG_OK;
+    ZG_LAUNCH(ctx, "blind_rows", 0, blind_rows_kernel, dim3((total + 63) / 64, nb), dim3(64), 0, pc, base, base_bs, col_stride,
+              ncols0 + ncols1, row0, nrows, tag0, ncols0, tag1);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
-int poly_blind_rows(zg_ctx* ctx, Fe* base, size_t col_stride, uint32_t ncols, uint32_t row0, uint32_t nrows,
-                    uint64_t seed, uint32_t tag) {
-    return poly_blind_rows2(ctx, base, col_stride, ncols, tag, 0, tag, row0, nrows, seed);
-}
 
 // The two draws a proof starts with, in one launch: the vanishing argument's random polynomial (n values,
-// written to out and out2) and the blinding rows of the advice columns.
-__global__ void random_and_blind_kernel(Fe* out, Fe* out2, uint32_t n, uint64_t seed, uint32_t tag, Fe* base, size_t col_stride,
-                                        uint32_t ncols, uint32_t row0, uint32_t nrows, uint32_t blind_tag) {
+// written to out and out2) and the blinding rows of the advice columns.  Proof b = blockIdx.y.
+__global__ void random_and_blind_kernel(const ProofConst* __restrict__ pc, Fe* out, size_t out_bs, Fe* out2, size_t out2_bs,
+                                        uint32_t n, uint32_t tag, Fe* base, size_t base_bs, size_t col_stride, uint32_t ncols,
+                                        uint32_t row0, uint32_t nrows, uint32_t blind_tag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.y;
     if (i < n) {
-        const Fe v = rand_fr(seed, tag, i);
-        stg(out + i, v);
-        if (out2) stg(out2 + i, v);
+        const Fe v = rand_fr(pc[b].key, tag, i);
+        stg(out + (size_t)b * out_bs + i, v);
+        if (out2) stg(out2 + (size_t)b * out2_bs + i, v);
         return;
     }
     i -= n;
     if (i >= ncols * nrows) return;
     const uint32_t c = i / nrows, j = i % nrows;
-    stg(base + (size_t)c * col_stride + row0 + j, rand_fr(seed, blind_tag, (uint64_t)c * nrows + j));
+    stg(base + (size_t)b * base_bs + (size_t)c * col_stride + row0 + j, rand_fr(pc[b].key, blind_tag, (uint64_t)c * nrows + j));
 }
-int poly_random_and_blind(zg_ctx* ctx, Fe* out, Fe* out2, uint32_t n, uint64_t seed, uint32_t tag, Fe* base, size_t col_stride,
-                          uint32_t ncols, uint32_t row0, uint32_t nrows, uint32_t blind_tag) {
+int poly_random_and_blind(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, Fe* out, size_t out_bs, Fe* out2, size_t out2_bs,
+                          uint32_t n, uint32_t tag, Fe* base, size_t base_bs, size_t col_stride, uint32_t ncols,
+                          uint32_t row0, uint32_t nrows, uint32_t blind_tag) {
     const uint32_t total = n + ncols * nrows;
-    ZG_LAUNCH(ctx, "random_poly", (double)n * 32, random_and_blind_kernel, dim3((total + 255) / 256), dim3(256), 0, out, out2, n, seed,
-              tag, base, col_stride, ncols, row0, nrows, blind_tag);
-    ZG_HIP(hipGetLastError());
-    return ZG_OK;
-}
-
-int poly_random(zg_ctx* ctx, Fe* out, uint32_t n, uint64_t seed, uint32_t tag, Fe* out2) {
-    ZG_LAUNCH(ctx, "random_poly", (double)n * 32, random_kernel, dim3((n + 255) / 256), dim3(256), 0, out, out2, n, seed, tag);
+    if (nb == 0) return ZG_OK;
+    ZG_LAUNCH(ctx, "random_poly", (double)nb * n * 32, random_and_blind_kernel, dim3((total + 255) / 256, nb), dim3(256), 0, pc,
+              out, out_bs, out2, out2_bs, n, tag, base, base_bs, col_stride, ncols, row0, nrows, blind_tag);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -154,12 +162,24 @@ __device__ __forceinline__ Fe eval_poly(const DevCircuit& c, const Cols& cols, z
 // lookup::Argument::commit_permuted `compress_expressions`: theta-fold of the input / table tuples
 // raw_in / raw_tab (optional): the same values as canonical integers -- the sort keys of permute_expression_pair --
 // with the all-ones sentinel on the rows from `usable` on (sorts last; real keys are < r < 2^254)
-__global__ __launch_bounds__(256) void lookup_compress_kernel(DevCircuit c, Cols cols, Fe theta, Fe* cin, Fe* ctab,
-                                                              uint32_t n, Fe* raw_in, Fe* raw_tab, uint32_t usable) {
+__device__ __forceinline__ Cols cols_of(const Cols& c, uint32_t b) {  // proof b's view of a batch's columns
+    Cols r = c;
+    r.advice += (size_t)b * c.adv_bs;
+    r.instance += (size_t)b * c.inst_bs;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void lookup_compress_kernel(DevCircuit c, Cols cols_all, const ProofConst* __restrict__ pc,
+                                                              Fe* cin, Fe* ctab, uint32_t n, Fe* raw_in, Fe* raw_tab,
+                                                              uint32_t usable) {
     uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.z;
     uint32_t l = blockIdx.y;
     if (row >= n) return;
+    const Cols cols = cols_of(cols_all, b);
+    const Fe theta = pc[b].theta;
     const DLookup* lk = c.lookups + l;
+    l += b * c.n_lookups;  // (outputs: lookup l of proof b)
     Fe ai = fe_zero(), ti = fe_zero();
     for (uint32_t e = 0; e < lk->width; e++) {
         ai = Fr::add(Fr::mul(ai, theta), eval_poly(c, cols, lk->inputs[e], row));
@@ -181,11 +201,11 @@ __global__ __launch_bounds__(256) void lookup_compress_kernel(DevCircuit c, Cols
     }
 }
 
-int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe& theta, Fe* cin, Fe* ctab,
-                         uint32_t n, Fe* raw_in, Fe* raw_tab, uint32_t usable) {
-    if (c.n_lookups == 0) return ZG_OK;
-    ZG_LAUNCH(ctx, "lookup_compress", (double)c.n_lookups * n * 64, lookup_compress_kernel,
-              dim3((n + 255) / 256, c.n_lookups), dim3(256), 0, c, cols, theta, cin, ctab, n, raw_in, raw_tab, usable);
+int poly_lookup_compress(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const ProofConst* pc, uint32_t nb, Fe* cin,
+                         Fe* ctab, uint32_t n, Fe* raw_in, Fe* raw_tab, uint32_t usable) {
+    if (c.n_lookups == 0 || nb == 0) return ZG_OK;
+    ZG_LAUNCH(ctx, "lookup_compress", (double)nb * c.n_lookups * n * 64, lookup_compress_kernel,
+              dim3((n + 255) / 256, c.n_lookups, nb), dim3(256), 0, c, cols, pc, cin, ctab, n, raw_in, raw_tab, usable);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -214,28 +234,32 @@ int poly_from_raw_rows(zg_ctx* ctx, const Fe* src, size_t src_stride, Fe* dst, s
 
 // lookup commit_permuted's last step in one launch: perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form) on
 // the usable rows [0, usable), blinding scalars on the rows after them (tag_in / tag_tab, index = l * nblind + j)
-__global__ __launch_bounds__(256) void permuted_finish_kernel(const Fe* __restrict__ raw_in, const Fe* __restrict__ raw_tab,
-                                                              Fe* __restrict__ perm, uint32_t n, uint32_t usable, uint32_t nblind,
-                                                              uint64_t seed, uint32_t tag_in, uint32_t tag_tab) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y;
+__global__ __launch_bounds__(256) void permuted_finish_kernel(const ProofConst* __restrict__ pc, const Fe* __restrict__ raw_in,
+                                                              const Fe* __restrict__ raw_tab, Fe* __restrict__ perm, size_t perm_bs,
+                                                              uint32_t n, uint32_t usable, uint32_t nblind, uint32_t tag_in,
+                                                              uint32_t tag_tab) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, b = blockIdx.z;
     if (i >= usable + nblind) return;
-    Fe* a = perm + (size_t)(2 * l) * n;
+    Fe* a = perm + (size_t)b * perm_bs + (size_t)(2 * l) * n;
     Fe* t = a + n;
+    const size_t src = (size_t)(b * gridDim.y + l) * n;  // (raw rows: lookup l of proof b)
     if (i < usable) {
-        stg(a + i, Fr::from_raw(ldg(raw_in + (size_t)l * n + i)));
-        stg(t + i, Fr::from_raw(ldg(raw_tab + (size_t)l * n + i)));
+        stg(a + i, Fr::from_raw(ldg(raw_in + src + i)));
+        stg(t + i, Fr::from_raw(ldg(raw_tab + src + i)));
     } else {
         const uint64_t idx = (uint64_t)l * nblind + (i - usable);
-        stg(a + i, rand_fr(seed, tag_in, idx));
-        stg(t + i, rand_fr(seed, tag_tab, idx));
+        stg(a + i, rand_fr(pc[b].key, tag_in, idx));
+        stg(t + i, rand_fr(pc[b].key, tag_tab, idx));
     }
 }
-int poly_permuted_finish(zg_ctx* ctx, const Fe* raw_in, const Fe* raw_tab, Fe* perm, uint32_t n, uint32_t usable,
-                         uint32_t nblind, uint32_t n_lookups, uint64_t seed, uint32_t tag_in, uint32_t tag_tab) {
-    if (!n_lookups) return ZG_OK;
+int poly_permuted_finish(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, const Fe* raw_in, const Fe* raw_tab, Fe* perm,
+                         size_t perm_bs, uint32_t n, uint32_t usable, uint32_t nblind, uint32_t n_lookups, uint32_t tag_in,
+                         uint32_t tag_tab) {
+    if (!n_lookups || !nb) return ZG_OK;
     ZG_REQUIRE(usable + nblind <= n, ZG_ERR_INVALID_ARG, "poly_permuted_finish: %u + %u rows of %u", usable, nblind, n);
-    ZG_LAUNCH(ctx, "permuted_finish", (double)n_lookups * n * 128, permuted_finish_kernel, dim3((usable + nblind + 255) / 256, n_lookups),
-              dim3(256), 0, raw_in, raw_tab, perm, n, usable, nblind, seed, tag_in, tag_tab);
+    ZG_LAUNCH(ctx, "permuted_finish", (double)nb * n_lookups * n * 128, permuted_finish_kernel,
+              dim3((usable + nblind + 255) / 256, n_lookups, nb), dim3(256), 0, pc, raw_in, raw_tab, perm, perm_bs, n, usable,
+              nblind, tag_in, tag_tab);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -255,33 +279,42 @@ int poly_from_raw(zg_ctx* ctx, const Fe* in, Fe* out, size_t count) {
 
 // ------------------------------------------------------------------ grand-product terms
 // lookup commit_product: den = (a' + beta)(s' + gamma), num = (A + beta)(S + gamma)
-// (lookup l = blockIdx.y: compressed columns and outputs at l * n, permuted columns at l * perm_stride)
-__global__ __launch_bounds__(256) void lookup_terms_kernel(const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab,
-                                                           size_t perm_stride, Fe beta, Fe gamma, Fe* num, Fe* den, uint32_t n) {
+// (lookup l = blockIdx.y of proof b = blockIdx.z: compressed columns at (b * n_lookups + l) * n, permuted columns at
+//  b * perm_bs + l * perm_stride, outputs at product (b * per + first + l) * n)
+__global__ __launch_bounds__(256) void lookup_terms_kernel(const ProofConst* __restrict__ pc, const Fe* cin, const Fe* ctab,
+                                                           const Fe* pin, const Fe* ptab, size_t perm_stride, size_t perm_bs,
+                                                           Fe* num, Fe* den, uint32_t per, uint32_t first, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t l = blockIdx.y, b = blockIdx.z;
     if (i >= n) return;
-    size_t o = (size_t)blockIdx.y * n + i, po = (size_t)blockIdx.y * perm_stride + i;
+    const Fe beta = pc[b].beta, gamma = pc[b].gamma;
+    const size_t ci = (size_t)(b * gridDim.y + l) * n + i, po = (size_t)b * perm_bs + (size_t)l * perm_stride + i;
+    const size_t o = (size_t)(b * per + first + l) * n + i;
     stg(den + o, Fr::mul(Fr::add(ldg(pin + po), beta), Fr::add(ldg(ptab + po), gamma)));
-    stg(num + o, Fr::mul(Fr::add(ldg(cin + o), beta), Fr::add(ldg(ctab + o), gamma)));
+    stg(num + o, Fr::mul(Fr::add(ldg(cin + ci), beta), Fr::add(ldg(ctab + ci), gamma)));
 }
 
-int poly_lookup_terms(zg_ctx* ctx, const Fe* cin, const Fe* ctab, const Fe* pin, const Fe* ptab, size_t perm_stride,
-                      const Fe& beta, const Fe& gamma, Fe* num, Fe* den, uint32_t n, uint32_t n_lookups) {
-    if (!n_lookups) return ZG_OK;
-    ZG_LAUNCH(ctx, "lookup_terms", (double)n_lookups * n * 192, lookup_terms_kernel, dim3((n + 255) / 256, n_lookups),
-              dim3(256), 0, cin, ctab, pin, ptab, perm_stride, beta, gamma, num, den, n);
+int poly_lookup_terms(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, const Fe* cin, const Fe* ctab, const Fe* pin,
+                      const Fe* ptab, size_t perm_stride, size_t perm_bs, Fe* num, Fe* den, uint32_t per, uint32_t first,
+                      uint32_t n, uint32_t n_lookups) {
+    if (!n_lookups || !nb) return ZG_OK;
+    ZG_LAUNCH(ctx, "lookup_terms", (double)nb * n_lookups * n * 192, lookup_terms_kernel, dim3((n + 255) / 256, n_lookups, nb),
+              dim3(256), 0, pc, cin, ctab, pin, ptab, perm_stride, perm_bs, num, den, per, first, n);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 // permutation commit, one set per blockIdx.y:
 //   den = prod_c (v_c + beta*sigma_c + gamma),  num = prod_c (v_c + delta^c * omega^i * beta + gamma)
-__global__ __launch_bounds__(256) void perm_terms_kernel(DevCircuit c, Cols cols, const Fe* sigma_val,
-                                                         const Fe* omega_tw, Fe beta, Fe gamma, Fe* num, Fe* den,
-                                                         uint32_t n) {
+__global__ __launch_bounds__(256) void perm_terms_kernel(DevCircuit c, Cols cols_all, const ProofConst* __restrict__ pc,
+                                                         const Fe* sigma_val, const Fe* omega_tw, Fe* num, Fe* den,
+                                                         uint32_t per, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t s = blockIdx.y;
+    const uint32_t b = blockIdx.z;
     if (i >= n) return;
+    const Cols cols = cols_of(cols_all, b);
+    const Fe beta = pc[b].beta, gamma = pc[b].gamma;
     uint32_t c0 = s * c.chunk, c1 = c0 + c.chunk;
     if (c1 > c.n_perm) c1 = c.n_perm;
     Fe d = Fr::one(), m = Fr::one();
@@ -295,15 +328,15 @@ __global__ __launch_bounds__(256) void perm_terms_kernel(DevCircuit c, Cols cols
         m = Fr::mul(m, Fr::add(Fr::add(dw, gamma), v));
         dw = Fr::mul(dw, fr_delta());
     }
-    stg(den + (size_t)s * n + i, d);
-    stg(num + (size_t)s * n + i, m);
+    stg(den + (size_t)(b * per + s) * n + i, d);
+    stg(num + (size_t)(b * per + s) * n + i, m);
 }
 
-int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Fe* sigma_val, const Fe* omega_tw,
-                    const Fe& beta, const Fe& gamma, Fe* num, Fe* den, uint32_t n) {
-    if (!c.n_sets) return ZG_OK;
-    ZG_LAUNCH(ctx, "perm_terms", (double)c.n_perm * n * 64 + (double)c.n_sets * n * 64, perm_terms_kernel,
-              dim3((n + 255) / 256, c.n_sets), dim3(256), 0, c, cols, sigma_val, omega_tw, beta, gamma, num, den, n);
+int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const ProofConst* pc, uint32_t nb,
+                    const Fe* sigma_val, const Fe* omega_tw, Fe* num, Fe* den, uint32_t per, uint32_t n) {
+    if (!c.n_sets || !nb) return ZG_OK;
+    ZG_LAUNCH(ctx, "perm_terms", nb * ((double)c.n_perm * n * 64 + (double)c.n_sets * n * 64), perm_terms_kernel,
+              dim3((n + 255) / 256, c.n_sets, nb), dim3(256), 0, c, cols, pc, sigma_val, omega_tw, num, den, per, n);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -425,16 +458,18 @@ __global__ __launch_bounds__(GP_BLOCK) void gp_apply_kernel(const Fe* __restrict
                                                             const Fe* __restrict__ totn, const Fe* __restrict__ totd,
                                                             const Fe* __restrict__ tinv, const Fe* __restrict__ zlast,
                                                             const Fe* __restrict__ z0, Fe* __restrict__ z, uint32_t n,
-                                                            uint32_t nblk, uint32_t chain, FeSet host_tinv, uint32_t use_host) {
+                                                            uint32_t nblk, uint32_t chain, FeSet host_tinv, uint32_t use_host,
+                                                            uint32_t per, size_t z_outer) {
     const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
     const uint32_t i = blk * GP_BLOCK + tid;
     if (i >= n) return;
-    // start value: z0[b] (if given) times the chained last values of the products before b
-    // (use_host: 1/T arrives in the kernel arguments and zlast still lacks that factor)
+    const uint32_t j = b % per, g0 = b - j;  // product j of its group; the group's first product
+    // start value: z0[b] (if given) times the chained last values of the group's products before this one
+    // (use_host: 1/T arrives in the kernel arguments and zlast still lacks that factor; one group only)
     Fe c = z0 ? ldg(z0 + b) : Fr::one();
-    if (b < chain)
-        for (uint32_t s = 0; s < b; s++) {
-            c = Fr::mul(c, ldg(zlast + s));
+    if (j < chain)
+        for (uint32_t s = 0; s < j; s++) {
+            c = Fr::mul(c, ldg(zlast + g0 + s));
             if (use_host) c = Fr::mul(c, host_tinv.v[s]);
         }
     Fe v = Fr::mul(c, use_host ? host_tinv.v[b] : ldg(tinv + b));
@@ -443,7 +478,7 @@ __global__ __launch_bounds__(GP_BLOCK) void gp_apply_kernel(const Fe* __restrict
         uint32_t pb = (i - 1) / GP_BLOCK;
         v = Fr::mul(v, Fr::mul(ldg(locn + (size_t)b * n + i - 1), ldg(totn + (size_t)b * nblk + pb)));
     }
-    stg(z + (size_t)b * n + i, v);
+    stg(z + (size_t)(b / per) * z_outer + (size_t)j * n + i, v);
 }
 
 // tmp: 2*batch*n + 2*batch*nblk + 2*batch elements
@@ -453,8 +488,14 @@ size_t poly_grand_product_tmp_elems(uint32_t n, uint32_t batch) {
 }
 
 int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
-                       uint32_t batch, uint32_t chain, uint32_t last) {
+                       uint32_t batch, uint32_t chain, uint32_t last, uint32_t per, size_t z_outer) {
     if (!batch || !n) return ZG_OK;
+    if (per == 0) {  // one group, results back to back
+        per = batch;
+        z_outer = 0;
+    }
+    ZG_REQUIRE(batch % per == 0, ZG_ERR_INVALID_ARG, "grand product: %u products in groups of %u", batch, per);
+    if (batch == per) z_outer = 0;
     const uint32_t nblk = (n + GP_BLOCK - 1) / GP_BLOCK;
     ZG_REQUIRE(nblk <= 1024, ZG_ERR_UNSUPPORTED, "grand product: n=%u > 2^18 not built", n);
     Fe* locn = tmp;
@@ -467,7 +508,7 @@ int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0
     ZG_LAUNCH(ctx, "grand_product_local", bytes, gp_local_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, num, den, locn,
               locd, totn, totd, n, nblk);
     // latency configuration: the host inverts the totals (one shared inversion) between the two launches
-    const bool host_inv = ctx->msm_pair && batch <= FESET_MAX;
+    const bool host_inv = ctx->msm_pair && batch <= FESET_MAX && batch == per;
     ZG_LAUNCH(ctx, "grand_product_totals", bytes, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
               tinv, zlast, n, nblk, last, host_inv ? 1u : 0u);
     FeSet inv_set;
@@ -494,7 +535,7 @@ int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0
         }
     }
     ZG_LAUNCH(ctx, "grand_product_apply", bytes, gp_apply_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, locn, locd, totn,
-              totd, tinv, zlast, d_z0, z, n, nblk, chain, inv_set, host_inv ? 1u : 0u);
+              totd, tinv, zlast, d_z0, z, n, nblk, chain, inv_set, host_inv ? 1u : 0u, per, z_outer);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -503,9 +544,31 @@ int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0
 // Evaluator::evaluate_h for one circuit instance: gates, permutation argument, lookup arguments folded
 // by y on every point of the extended coset; the division by (X^n - 1) of vanishing::construct is
 // fused into the store (t_eval has period 2^(ext_k - k)).
+// One proof of a lock-step batch per grid row: its scalars, coset slabs and output (both kernels below).
+struct EvalHProof {
+    const ProofConst* pc;
+    Cols cols;
+    const Fe *pz_cos, *lz_cos, *pin_cos, *ptab_cos;
+    Fe* h;
+};
+__device__ __forceinline__ EvalHProof evalh_proof(const EvalHArgs& a, uint32_t b) {
+    EvalHProof r;
+    r.pc = a.pc + b;
+    r.cols = cols_of(a.cols, b);
+    const size_t o = (size_t)b * a.cos_bs;
+    r.pz_cos = a.pz_cos + o;
+    r.lz_cos = a.lz_cos + o;
+    r.pin_cos = a.pin_cos + o;
+    r.ptab_cos = a.ptab_cos + o;
+    r.h = a.h + (size_t)b * a.h_bs;
+    return r;
+}
+
 __global__ __launch_bounds__(256) void evaluate_h_kernel(EvalHArgs a, uint32_t en) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= en) return;
+    const EvalHProof pr = evalh_proof(a, blockIdx.y);
+    const Fe y = pr.pc->eh_y, beta = pr.pc->eh_beta, gamma = pr.pc->eh_gamma, theta = pr.pc->eh_theta;
     const DevCircuit& c = a.c;
     const uint32_t mask = en - 1;
     const uint32_t rs = (uint32_t)a.cols.rot_scale;
@@ -514,59 +577,59 @@ __global__ __launch_bounds__(256) void evaluate_h_kernel(EvalHArgs a, uint32_t e
     const uint32_t r_last = (idx + (uint32_t)(a.last_rot * (int32_t)rs)) & mask;
     Fe value = fe_zero();
     for (uint32_t g = 0; g < c.n_gates; g++)
-        value = Fr::add(Fr::mul(value, a.y), eval_poly(c, a.cols, c.gates[g], idx));
+        value = Fr::add(Fr::mul(value, y), eval_poly(c, pr.cols, c.gates[g], idx));
 
     const Fe l0 = ldg(a.l0 + idx), llast = ldg(a.llast + idx), lactive = ldg(a.lactive + idx);
     if (c.n_sets > 0) {
-        const Fe zf = ldg(a.pz_cos + idx);
-        const Fe zl = ldg(a.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
-        value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(Fr::one(), zf), l0));
-        value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(Fr::sqr(zl), zl), llast));
+        const Fe zf = ldg(pr.pz_cos + idx);
+        const Fe zl = ldg(pr.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
+        value = Fr::add(Fr::mul(value, y), Fr::mul(Fr::sub(Fr::one(), zf), l0));
+        value = Fr::add(Fr::mul(value, y), Fr::mul(Fr::sub(Fr::sqr(zl), zl), llast));
         for (uint32_t s = 1; s < c.n_sets; s++) {
-            Fe t = Fr::sub(ldg(a.pz_cos + (size_t)s * en + idx), ldg(a.pz_cos + (size_t)(s - 1) * en + r_last));
-            value = Fr::add(Fr::mul(value, a.y), Fr::mul(t, l0));
+            Fe t = Fr::sub(ldg(pr.pz_cos + (size_t)s * en + idx), ldg(pr.pz_cos + (size_t)(s - 1) * en + r_last));
+            value = Fr::add(Fr::mul(value, y), Fr::mul(t, l0));
         }
-        Fe current_delta = Fr::mul(a.delta_start, ldg(a.ext_tw + idx));
+        Fe current_delta = Fr::mul(pr.pc->eh_delta_start[a.zpow - 1], ldg(a.ext_tw + idx));
         for (uint32_t s = 0; s < c.n_sets; s++) {
             uint32_t c0 = s * c.chunk, c1 = c0 + c.chunk;
             if (c1 > c.n_perm) c1 = c.n_perm;
-            Fe left = ldg(a.pz_cos + (size_t)s * en + r_next);
-            Fe right = ldg(a.pz_cos + (size_t)s * en + idx);
+            Fe left = ldg(pr.pz_cos + (size_t)s * en + r_next);
+            Fe right = ldg(pr.pz_cos + (size_t)s * en + idx);
             for (uint32_t col = c0; col < c1; col++) {
                 const zg_query q = c.perm_cols[col];
-                const Fe* base = q.kind == ZG_FIXED ? a.cols.fixed : q.kind == ZG_ADVICE ? a.cols.advice : a.cols.instance;
+                const Fe* base = q.kind == ZG_FIXED ? pr.cols.fixed : q.kind == ZG_ADVICE ? pr.cols.advice : pr.cols.instance;
                 Fe v = ldg(base + ((size_t)q.column << a.cols.log_size) + idx);
                 Fe sg = ldg(a.sigma_cos + (size_t)col * en + idx);
-                left = Fr::mul(left, Fr::add(Fr::add(Fr::mul(a.beta, sg), v), a.gamma));
-                right = Fr::mul(right, Fr::add(Fr::add(v, current_delta), a.gamma));
+                left = Fr::mul(left, Fr::add(Fr::add(Fr::mul(beta, sg), v), gamma));
+                right = Fr::mul(right, Fr::add(Fr::add(v, current_delta), gamma));
                 current_delta = Fr::mul(current_delta, a.delta);
             }
-            value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(left, right), lactive));
+            value = Fr::add(Fr::mul(value, y), Fr::mul(Fr::sub(left, right), lactive));
         }
     }
     for (uint32_t l = 0; l < c.n_lookups; l++) {
         const DLookup* lk = c.lookups + l;
         Fe ai = fe_zero(), ti = fe_zero();
         for (uint32_t e = 0; e < lk->width; e++) {
-            ai = Fr::add(Fr::mul(ai, a.theta), eval_poly(c, a.cols, lk->inputs[e], idx));
-            ti = Fr::add(Fr::mul(ti, a.theta), eval_poly(c, a.cols, lk->tables[e], idx));
+            ai = Fr::add(Fr::mul(ai, theta), eval_poly(c, pr.cols, lk->inputs[e], idx));
+            ti = Fr::add(Fr::mul(ti, theta), eval_poly(c, pr.cols, lk->tables[e], idx));
         }
-        const Fe* zc = a.lz_cos + (size_t)l * en;
-        const Fe* ap = a.pin_cos + (size_t)l * a.perm_stride;
-        const Fe* sp = a.ptab_cos + (size_t)l * a.perm_stride;
+        const Fe* zc = pr.lz_cos + (size_t)l * en;
+        const Fe* ap = pr.pin_cos + (size_t)l * a.perm_stride;
+        const Fe* sp = pr.ptab_cos + (size_t)l * a.perm_stride;
         const Fe z = ldg(zc + idx), apv = ldg(ap + idx), spv = ldg(sp + idx);
-        value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(Fr::one(), z), l0));
-        value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(Fr::sqr(z), z), llast));
-        Fe lft = Fr::mul(Fr::mul(Fr::add(apv, a.beta), Fr::add(spv, a.gamma)), ldg(zc + r_next));
-        Fe rgt = Fr::mul(Fr::mul(Fr::add(ai, a.beta), Fr::add(ti, a.gamma)), z);
-        value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::sub(lft, rgt), lactive));
+        value = Fr::add(Fr::mul(value, y), Fr::mul(Fr::sub(Fr::one(), z), l0));
+        value = Fr::add(Fr::mul(value, y), Fr::mul(Fr::sub(Fr::sqr(z), z), llast));
+        Fe lft = Fr::mul(Fr::mul(Fr::add(apv, beta), Fr::add(spv, gamma)), ldg(zc + r_next));
+        Fe rgt = Fr::mul(Fr::mul(Fr::add(ai, beta), Fr::add(ti, gamma)), z);
+        value = Fr::add(Fr::mul(value, y), Fr::mul(Fr::sub(lft, rgt), lactive));
         Fe ams = Fr::sub(apv, spv);
-        value = Fr::add(Fr::mul(value, a.y), Fr::mul(ams, l0));
-        value = Fr::add(Fr::mul(value, a.y), Fr::mul(Fr::mul(ams, Fr::sub(apv, ldg(ap + r_prev))), lactive));
+        value = Fr::add(Fr::mul(value, y), Fr::mul(ams, l0));
+        value = Fr::add(Fr::mul(value, y), Fr::mul(Fr::mul(ams, Fr::sub(apv, ldg(ap + r_prev))), lactive));
     }
     // divide_by_vanishing_poly
     value = Fr::mul(value, ldg(a.t_eval + (idx & a.t_mask)));
-    stg(a.h + idx, value);
+    stg(pr.h + idx, value);
 }
 
 
@@ -651,6 +714,8 @@ int poly_gate_factor(zg_ctx* ctx, const Fe* col, uint32_t rot_off, uint32_t en, 
 __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t en) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= en) return;
+    const EvalHProof pr = evalh_proof(a, blockIdx.y);
+    const ProofConst* pc = pr.pc;  // (scalars are re-read where they are used: workgroup-uniform scalar loads)
     const DevCircuit& c = a.c;
     const uint32_t mask = en - 1;
     const uint32_t rs = (uint32_t)a.cols.rot_scale;
@@ -660,19 +725,19 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     // (constants and l-polynomial values are re-materialised at each use: a nine-limb value is 9 VGPRs, and
     // this kernel's occupancy is set by its register count)
     // value <- value * y + term   (term normalised; the sum has limbs < 2^30 and goes into the next product)
-    auto fold = [&](const F9& value, const F9& term) { return f9_add(Fr9::mul(value, f9_unpack(a.y)), term); };
+    auto fold = [&](const F9& value, const F9& term) { return f9_add(Fr9::mul(value, f9_unpack(pc->eh_y)), term); };
     // value <- value * y + u * v with ONE Montgomery reduction (value normalised, u and v with limbs < 2^29)
-    auto fold2 = [&](const F9& value, const F9& u, const F9& v) { return Fr9::mul2<false>(value, f9_unpack(a.y), u, v); };
+    auto fold2 = [&](const F9& value, const F9& u, const F9& v) { return Fr9::mul2<false>(value, f9_unpack(pc->eh_y), u, v); };
     F9 value;
 #pragma unroll
     for (int i = 0; i < 9; i++) value.l[i] = 0;
     auto cell = [&](uint32_t qi) {
         const zg_query q = c.queries[qi];
-        const Fe* base = q.kind == ZG_FIXED ? a.cols.fixed : q.kind == ZG_ADVICE ? a.cols.advice : a.cols.instance;
+        const Fe* base = q.kind == ZG_FIXED ? pr.cols.fixed : q.kind == ZG_ADVICE ? pr.cols.advice : pr.cols.instance;
         return ld9(base + ((size_t)q.column << a.cols.log_size) + ((idx + (uint32_t)(q.rotation * a.cols.rot_scale)) & mask));
     };
     for (uint32_t g = 0; g < c.n_gates; g++) {
-        const F9 inner = eval_poly9(c, a.monos_hat, a.cols, a.gates_hat[g], idx);
+        const F9 inner = eval_poly9(c, a.monos_hat, pr.cols, a.gates_hat[g], idx);
         const uint32_t common = a.gate_common[g];  // (wave-uniform)
         if (common != 0xffffffffu) {
             const uint32_t slab = a.gate_slab[g];
@@ -697,29 +762,29 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     auto lactive = [&]() { return ld9(a.lactive + idx); };
     auto one = [&]() { return Fr9Params::one(); };
     if (c.n_sets > 0) {
-        const F9 zf = ld9(a.pz_cos + idx);
-        const F9 zl = ld9(a.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
+        const F9 zf = ld9(pr.pz_cos + idx);
+        const F9 zl = ld9(pr.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
         value = fold2(value, f9_sub(one(), zf), l0());
         value = fold2(value, f9_sub(Fr9::sqr(zl), zl), llast());
         for (uint32_t s = 1; s < c.n_sets; s++) {
-            const F9 t = f9_sub(ld9(a.pz_cos + (size_t)s * en + idx), ld9(a.pz_cos + (size_t)(s - 1) * en + r_last));
+            const F9 t = f9_sub(ld9(pr.pz_cos + (size_t)s * en + idx), ld9(pr.pz_cos + (size_t)(s - 1) * en + r_last));
             value = fold2(value, t, l0());
         }
-        F9 current_delta = Fr9::mul(f9_unpack(a.delta_start), ld9(a.ext_tw + idx));
+        F9 current_delta = Fr9::mul(f9_unpack(pc->eh_delta_start[a.zpow - 1]), ld9(a.ext_tw + idx));
         const F9 delta = f9_unpack(a.delta);
         for (uint32_t s = 0; s < c.n_sets; s++) {
             uint32_t c0 = s * c.chunk, c1 = c0 + c.chunk;
             if (c1 > c.n_perm) c1 = c.n_perm;
-            F9 left = ld9(a.pz_cos + (size_t)s * en + r_next);
-            F9 right = ld9(a.pz_cos + (size_t)s * en + idx);
+            F9 left = ld9(pr.pz_cos + (size_t)s * en + r_next);
+            F9 right = ld9(pr.pz_cos + (size_t)s * en + idx);
             for (uint32_t col = c0; col < c1; col++) {
                 const zg_query q = c.perm_cols[col];
-                const Fe* base = q.kind == ZG_FIXED ? a.cols.fixed : q.kind == ZG_ADVICE ? a.cols.advice : a.cols.instance;
+                const Fe* base = q.kind == ZG_FIXED ? pr.cols.fixed : q.kind == ZG_ADVICE ? pr.cols.advice : pr.cols.instance;
                 const F9 v = ld9(base + ((size_t)q.column << a.cols.log_size) + idx);
                 const F9 sg = ld9(a.sigma_cos + (size_t)col * en + idx);
                 // three-term sums: normalise before they enter a product
-                const F9 fl = f9_norm(f9_add(f9_add(Fr9::mul(f9_unpack(a.beta), sg), v), f9_unpack(a.gamma)));
-                const F9 fr = f9_norm(f9_add(f9_add(v, current_delta), f9_unpack(a.gamma)));
+                const F9 fl = f9_norm(f9_add(f9_add(Fr9::mul(f9_unpack(pc->eh_beta), sg), v), f9_unpack(pc->eh_gamma)));
+                const F9 fr = f9_norm(f9_add(f9_add(v, current_delta), f9_unpack(pc->eh_gamma)));
                 current_delta = Fr9::mul(current_delta, delta);
                 if (col + 1 < c1) {
                     left = Fr9::mul(left, fl);
@@ -737,18 +802,18 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
 #pragma unroll
         for (int i = 0; i < 9; i++) ai.l[i] = ti.l[i] = 0;
         for (uint32_t e = 0; e < lk->width; e++) {
-            ai = f9_add(Fr9::mul(ai, f9_unpack(a.theta)), eval_poly9(c, a.monos_hat, a.cols, lk->inputs[e], idx));
-            ti = f9_add(Fr9::mul(ti, f9_unpack(a.theta)), eval_poly9(c, a.monos_hat, a.cols, lk->tables[e], idx));
+            ai = f9_add(Fr9::mul(ai, f9_unpack(pc->eh_theta)), eval_poly9(c, a.monos_hat, pr.cols, lk->inputs[e], idx));
+            ti = f9_add(Fr9::mul(ti, f9_unpack(pc->eh_theta)), eval_poly9(c, a.monos_hat, pr.cols, lk->tables[e], idx));
         }
-        const Fe* zc = a.lz_cos + (size_t)l * en;
-        const Fe* ap = a.pin_cos + (size_t)l * a.perm_stride;
-        const Fe* sp = a.ptab_cos + (size_t)l * a.perm_stride;
+        const Fe* zc = pr.lz_cos + (size_t)l * en;
+        const Fe* ap = pr.pin_cos + (size_t)l * a.perm_stride;
+        const Fe* sp = pr.ptab_cos + (size_t)l * a.perm_stride;
         const F9 z = ld9(zc + idx), apv = ld9(ap + idx), spv = ld9(sp + idx);
         value = fold2(value, f9_sub(one(), z), l0());
         value = fold2(value, f9_sub(Fr9::sqr(z), z), llast());
         // (x + beta)(y + gamma): one factor may stay a two-term sum, the other is normalised
-        const F9 lft = Fr9::mul(f9_add(apv, f9_unpack(a.beta)), f9_norm(f9_add(spv, f9_unpack(a.gamma))));
-        const F9 rgt = Fr9::mul(f9_norm(f9_add(ai, f9_unpack(a.beta))), f9_norm(f9_add(ti, f9_unpack(a.gamma))));
+        const F9 lft = Fr9::mul(f9_add(apv, f9_unpack(pc->eh_beta)), f9_norm(f9_add(spv, f9_unpack(pc->eh_gamma))));
+        const F9 rgt = Fr9::mul(f9_norm(f9_add(ai, f9_unpack(pc->eh_beta))), f9_norm(f9_add(ti, f9_unpack(pc->eh_gamma))));
         value = fold2(value, Fr9::mul2<true>(lft, ld9(zc + r_next), rgt, z), lactive());
         const F9 ams = f9_sub(apv, spv);
         value = fold2(value, ams, l0());
@@ -756,10 +821,12 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     }
     // divide_by_vanishing_poly, then back to the canonical packed form (still x * 2^261)
     value = Fr9::mul(value, ld9(a.t_eval + (idx & a.t_mask)));
-    stg(a.h + idx, f9_reduce_pack<Fr9Params>(value));
+    stg(pr.h + idx, f9_reduce_pack<Fr9Params>(value));
 }
 
-int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en) {
+int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en, uint32_t nb) {
+    if (!nb) return ZG_OK;
+    ZG_REQUIRE(a.pc != nullptr && (a.zpow == 1 || a.zpow == 2), ZG_ERR_INVALID_ARG, "evaluate_h: per-proof scalars missing");
     // algorithmic bytes: every input coset read once + h written
     const DevCircuit& c = a.c;
     double arrays = 3.0 + c.n_perm + c.n_sets + 3.0 * c.n_lookups + 1.0;  // l-polys, sigma, z's, lookup polys, h
@@ -768,53 +835,53 @@ int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en) {
     ZG_REQUIRE(!a.hat || c.n_gates == 0 || (a.gates_hat != nullptr && a.gate_common != nullptr && a.gate_uni != nullptr && a.uni_coef != nullptr && a.gate_slab != nullptr && a.gate_slabs != nullptr), ZG_ERR_INVALID_ARG,
                "evaluate_h: the factored gate table is missing");
     if (a.hat)
-        ZG_LAUNCH(ctx, "evaluate_h", arrays * en * 32.0, evaluate_h9_kernel, dim3((en + 255) / 256), dim3(256), 0, a, en);
+        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h9_kernel, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
     else
-        ZG_LAUNCH(ctx, "evaluate_h", arrays * en * 32.0, evaluate_h_kernel, dim3((en + 255) / 256), dim3(256), 0, a, en);
+        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h_kernel, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 // ------------------------------------------------------------------ eval_polynomial
-// pow[p][i] = x_p^i : lane computes x^(i0) by square-and-multiply, then a strip of 16 products
-__global__ __launch_bounds__(256) void powers_kernel(FeSet points, uint32_t n, Fe* __restrict__ pw) {
+__device__ __forceinline__ const Fe* poly_of(const PolySet& ps, uint32_t ix, uint32_t b) {
+    return ix < ps.nsh ? ps.sh + (size_t)ix * ps.n : ps.pp + (size_t)b * ps.pp_bs + (size_t)(ix - ps.nsh) * ps.n;
+}
+
+// pow[b][s][i] = x^i for x = pc[b].points[s]: lane computes x^(i0) by square-and-multiply, then a strip of 16 products
+__global__ __launch_bounds__(256) void powers_kernel(const ProofConst* __restrict__ pc, uint32_t n, Fe* __restrict__ pw,
+                                                     size_t pw_bs) {
     constexpr uint32_t CH = 16;
     uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * CH;
     if (i0 >= n) return;
-    Fe x = points.v[blockIdx.y];
+    const uint32_t sl = blockIdx.y, b = blockIdx.z;
+    Fe x = pc[b].points[sl];
     Fe cur = Fr::pow_u64(x, i0);
-    Fe* out = pw + (size_t)blockIdx.y * n;
+    Fe* out = pw + (size_t)b * pw_bs + (size_t)sl * n;
     for (uint32_t j = 0; j < CH && i0 + j < n; j++) {
         stg(out + i0 + j, cur);
         cur = Fr::mul(cur, x);
     }
 }
 
-int poly_powers(zg_ctx* ctx, const Fe* points_host, uint32_t npoints, uint32_t n, Fe* d_pow) {
-    if (!npoints) return ZG_OK;
-    for (uint32_t p0 = 0; p0 < npoints; p0 += FESET_MAX) {  // (the points travel in the kernel arguments)
-        const uint32_t m = npoints - p0 < FESET_MAX ? npoints - p0 : FESET_MAX;
-        FeSet pts;
-        memset(&pts, 0, sizeof(pts));
-        for (uint32_t j = 0; j < m; j++) pts.v[j] = points_host[p0 + j];
-        ZG_LAUNCH(ctx, "powers", (double)m * n * 32, powers_kernel, dim3((n + 256 * 16 - 1) / (256 * 16), m), dim3(256), 0, pts, n,
-                  d_pow + (size_t)p0 * n);
-    }
+int poly_powers(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, uint32_t npoints, uint32_t n, Fe* d_pow, size_t pw_bs) {
+    if (!npoints || !nb) return ZG_OK;
+    ZG_REQUIRE(npoints <= PC_MAX_POINTS, ZG_ERR_UNSUPPORTED, "poly_powers: %u opening points (max %u)", npoints, PC_MAX_POINTS);
+    ZG_LAUNCH(ctx, "powers", (double)nb * npoints * n * 32, powers_kernel, dim3((n + 256 * 16 - 1) / (256 * 16), npoints, nb),
+              dim3(256), 0, pc, n, d_pow, pw_bs);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
-// out[j] = <poly_j, pow_{point_j}> : one 1024-lane workgroup per (poly, point) pair (a few dozen pairs per
-// proof: the wide workgroup is what keeps a lone proof from waiting on 64 products per lane)
+// out[b][j] = <poly_j of proof b, pow_{point_j} of proof b> : one 1024-lane workgroup per (poly, point) pair (a few
+// dozen pairs per proof: the wide workgroup is what keeps a lone proof from waiting on 64 products per lane)
 constexpr uint32_t DOT_NT = 1024;
-__global__ __launch_bounds__(DOT_NT) void dot_kernel(const Fe* __restrict__ polys, size_t stride, uint32_t n,
-                                                     const uint32_t* __restrict__ poly_idx,
+__global__ __launch_bounds__(DOT_NT) void dot_kernel(PolySet ps, uint32_t n, const uint32_t* __restrict__ poly_idx,
                                                      const uint32_t* __restrict__ point_idx, const Fe* __restrict__ pw,
-                                                     Fe* __restrict__ out) {
+                                                     size_t pw_bs, Fe* __restrict__ out, size_t out_bs) {
     __shared__ Fe sh[DOT_NT];
-    const uint32_t j = blockIdx.x, tid = threadIdx.x;
-    const Fe* p = polys + (size_t)poly_idx[j] * stride;
-    const Fe* w = pw + (size_t)point_idx[j] * n;
+    const uint32_t j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const Fe* p = poly_of(ps, poly_idx[j], b);
+    const Fe* w = pw + (size_t)b * pw_bs + (size_t)point_idx[j] * n;
     Fe acc = fe_zero();
     for (uint32_t i = tid; i < n; i += DOT_NT) acc = Fr::add(acc, Fr::mul(ldg(p + i), ldg(w + i)));
     sh[tid] = acc;
@@ -823,74 +890,76 @@ __global__ __launch_bounds__(DOT_NT) void dot_kernel(const Fe* __restrict__ poly
         if (tid < off) sh[tid] = Fr::add(sh[tid], sh[tid + off]);
         __syncthreads();
     }
-    if (tid == 0) stg(out + j, sh[0]);
+    if (tid == 0) stg(out + (size_t)b * out_bs + j, sh[0]);
 }
 
-int poly_dot(zg_ctx* ctx, const Fe* polys, size_t stride, uint32_t n, const uint32_t* d_poly_idx,
-             const uint32_t* d_point_idx, const Fe* d_pow, uint32_t count, Fe* d_out) {
-    if (!count) return ZG_OK;
-    ZG_LAUNCH(ctx, "eval_dot", (double)count * n * 64, dot_kernel, dim3(count), dim3(DOT_NT), 0, polys, stride, n, d_poly_idx,
-              d_point_idx, d_pow, d_out);
+int poly_dot(zg_ctx* ctx, const PolySet& polys, uint32_t nb, uint32_t n, const uint32_t* d_poly_idx,
+             const uint32_t* d_point_idx, const Fe* d_pow, size_t pw_bs, uint32_t count, Fe* d_out, size_t out_bs) {
+    if (!count || !nb) return ZG_OK;
+    ZG_LAUNCH(ctx, "eval_dot", (double)nb * count * n * 64, dot_kernel, dim3(count, nb), dim3(DOT_NT), 0, polys, n, d_poly_idx,
+              d_point_idx, d_pow, pw_bs, d_out, out_bs);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
 // ------------------------------------------------------------------ GWC
-// out[i] = (...((p_0[i]) v + p_1[i]) v + ...) + p_{m-1}[i];  out[0] -= sub
-__global__ __launch_bounds__(256) void horner_combine_kernel(const Fe* __restrict__ polys, size_t stride,
-                                                             const uint32_t* __restrict__ list, uint32_t count, Fe v,
-                                                             Fe sub, Fe* __restrict__ out, uint32_t n) {
+// out[b][i] = (...((p_0[i]) x + p_1[i]) x + ...) + p_{m-1}[i] with x = pc[b].xn (vanishing::evaluate's h(X))
+__global__ __launch_bounds__(256) void horner_combine_kernel(PolySet ps, const ProofConst* __restrict__ pc,
+                                                             const uint32_t* __restrict__ list, uint32_t count,
+                                                             Fe* __restrict__ out, size_t out_bs, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = blockIdx.y;
     if (i >= n) return;
+    const Fe v = pc[b].xn;
     Fe acc = fe_zero();
-    for (uint32_t j = 0; j < count; j++) acc = Fr::add(Fr::mul(acc, v), ldg(polys + (size_t)list[j] * stride + i));
-    if (i == 0) acc = Fr::sub(acc, sub);
-    stg(out + i, acc);
+    for (uint32_t j = 0; j < count; j++) acc = Fr::add(Fr::mul(acc, v), ldg(poly_of(ps, list[j], b) + i));
+    stg(out + (size_t)b * out_bs + i, acc);
 }
 
-int poly_horner_combine(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_list, uint32_t count,
-                        const Fe& v, const Fe& sub, Fe* out, uint32_t n) {
-    ZG_LAUNCH(ctx, "horner_combine", (double)(count + 1) * n * 32, horner_combine_kernel, dim3((n + 255) / 256), dim3(256),
-              0, polys, stride, d_list, count, v, sub, out, n);
+int poly_horner_combine_xn(zg_ctx* ctx, const PolySet& polys, const ProofConst* pc, uint32_t nb, const uint32_t* d_list,
+                           uint32_t count, Fe* out, size_t out_bs, uint32_t n) {
+    if (!nb) return ZG_OK;
+    ZG_LAUNCH(ctx, "horner_combine", (double)nb * (count + 1) * n * 32, horner_combine_kernel, dim3((n + 255) / 256, nb), dim3(256),
+              0, polys, pc, d_list, count, out, out_bs, n);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
 
-// the same for up to HC_MAX_SETS lists at once (GWC: one list per opening point): set s = blockIdx.y reads
-// lists + s * list_stride and writes out + s * out_stride
+// the same in pc[b].v for up to HC_MAX_SETS lists at once (GWC: one list per opening point): set s = blockIdx.y of
+// proof b = blockIdx.z reads lists + s * list_stride and writes out + b * out_bs + s * out_stride, with
+// pc[b].subs[s] taken off the constant term
 struct HornerSets {
     uint32_t count[HC_MAX_SETS];
-    Fe sub[HC_MAX_SETS];
 };
-__global__ __launch_bounds__(256) void horner_combine_sets_kernel(const Fe* __restrict__ polys, size_t stride,
+__global__ __launch_bounds__(256) void horner_combine_sets_kernel(PolySet ps, const ProofConst* __restrict__ pc,
                                                                   const uint32_t* __restrict__ lists, uint32_t list_stride,
-                                                                  HornerSets sets, Fe v, Fe* __restrict__ out, size_t out_stride,
-                                                                  uint32_t n) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+                                                                  HornerSets sets, Fe* __restrict__ out, size_t out_stride,
+                                                                  size_t out_bs, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, b = blockIdx.z;
     if (i >= n) return;
     const uint32_t* list = lists + (size_t)s * list_stride;
     const uint32_t count = sets.count[s];
+    const Fe v = pc[b].v;
     Fe acc = fe_zero();
-    for (uint32_t j = 0; j < count; j++) acc = Fr::add(Fr::mul(acc, v), ldg(polys + (size_t)list[j] * stride + i));
-    if (i == 0) acc = Fr::sub(acc, sets.sub[s]);
-    stg(out + (size_t)s * out_stride + i, acc);
+    for (uint32_t j = 0; j < count; j++) acc = Fr::add(Fr::mul(acc, v), ldg(poly_of(ps, list[j], b) + i));
+    if (i == 0) acc = Fr::sub(acc, pc[b].subs[s]);
+    stg(out + (size_t)b * out_bs + (size_t)s * out_stride + i, acc);
 }
 
-int poly_horner_combine_sets(zg_ctx* ctx, const Fe* polys, size_t stride, const uint32_t* d_lists, uint32_t list_stride,
-                             const uint32_t* counts, const Fe* subs, uint32_t nsets, const Fe& v, Fe* out, size_t out_stride,
-                             uint32_t n) {
-    if (!nsets) return ZG_OK;
+int poly_horner_combine_sets(zg_ctx* ctx, const PolySet& polys, const ProofConst* pc, uint32_t nb, const uint32_t* d_lists,
+                             uint32_t list_stride, const uint32_t* counts, uint32_t nsets, Fe* out, size_t out_stride,
+                             size_t out_bs, uint32_t n) {
+    if (!nsets || !nb) return ZG_OK;
     ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "poly_horner_combine_sets: %u sets", nsets);
     HornerSets sets;
     memset(&sets, 0, sizeof(sets));
     double total = 0;
     for (uint32_t s = 0; s < nsets; s++) {
         sets.count[s] = counts[s];
-        sets.sub[s] = subs[s];
         total += counts[s] + 1;
     }
-    ZG_LAUNCH(ctx, "horner_combine", total * n * 32, horner_combine_sets_kernel, dim3((n + 255) / 256, nsets), dim3(256), 0, polys,
-              stride, d_lists, list_stride, sets, v, out, out_stride, n);
+    ZG_LAUNCH(ctx, "horner_combine", nb * total * n * 32, horner_combine_sets_kernel, dim3((n + 255) / 256, nsets, nb), dim3(256), 0,
+              polys, pc, d_lists, list_stride, sets, out, out_stride, out_bs, n);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -898,21 +967,26 @@ int poly_horner_combine_sets(zg_ctx* ctx, const Fe* polys, size_t stride, const 
 // kate_division: q_i = a_{i+1} + z q_{i+1} (i = n-2 .. 0, q_{n-1} = 0), i.e. the weighted suffix sums
 // q_i = sum_{j>=i} a_{j+1} z^(j-i).  Same three-launch shape as the grand product: block-local weighted
 // suffix scans (weight z^off at step off), one workgroup per polynomial for the block heads (weight
-// z^256 per block), then q_i = local_i + z^(block_end - i) * carry.  Batched over (polynomial, point).
+// z^256 per block), then q_i = local_i + z^(block_end - i) * carry.  Batched over (proof, point set):
+// set s of proof b divides by X - pc[b].points[slot[s]]; scratch rows are indexed b * nsets + s.
 constexpr uint32_t KD_BLOCK = 256;
+struct KdSlots {
+    uint32_t slot[HC_MAX_SETS];
+};
 
-// (the opening points travel in the kernel arguments: FeSet, at most FESET_MAX of them per launch)
-__global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const Fe* __restrict__ a, size_t a_stride, FeSet zs,
+__global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const ProofConst* __restrict__ pc, KdSlots slots,
+                                                            const Fe* __restrict__ a, size_t a_stride, size_t a_bs,
                                                             Fe* __restrict__ loc, Fe* __restrict__ heads, uint32_t n,
                                                             uint32_t nblk) {
     __shared__ Fe sh[KD_BLOCK];
-    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    const uint32_t q = b * gridDim.y + s;
     const uint32_t i = blk * KD_BLOCK + tid;
-    const Fe* ap = a + (size_t)b * a_stride;
+    const Fe* ap = a + (size_t)b * a_bs + (size_t)s * a_stride;
     Fe v = (i + 1 < n) ? ldg(ap + i + 1) : fe_zero();
     sh[tid] = v;
     __syncthreads();
-    Fe w = zs.v[b];  // z^off
+    Fe w = pc[b].points[slots.slot[s]];  // z^off
     for (uint32_t off = 1; off < KD_BLOCK; off <<= 1) {
         Fe t = fe_zero();
         const bool has = tid + off < KD_BLOCK;
@@ -922,18 +996,20 @@ __global__ __launch_bounds__(KD_BLOCK) void kd_local_kernel(const Fe* __restrict
         w = Fr::sqr(w);
         __syncthreads();
     }
-    if (i < n) stg(loc + (size_t)b * n + i, sh[tid]);
-    if (tid == 0) stg(heads + (size_t)b * nblk + blk, sh[0]);
+    if (i < n) stg(loc + (size_t)q * n + i, sh[tid]);
+    if (tid == 0) stg(heads + (size_t)q * nblk + blk, sh[0]);
 }
 
 // heads[blk] <- sum_{blk' > blk} heads[blk'] * (z^256)^(blk' - blk - 1): the carry entering block blk from above
-__global__ __launch_bounds__(1024) void kd_heads_kernel(Fe* __restrict__ heads, FeSet zs, uint32_t nblk) {
+__global__ __launch_bounds__(1024) void kd_heads_kernel(const ProofConst* __restrict__ pc, KdSlots slots, uint32_t nsets,
+                                                        Fe* __restrict__ heads, uint32_t nblk) {
     __shared__ Fe sh[1024];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
-    Fe* hp = heads + (size_t)b * nblk;
+    const uint32_t tid = threadIdx.x, q = blockIdx.x;
+    const uint32_t b = q / nsets, s = q % nsets;
+    Fe* hp = heads + (size_t)q * nblk;
     sh[tid] = tid < nblk ? ldg(hp + tid) : fe_zero();
     __syncthreads();
-    Fe w = Fr::pow_u64(zs.v[b], KD_BLOCK);
+    Fe w = Fr::pow_u64(pc[b].points[slots.slot[s]], KD_BLOCK);
     uint32_t span = 64;  // (entries at and beyond nblk are zero: the scan only has to span the block heads)
     while (span < nblk) span <<= 1;
     for (uint32_t off = 1; off < span; off <<= 1) {
@@ -950,15 +1026,18 @@ __global__ __launch_bounds__(1024) void kd_heads_kernel(Fe* __restrict__ heads, 
     if (tid < nblk) stg(hp + tid, carry);
 }
 
-__global__ __launch_bounds__(KD_BLOCK) void kd_apply_kernel(const Fe* __restrict__ loc, const Fe* __restrict__ heads, FeSet zs,
-                                                            Fe* __restrict__ q, size_t q_stride, uint32_t n, uint32_t nblk) {
-    const uint32_t tid = threadIdx.x, blk = blockIdx.x, b = blockIdx.y;
+__global__ __launch_bounds__(KD_BLOCK) void kd_apply_kernel(const ProofConst* __restrict__ pc, KdSlots slots,
+                                                            const Fe* __restrict__ loc, const Fe* __restrict__ heads,
+                                                            Fe* __restrict__ qo, size_t q_stride, size_t q_bs, uint32_t n,
+                                                            uint32_t nblk) {
+    const uint32_t tid = threadIdx.x, blk = blockIdx.x, s = blockIdx.y, b = blockIdx.z;
+    const uint32_t q = b * gridDim.y + s;
     const uint32_t i = blk * KD_BLOCK + tid;
     if (i >= n) return;
-    Fe v = ldg(loc + (size_t)b * n + i);
-    Fe carry = ldg(heads + (size_t)b * nblk + blk);
-    if (!fe_is_zero(carry)) v = Fr::add(v, Fr::mul(Fr::pow_u64(zs.v[b], KD_BLOCK - tid), carry));
-    stg(q + (size_t)b * q_stride + i, v);
+    Fe v = ldg(loc + (size_t)q * n + i);
+    Fe carry = ldg(heads + (size_t)q * nblk + blk);
+    if (!fe_is_zero(carry)) v = Fr::add(v, Fr::mul(Fr::pow_u64(pc[b].points[slots.slot[s]], KD_BLOCK - tid), carry));
+    stg(qo + (size_t)b * q_bs + (size_t)s * q_stride + i, v);
 }
 
 size_t poly_kate_tmp_elems(uint32_t n, uint32_t batch) {
@@ -966,26 +1045,28 @@ size_t poly_kate_tmp_elems(uint32_t n, uint32_t batch) {
     return (size_t)batch * n + (size_t)batch * nblk + batch;
 }
 
-// zs_host: `batch` opening points; a_b = a + b*a_stride, q_b = q + b*q_stride; tmp per poly_kate_tmp_elems
-int poly_kate_division(zg_ctx* ctx, const Fe* a, size_t a_stride, const Fe* zs_host, Fe* q, size_t q_stride, Fe* tmp,
-                       uint32_t n, uint32_t batch) {
-    if (!batch || !n) return ZG_OK;
+// tmp per poly_kate_tmp_elems(n, nb * nsets)
+int poly_kate_division(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, const uint32_t* slots, uint32_t nsets, const Fe* a,
+                       size_t a_stride, size_t a_bs, Fe* q, size_t q_stride, size_t q_bs, Fe* tmp, uint32_t n) {
+    if (!nb || !nsets || !n) return ZG_OK;
     const uint32_t nblk = (n + KD_BLOCK - 1) / KD_BLOCK;
     ZG_REQUIRE(nblk <= 1024, ZG_ERR_UNSUPPORTED, "kate division: n=%u > 2^18 not built", n);
-    for (uint32_t b0 = 0; b0 < batch; b0 += FESET_MAX) {
-        const uint32_t m = batch - b0 < FESET_MAX ? batch - b0 : FESET_MAX;
-        Fe* loc = tmp;
-        Fe* heads = loc + (size_t)m * n;
-        FeSet zs;
-        memset(&zs, 0, sizeof(zs));
-        for (uint32_t j = 0; j < m; j++) zs.v[j] = zs_host[b0 + j];
-        const double bytes = (double)m * n * 64;
-        ZG_LAUNCH(ctx, "kate_local", bytes, kd_local_kernel, dim3(nblk, m), dim3(KD_BLOCK), 0, a + (size_t)b0 * a_stride, a_stride,
-                  zs, loc, heads, n, nblk);
-        ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(m), dim3(1024), 0, heads, zs, nblk);
-        ZG_LAUNCH(ctx, "kate_apply", bytes, kd_apply_kernel, dim3(nblk, m), dim3(KD_BLOCK), 0, loc, heads, zs,
-                  q + (size_t)b0 * q_stride, q_stride, n, nblk);
+    ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "kate division: %u point sets", nsets);
+    KdSlots ks;
+    memset(&ks, 0, sizeof(ks));
+    for (uint32_t s = 0; s < nsets; s++) {
+        ZG_REQUIRE(slots[s] < PC_MAX_POINTS, ZG_ERR_INVALID_ARG, "kate division: point slot %u", slots[s]);
+        ks.slot[s] = slots[s];
     }
+    const uint32_t m = nb * nsets;
+    Fe* loc = tmp;
+    Fe* heads = loc + (size_t)m * n;
+    const double bytes = (double)m * n * 64;
+    ZG_LAUNCH(ctx, "kate_local", bytes, kd_local_kernel, dim3(nblk, nsets, nb), dim3(KD_BLOCK), 0, pc, ks, a, a_stride, a_bs, loc,
+              heads, n, nblk);
+    ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(m), dim3(1024), 0, pc, ks, nsets, heads, nblk);
+    ZG_LAUNCH(ctx, "kate_apply", bytes, kd_apply_kernel, dim3(nblk, nsets, nb), dim3(KD_BLOCK), 0, pc, ks, loc, heads, q, q_stride,
+              q_bs, n, nblk);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -1027,38 +1108,52 @@ int poly_scale(zg_ctx* ctx, const Fe* in, Fe* out, size_t count, const Fe& facto
     return ZG_OK;
 }
 
-// ---- interpolation across the two cosets of the split extended domain (prover.hip)
-__global__ void fold_kernel(const Fe* a, uint32_t len, uint32_t parts, Fe e, Fe* out) {
+// ---- interpolation across the two cosets of the split extended domain (prover.hip); proof b = blockIdx.y
+__global__ void fold_kernel(const Fe* a, size_t a_bs, uint32_t len, uint32_t parts, Fe e, Fe* out, size_t out_bs) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= len) return;
+    a += (size_t)blockIdx.y * a_bs;
     Fe acc = ldg(a + (size_t)(parts - 1) * len + r);
     for (uint32_t q = parts - 1; q-- > 0;) acc = Fr::add(Fr::mul(acc, e), ldg(a + (size_t)q * len + r));
-    stg(out + r, acc);
+    stg(out + (size_t)blockIdx.y * out_bs + r, acc);
 }
-int poly_fold(zg_ctx* ctx, const Fe* a, uint32_t len, uint32_t parts, const Fe& e, Fe* out) {
+int poly_fold(zg_ctx* ctx, uint32_t nb, const Fe* a, size_t a_bs, uint32_t len, uint32_t parts, const Fe& e, Fe* out,
+              size_t out_bs) {
     ZG_REQUIRE(parts >= 1 && len >= 1, ZG_ERR_INVALID_ARG, "poly_fold: %u parts of %u", parts, len);
-    ZG_LAUNCH(ctx, "fold", (double)(parts + 1) * len * 32, fold_kernel, dim3((len + 255) / 256), dim3(256), 0, a, len, parts, e, out);
+    if (!nb) return ZG_OK;
+    ZG_LAUNCH(ctx, "fold", (double)nb * (parts + 1) * len * 32, fold_kernel, dim3((len + 255) / 256, nb), dim3(256), 0, a, a_bs, len,
+              parts, e, out, out_bs);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
-__global__ void diff_scale_kernel(const Fe* u, Fe cu, const Fe* v, Fe scale, Fe* out, uint32_t len) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < len) stg(out + i, Fr::mul(Fr::sub(Fr::mul(ldg(u + i), cu), ldg(v + i)), scale));
+__global__ void diff_scale_kernel(const Fe* u, size_t u_bs, Fe cu, const Fe* v, size_t v_bs, Fe scale, Fe* out, size_t out_bs,
+                                  uint32_t len) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i < len)
+        stg(out + (size_t)b * out_bs + i,
+            Fr::mul(Fr::sub(Fr::mul(ldg(u + (size_t)b * u_bs + i), cu), ldg(v + (size_t)b * v_bs + i)), scale));
 }
-int poly_diff_scale(zg_ctx* ctx, const Fe* u, const Fe& cu, const Fe* v, const Fe& scale, Fe* out, uint32_t len) {
-    ZG_LAUNCH(ctx, "diff_scale", (double)len * 96, diff_scale_kernel, dim3((len + 255) / 256), dim3(256), 0, u, cu, v, scale, out, len);
+int poly_diff_scale(zg_ctx* ctx, uint32_t nb, const Fe* u, size_t u_bs, const Fe& cu, const Fe* v, size_t v_bs, const Fe& scale,
+                    Fe* out, size_t out_bs, uint32_t len) {
+    if (!nb) return ZG_OK;
+    ZG_LAUNCH(ctx, "diff_scale", (double)nb * len * 96, diff_scale_kernel, dim3((len + 255) / 256, nb), dim3(256), 0, u, u_bs, cu, v,
+              v_bs, scale, out, out_bs, len);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
-__global__ void split_combine_kernel(Fe* h, const Fe* b, uint32_t len, Fe c1, uint32_t hi_at) {
+__global__ void split_combine_kernel(Fe* h, size_t h_bs, const Fe* bq, size_t b_bs, uint32_t len, Fe c1, uint32_t hi_at) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= len) return;
-    const Fe bj = ldg(b + j);
+    h += (size_t)blockIdx.y * h_bs;
+    const Fe bj = ldg(bq + (size_t)blockIdx.y * b_bs + j);
     stg(h + j, Fr::sub(ldg(h + j), Fr::mul(c1, bj)));
     stg(h + hi_at + j, bj);
 }
-int poly_split_combine(zg_ctx* ctx, Fe* h, const Fe* b, uint32_t len, const Fe& c1, uint32_t hi_at) {
-    ZG_LAUNCH(ctx, "split_combine", (double)len * 128, split_combine_kernel, dim3((len + 255) / 256), dim3(256), 0, h, b, len, c1, hi_at);
+int poly_split_combine(zg_ctx* ctx, uint32_t nb, Fe* h, size_t h_bs, const Fe* b, size_t b_bs, uint32_t len, const Fe& c1,
+                       uint32_t hi_at) {
+    if (!nb) return ZG_OK;
+    ZG_LAUNCH(ctx, "split_combine", (double)nb * len * 128, split_combine_kernel, dim3((len + 255) / 256, nb), dim3(256), 0, h, h_bs,
+              b, b_bs, len, c1, hi_at);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -2,6 +2,9 @@
 // halo2_proofs::plonk::create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC, _, _, EvmTranscript, _>
 // as Wnn::proof calls it (/root/reference/src/wnn.rs:232-262; upstream v2023_04_20 src/plonk/prover.rs).
 //
+// Proofs are made in lock-step batches: one launch sequence serves `nb` circuit instances at once (a single proof
+// is the batch of one), each with its own Fiat-Shamir transcript on the host.
+//
 // Everything between "advice columns assigned" and "proof bytes" stays in HBM: columns, coefficient
 // forms, extended cosets, lookup/permutation products, h(X).  The host only sees what the Fiat-Shamir
 // transcript needs -- commitments (one 128-B XYZZ point each), evaluations (32 B each).  Even
@@ -77,17 +80,16 @@ void keccak256(const uint8_t* data, size_t len, uint8_t out[32]) {
 
 using namespace zg;
 
-// ------------------------------------------------------------------ prover object
-struct zg_prover {
-    zg_ctx* ctx = nullptr;
+// ------------------------------------------------------------------ proving key on the device
+// What keygen_pk derives, resident in HBM, shared (read-only) by every prover forked from the one that built it.
+struct PkDev {
+    int device = 0;
     uint32_t k = 0, ext_k = 0, cs_degree = 0, bf = 0, qpd = 0;
     uint32_t n = 0, en = 0, usable = 0;
     uint32_t F = 0, A = 0, I = 0, P = 0, NL = 0, sets = 0, chunk = 0;
     std::vector<zg_query> advice_queries, fixed_queries;
     DevCircuit dc{};
-    std::vector<void*> owned;  // device allocations freed at destroy
-    zg_bases *g = nullptr, *gl = nullptr;
-    bool use_side = true;   // coefficient / coset forms on a side stream (latency) or inline (throughput)
+    std::vector<void*> owned;  // device allocations freed with the key
     // evaluate_h on nine 29-bit limbs: the coset slabs, l-polynomials, t_eval and the monomial coefficients it
     // reads are kept in the 2^261 Montgomery form (x * 2^5 of the library form); ZG_EVALH9=0 turns it off
     bool hat = true;
@@ -99,11 +101,10 @@ struct zg_prover {
     uint32_t* gate_slab = nullptr;  // per gate: index of its U(fixed cell) coset in gate_slabs, or 0xffffffff
     struct SlabJob { uint32_t gate, query, first, count; };
     std::vector<SlabJob> slab_jobs;  // filled when the gates are factored, run once the fixed cosets exist
-    bool own_bases = true;  // false: tables shared with other provers of the same device
     Fe vk_repr{};
     Fe omega{}, omega_inv{}, ifft_div{};
-    // pk-derived, resident
     Fe *fixed_val = nullptr, *sigma_val = nullptr, *omega_tw = nullptr;
+    Fe* sh_polys = nullptr;  // coefficient forms [F + P][n]: fixed, then sigma
     // The extended domain evaluate_h works on.  Either EvaluationDomain's own coset zeta * <omega_(2^ext_k)> (8n points
     // for degree 6), or -- split -- two cosets that together hold just the (degree - 1) * n points the quotient needs:
     // zeta * <omega_(m1 n)> and zeta^2 * <omega_(m2 n)>, m1 + m2 = degree - 1 (4n + n).  Every coset slab exists per part.
@@ -111,43 +112,71 @@ struct zg_prover {
         uint32_t ek = 0, en = 0;
         int zpow = 1;  // the coset shift is zeta^zpow
         Fe *fixed_cos = nullptr, *sigma_cos = nullptr, *l0 = nullptr, *llast = nullptr, *lactive = nullptr,
-           *gate_slabs = nullptr, *t_eval = nullptr, *ext_tw = nullptr;                                   // proving key
-        Fe *adv_cos = nullptr, *inst_cos = nullptr, *pz_cos = nullptr, *lz_cos = nullptr, *perm_cos = nullptr,
-           *h = nullptr;                                                                                   // per proof
+           *gate_slabs = nullptr, *t_eval = nullptr, *ext_tw = nullptr;
     };
-    Dom dom[3];               // [0]: the single coset; [1], [2]: the two parts of the split domain (when it applies)
-    uint32_t nparts = 1;      // 1, or 3 when the split domain is prepared too
-    bool last_split = false;  // which of the two the last proof used (zg_prover_fetch)
-    Fe* split_tmp = nullptr;  // interpolation between the two parts: 3 * dom[2].en elements
-    // coefficient-form slab [n_polys][n]
-    Fe* polys = nullptr;
-    uint32_t n_polys = 0;
+    Dom dom[3];           // [0]: the single coset; [1], [2]: the two parts of the split domain (when it applies)
+    uint32_t nparts = 1;  // 1, or 3 when the split domain is prepared too
+    ~PkDev() {
+        (void)hipSetDevice(device);
+        for (void* q : owned) (void)hipFree(q);
+    }
+};
+
+// ------------------------------------------------------------------ prover object
+// One context (stream + workspace), one proving key (possibly shared), `cap` proof slots: every per-proof buffer is
+// [cap] x its single-proof size, proof-major, so that one launch serves every proof of a lock-step batch.
+struct zg_prover {
+    zg_ctx* ctx = nullptr;
+    std::shared_ptr<PkDev> pk;
+    zg_bases *g = nullptr, *gl = nullptr;
+    bool own_bases = true;  // false: tables shared with other provers of the same device
+    bool use_side = true;   // coefficient / coset forms on a side stream (latency) or inline (throughput)
+    // point-range shard of the commitments (zg_prover_set_shard): this prover's base sets hold points
+    // [shard_lo, shard_lo + shard_n) of the SRS; partial commitments of all ranks are exchanged and summed
+    uint32_t shard_lo = 0, shard_n = 0, world = 1, rank = 0;
+    zg_exchange_fn exchange = nullptr;
+    void* exchange_user = nullptr;
+    // per-proof buffers, [cap] slots each (alloc_slots)
+    uint32_t cap = 0;
+    std::vector<void*> slot_owned;
+    uint32_t npp = 0;  // per-proof coefficient polynomials: advice, instance, perm z, lookup z, a'/s', random, h pieces, h
+    uint32_t ncos = 0; // per-proof coset slabs: advice, instance, perm z, lookup z, a'/s'
+    // indices into the coefficient-polynomial space (PolySet: < nsh = F + P shared, the rest per proof)
     uint32_t ix_fixed = 0, ix_sigma = 0, ix_adv = 0, ix_inst = 0, ix_pz = 0, ix_lz = 0, ix_perm = 0, ix_random = 0,
-             ix_hpiece = 0, ix_hpoly = 0;
-    // per-proof buffers
-    Fe *adv_val = nullptr, *inst_val = nullptr;
-    Fe *cin = nullptr, *ctab = nullptr, *perm = nullptr /* [2NL][n]: a'_l, s'_l */, *zs = nullptr /* [sets+NL][n] */;
-    Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr,
-       *raw = nullptr, *sraw = nullptr, *sort_fe = nullptr;
+             ix_hpiece = 0, ix_hpoly = 0, nsh = 0;
+    Fe* pp = nullptr;  // [cap][npp][n]
+    struct DomBuf {
+        Fe *cos = nullptr /* [cap][ncos][en] */, *h = nullptr /* [cap][en] */;
+    };
+    DomBuf dbuf[3];
+    Fe* split_tmp = nullptr;  // [cap][3 * dom[2].en]
+    Fe *adv_val = nullptr /* [cap][A][n] */, *inst_val = nullptr /* [cap][I][n] */;
+    Fe *cin = nullptr, *ctab = nullptr /* [cap * NL][n] each */, *perm = nullptr /* [cap][2NL + 1][n]: a'_l, s'_l, random */,
+       *zs = nullptr /* [cap][S + NL + 1][n] */;
+    Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr, *raw = nullptr,
+       *sraw = nullptr, *sort_fe = nullptr, *ktmp = nullptr;
     uint32_t *sort_u32 = nullptr, *d_err = nullptr;
-    Fe *pin_c = nullptr, *ptab_c = nullptr;
     XYZZ* xyzz = nullptr;
-    uint32_t* d_idx = nullptr;
+    uint32_t maxv = 0, max_points = 0, max_evals = 0;
+    ProofConst* d_pc = nullptr;
+    std::vector<ProofConst> hpc;
+    uint32_t* d_idx = nullptr;  // index lists (circuit only: the same for every proof)
     std::map<uint32_t*, std::vector<uint32_t>> uploaded_lists;  // what h2d_list left at each destination
-    size_t inst_filled = 0;  // rows of inst_val that may be non-zero
-    Fe* ktmp = nullptr;
+    std::vector<size_t> inst_filled;  // per slot: rows of inst_val that may be non-zero
     hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
     void* pinned = nullptr;
-    size_t pinned_cap = 0;
+    size_t pinned_cap = 0, pin_results = 0, pin_evals = 0, pin_stage = 0;
     size_t stage_off = 0;
     bool have_last = false;
+    bool last_split = false;  // which extended domain the last proof used (zg_prover_fetch)
+    uint32_t last_nb = 0;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 namespace {
 
 template <class T>
-int dalloc(zg_prover* p, T** out, size_t count) {
+int dalloc_into(std::vector<void*>& owned, T** out, size_t count) {
     void* q = nullptr;
     size_t bytes = (count ? count : 1) * sizeof(T);
     hipError_t e = hipMalloc(&q, bytes);
@@ -155,7 +184,7 @@ int dalloc(zg_prover* p, T** out, size_t count) {
         set_error("zg_prover: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
         return ZG_ERR_OOM;
     }
-    p->owned.push_back(q);
+    owned.push_back(q);
     *out = reinterpret_cast<T*>(q);
     return ZG_OK;
 }
@@ -166,18 +195,15 @@ inline Fe to_fe(const zg_fr* s) {
     return r;
 }
 
-Fe rotate_omega(const zg_prover* p, const Fe& x, int32_t rot) {
-    Fe w = rot >= 0 ? Fr::pow_u64(p->omega, (uint64_t)rot) : Fr::pow_u64(p->omega_inv, (uint64_t)(-(int64_t)rot));
+Fe rotate_omega(const PkDev& k, const Fe& x, int32_t rot) {
+    Fe w = rot >= 0 ? Fr::pow_u64(k.omega, (uint64_t)rot) : Fr::pow_u64(k.omega_inv, (uint64_t)(-(int64_t)rot));
     return Fr::mul(x, w);
 }
 
 // Small host->device transfers go through a pinned staging arena: hipMemcpyAsync from pageable memory
 // blocks the calling thread until the stream has drained up to the copy, which serialises host and
 // GPU inside a proof and throttles concurrent proof streams.  The arena is a bump allocator reset at
-// the start of every proof; each region is written once per proof.
-constexpr size_t PIN_RESULTS = 0;            // commitments D2H
-constexpr size_t PIN_EVALS = 64 * 1024;      // evaluations D2H
-constexpr size_t PIN_STAGE = 128 * 1024;     // H2D staging arena starts here
+// the start of every batch; each region is written once per batch.
 void* stage(zg_prover* p, const void* src, size_t bytes) {
     size_t off = (p->stage_off + 63) & ~size_t(63);
     if (off + bytes > p->pinned_cap - 4096) return nullptr;  // caller falls back to a direct copy
@@ -200,23 +226,127 @@ int h2d_list(zg_prover* p, uint32_t* d_dst, const std::vector<uint32_t>& list) {
 int h2d(zg_prover* p, void* d_dst, const void* src, size_t bytes) {
     const void* s = stage(p, src, bytes);
     ZG_HIP(hipMemcpyAsync(d_dst, s ? s : src, bytes, hipMemcpyHostToDevice, p->ctx->stream));
+    if (!s) ZG_HIP(hipStreamSynchronize(p->ctx->stream));
+    return ZG_OK;
+}
+// the per-proof scalars of the batch, as the host holds them now, to the device (behind the work already queued)
+int upload_consts(zg_prover* p, uint32_t nb) { return h2d(p, p->d_pc, p->hpc.data(), (size_t)nb * sizeof(ProofConst)); }
+
+}  // namespace
+
+// Host: out[i] = normalised sum over ranks r of the extended-Jacobian (X, Y, ZZ, ZZZ; 128 B) partial parts[r * count + i]
+// -- the additions that follow the all-gather of a sharded commitment phase.
+extern "C" int zg_xyzz_sum_ranks(const void* parts, size_t world, size_t count, zg_g1* out) {
+    ZG_REQUIRE(out && (parts || count == 0) && world >= 1, ZG_ERR_INVALID_ARG, "zg_xyzz_sum_ranks: bad argument");
+    const XYZZ* all = reinterpret_cast<const XYZZ*>(parts);
+    std::vector<XYZZ> sum(count);
+    for (size_t i = 0; i < count; i++) {
+        XYZZ acc = all[i];
+        for (size_t r = 1; r < world; r++) acc = xyzz_add(acc, all[r * count + i]);
+        sum[i] = acc;
+    }
+    xyzz_batch_normalise(sum.data(), count, out);
     return ZG_OK;
 }
 
-// D2H of `count` XYZZ results behind the work already queued; returns after ONLY that copy is done
-int fetch_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
-    zg_ctx* ctx = p->ctx;
-    ZG_HIP(hipMemcpyAsync((char*)p->pinned + PIN_RESULTS, p->xyzz, count * sizeof(XYZZ), hipMemcpyDeviceToHost, ctx->stream));
-    ZG_HIP(hipEventRecord(p->ev, ctx->stream));
+namespace {
+
+// Commitments of a phase: one MSM launch sequence over `count` = groups x per scalar vectors (msm_batch4_dev), against
+// this prover's point range of the base sets; the XYZZ results go to the host behind it.
+int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, const Fe* scalars, size_t stride, size_t per,
+           size_t outer, size_t count, uint64_t run_mask) {
+    ZG_REQUIRE(count <= p->maxv * (size_t)p->cap, ZG_ERR_INVALID_ARG, "zg_prover: %zu commitments in one phase", count);
+    ZG_TRY(msm_batch4_dev(p->ctx, a, b2, split, scalars + p->shard_lo, stride, per, outer, count, p->shard_n, p->xyzz, run_mask));
+    ZG_HIP(hipMemcpyAsync((char*)p->pinned + p->pin_results, p->xyzz, count * sizeof(XYZZ), hipMemcpyDeviceToHost, p->ctx->stream));
+    ZG_HIP(hipEventRecord(p->ev, p->ctx->stream));
     return ZG_OK;
 }
+// ... and waits for ONLY that copy; with a sharded SRS the partial commitments of all ranks are exchanged
+// (all-gather) and summed here -- EC addition is not a reduction operator of the collective library
 int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
     ZG_HIP(hipEventSynchronize(p->ev));
+    const XYZZ* local = (const XYZZ*)((char*)p->pinned + p->pin_results);
     out.resize(count);
-    xyzz_batch_normalise((const XYZZ*)((char*)p->pinned + PIN_RESULTS), count, reinterpret_cast<zg_g1*>(out.data()));
-    return ZG_OK;
+    if (p->world <= 1) {
+        xyzz_batch_normalise(local, count, reinterpret_cast<zg_g1*>(out.data()));
+        return ZG_OK;
+    }
+    ZG_REQUIRE(p->exchange != nullptr, ZG_ERR_INVALID_ARG, "zg_prover: sharded prover without an exchange function");
+    std::vector<XYZZ> all((size_t)p->world * count);
+    const int st = p->exchange(p->exchange_user, local, count * sizeof(XYZZ), all.data());
+    ZG_REQUIRE(st == 0, ZG_ERR_HIP, "zg_prover: the exchange function failed with %d", st);
+    return zg_xyzz_sum_ranks(all.data(), p->world, count, reinterpret_cast<zg_g1*>(out.data()));
 }
 
+void free_slots(zg_prover* p) {
+    for (void* q : p->slot_owned) (void)hipFree(q);
+    p->slot_owned.clear();
+    if (p->pinned) (void)hipHostFree(p->pinned);
+    p->pinned = nullptr;
+    p->cap = 0;
+    p->uploaded_lists.clear();
+}
+
+// (re)allocates every per-proof buffer for `cap` proofs in flight
+int alloc_slots(zg_prover* p, uint32_t cap) {
+    const PkDev& k = *p->pk;
+    ZG_REQUIRE(cap >= 1 && cap <= 1024, ZG_ERR_INVALID_ARG, "zg_prover: batch of %u proofs", cap);
+    free_slots(p);
+    auto& own = p->slot_owned;
+    const uint32_t n = k.n, F = k.F, A = k.A, I = k.I, P = k.P, NL = k.NL, S = k.sets, Q = k.qpd;
+    (void)F;
+    p->cap = cap;
+    p->ncos = A + I + S + NL + 2 * NL;
+    p->npp = p->ncos + 1 + Q + 1;
+    p->nsh = k.F + P;
+    p->ix_fixed = 0; p->ix_sigma = k.F; p->ix_adv = p->nsh; p->ix_inst = p->ix_adv + A; p->ix_pz = p->ix_inst + I;
+    p->ix_lz = p->ix_pz + S; p->ix_perm = p->ix_lz + NL; p->ix_random = p->ix_perm + 2 * NL;
+    p->ix_hpiece = p->ix_random + 1; p->ix_hpoly = p->ix_hpiece + Q;
+    const size_t c = cap;
+    ZG_TRY(dalloc_into(own, &p->pp, c * p->npp * n));
+    for (uint32_t di = 0; di < k.nparts; di++) {
+        // (one block per proof, in the order of the coefficient slab: advice, instance, permutation z, lookup z, a'/s'
+        //  -- the split form transforms all of them in one batch)
+        ZG_TRY(dalloc_into(own, &p->dbuf[di].cos, c * p->ncos * k.dom[di].en));
+        ZG_TRY(dalloc_into(own, &p->dbuf[di].h, c * k.dom[di].en));
+    }
+    if (k.nparts == 3) ZG_TRY(dalloc_into(own, &p->split_tmp, c * 3 * k.dom[2].en));
+    ZG_TRY(dalloc_into(own, &p->adv_val, c * A * n));
+    ZG_TRY(dalloc_into(own, &p->inst_val, c * I * n));
+    if (I) ZG_HIP(hipMemset(p->inst_val, 0, c * I * n * 32));  // rows past the instance stay zero (prove refills only what it must)
+    p->inst_filled.assign(cap, 0);
+    ZG_TRY(dalloc_into(own, &p->cin, c * 2 * NL * n));  // compressed inputs, then compressed tables
+    p->ctab = p->cin + c * NL * n;
+    ZG_TRY(dalloc_into(own, &p->perm, c * (2 * NL + 1) * n));  // + the vanishing argument's random polynomial
+    ZG_TRY(dalloc_into(own, &p->zs, c * (S + NL + 1) * n));
+    const uint32_t mb = S + NL;
+    ZG_TRY(dalloc_into(own, &p->num, c * mb * n));
+    ZG_TRY(dalloc_into(own, &p->den, c * mb * n));
+    ZG_TRY(dalloc_into(own, &p->tmp, poly_grand_product_tmp_elems(n, cap * mb)));
+    ZG_TRY(dalloc_into(own, &p->raw, c * 2 * NL * n));
+    ZG_TRY(dalloc_into(own, &p->sraw, c * NL * n));
+    ZG_TRY(dalloc_into(own, &p->sort_fe, c * NL * n));
+    ZG_TRY(dalloc_into(own, &p->sort_u32, c * 2 * NL * n + c * 3 * NL + 2));
+    p->max_points = 4 + (uint32_t)(k.advice_queries.size() + k.fixed_queries.size());
+    if (p->max_points > PC_MAX_POINTS) p->max_points = PC_MAX_POINTS;
+    ZG_TRY(dalloc_into(own, &p->pw, c * p->max_points * n));
+    p->max_evals = (uint32_t)(k.advice_queries.size() + k.fixed_queries.size()) + P + 3 * S + 5 * NL + 4;
+    ZG_TRY(dalloc_into(own, &p->evals, c * p->max_evals));
+    ZG_TRY(dalloc_into(own, &p->wpoly, c * 2 * p->max_points * n));
+    p->maxv = std::max<uint32_t>(std::max<uint32_t>(A, 2 * NL + 1), std::max<uint32_t>(S + NL + 1, std::max<uint32_t>(Q, p->max_points)));
+    ZG_TRY(dalloc_into(own, &p->xyzz, c * p->maxv));
+    ZG_TRY(dalloc_into(own, &p->d_idx, (size_t)4 * p->max_evals + 64 + (size_t)p->max_points * 512));
+    ZG_TRY(dalloc_into(own, &p->ktmp, poly_kate_tmp_elems(n, cap * p->max_points)));
+    ZG_TRY(dalloc_into(own, &p->d_pc, c));
+    p->hpc.assign(cap, ProofConst{});
+    // pinned: commitments D2H (128 B each), evaluations D2H, error flags, then the H2D staging arena
+    p->pin_results = 0;
+    p->pin_evals = (c * p->maxv * sizeof(XYZZ) + 4095) & ~size_t(4095);
+    p->pin_stage = p->pin_evals + ((c * p->max_evals * sizeof(Fe) + c * NL * 4 + 4095) & ~size_t(4095));
+    p->pinned_cap = p->pin_stage + (1u << 20) + c * 16 * sizeof(ProofConst) + c * (size_t)k.I * 4096;
+    ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocDefault));
+    return ZG_OK;
+}
 
 // ---- evaluate_h's view of one gate: gate = U(cell f) * inner, f a query index present in every monomial.
 // U(x) = x when f occurs exactly once per monomial (uc empty); otherwise the monomials are grouped by the
@@ -304,6 +434,7 @@ GateFactor factor_gate(const std::vector<DMono>& monos, zg_poly g, uint32_t f, c
     return out;
 }
 
+
 }  // namespace
 
 extern "C" {
@@ -312,27 +443,30 @@ void zg_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) { keccak256(
 
 size_t zg_prover_proof_size(const zg_prover* p) {
     if (!p) return 0;
-    size_t points = p->A + 2 * p->NL + p->sets + p->NL + 1 + p->qpd;
-    size_t scalars = p->advice_queries.size() + p->fixed_queries.size() + 1 + p->P + (p->sets ? 3 * p->sets - 1 : 0) +
-                     5 * p->NL;
-    size_t max_open = 2 + p->advice_queries.size() + p->fixed_queries.size();
+    const PkDev& k = *p->pk;
+    size_t points = k.A + 2 * k.NL + k.sets + k.NL + 1 + k.qpd;
+    size_t scalars = k.advice_queries.size() + k.fixed_queries.size() + 1 + k.P + (k.sets ? 3 * k.sets - 1 : 0) + 5 * k.NL;
+    size_t max_open = 2 + k.advice_queries.size() + k.fixed_queries.size();
     return 64 * (points + max_open) + 32 * scalars;
 }
 
 void zg_prover_destroy(zg_prover* p) {
     if (!p) return;
-    (void)hipSetDevice(p->ctx->device);
-    (void)hipStreamSynchronize(p->ctx->stream);
-    if (p->ctx->side) (void)hipStreamSynchronize(p->ctx->side->stream);
-    for (void* q : p->owned) (void)hipFree(q);
-    if (p->own_bases) {
-        if (p->g) zg_bases_free(p->g);
-        if (p->gl) zg_bases_free(p->gl);
+    {
+        std::lock_guard<std::recursive_mutex> lock(p->ctx->mu);
+        (void)hipSetDevice(p->ctx->device);
+        (void)hipStreamSynchronize(p->ctx->stream);
+        if (p->ctx->side) (void)hipStreamSynchronize(p->ctx->side->stream);
+        free_slots(p);
+        if (p->own_bases) {
+            if (p->g) zg_bases_free(p->g);
+            if (p->gl) zg_bases_free(p->gl);
+        }
+        if (p->ev) (void)hipEventDestroy(p->ev);
+        if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+        if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+        p->pk.reset();  // (the key's HBM goes with its last prover)
     }
-    if (p->ev) (void)hipEventDestroy(p->ev);
-    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
-    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
-    if (p->pinned) (void)hipHostFree(p->pinned);
     delete p;
 }
 
@@ -352,6 +486,13 @@ int zg_prover_create_shared(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixe
     return prover_create_impl(ctx, cs, fixed_values, sigma_values, nullptr, nullptr, g, g_lagrange, vk_repr, out);
 }
 
+static int prover_events(zg_prover* p) {
+    ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    return ZG_OK;
+}
+
 static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixed_values, const zg_fr* sigma_values,
                               const zg_g1_affine* g, const zg_g1_affine* g_lagrange, const zg_bases* shared_g,
                               const zg_bases* shared_gl, const zg_fr* vk_repr, zg_prover** out) {
@@ -360,42 +501,44 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_REQUIRE(cs->n_perm_columns == 0 || sigma_values, ZG_ERR_INVALID_ARG, "zg_prover_create: sigma_values is null");
     ZG_REQUIRE(cs->cs_degree >= 3 && cs->cs_degree <= 9, ZG_ERR_UNSUPPORTED, "zg_prover_create: cs_degree %u", cs->cs_degree);
     ZG_REQUIRE(cs->k >= 4, ZG_ERR_UNSUPPORTED, "zg_prover_create: k=%u < 4", cs->k);
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     std::unique_ptr<zg_prover, void (*)(zg_prover*)> guard(new zg_prover(), zg_prover_destroy);
     zg_prover* p = guard.get();
     p->ctx = ctx;
-    p->k = cs->k;
-    p->n = 1u << cs->k;
-    p->cs_degree = cs->cs_degree;
-    p->bf = cs->blinding_factors;
-    p->qpd = cs->cs_degree - 1;
-    p->ext_k = cs->k;
-    while ((1ull << p->ext_k) < (uint64_t)p->n * p->qpd) p->ext_k++;
-    ZG_REQUIRE(p->ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_prover_create: extended domain 2^%u not built", p->ext_k);
-    p->en = 1u << p->ext_k;
-    ZG_REQUIRE(p->n > p->bf + 2, ZG_ERR_INVALID_ARG, "zg_prover_create: too few rows");
-    p->usable = p->n - (p->bf + 1);
-    p->F = cs->n_fixed; p->A = cs->n_advice; p->I = cs->n_instance; p->P = cs->n_perm_columns; p->NL = cs->n_lookups;
-    p->chunk = cs->cs_degree - 2;
-    p->sets = p->P ? (p->P + p->chunk - 1) / p->chunk : 0;
-    p->advice_queries.assign(cs->advice_queries, cs->advice_queries + cs->n_advice_queries);
-    p->fixed_queries.assign(cs->fixed_queries, cs->fixed_queries + cs->n_fixed_queries);
-    p->vk_repr = to_fe(vk_repr);
-    p->omega = host_domain_omega(p->k);
-    p->omega_inv = Fr::inv(p->omega);
-    p->ifft_div = Fr::inv(Fr::from_u64(p->n));
-    const uint32_t n = p->n, en = p->en;
+    p->pk = std::make_shared<PkDev>();
+    PkDev* pk = p->pk.get();
+    pk->device = ctx->device;
+    pk->k = cs->k;
+    pk->n = 1u << cs->k;
+    pk->cs_degree = cs->cs_degree;
+    pk->bf = cs->blinding_factors;
+    pk->qpd = cs->cs_degree - 1;
+    pk->ext_k = cs->k;
+    while ((1ull << pk->ext_k) < (uint64_t)pk->n * pk->qpd) pk->ext_k++;
+    ZG_REQUIRE(pk->ext_k <= 22, ZG_ERR_UNSUPPORTED, "zg_prover_create: extended domain 2^%u not built", pk->ext_k);
+    pk->en = 1u << pk->ext_k;
+    ZG_REQUIRE(pk->n > pk->bf + 2, ZG_ERR_INVALID_ARG, "zg_prover_create: too few rows");
+    pk->usable = pk->n - (pk->bf + 1);
+    pk->F = cs->n_fixed; pk->A = cs->n_advice; pk->I = cs->n_instance; pk->P = cs->n_perm_columns; pk->NL = cs->n_lookups;
+    pk->chunk = cs->cs_degree - 2;
+    pk->sets = pk->P ? (pk->P + pk->chunk - 1) / pk->chunk : 0;
+    pk->advice_queries.assign(cs->advice_queries, cs->advice_queries + cs->n_advice_queries);
+    pk->fixed_queries.assign(cs->fixed_queries, cs->fixed_queries + cs->n_fixed_queries);
+    pk->vk_repr = to_fe(vk_repr);
+    pk->omega = host_domain_omega(pk->k);
+    pk->omega_inv = Fr::inv(pk->omega);
+    pk->ifft_div = Fr::inv(Fr::from_u64(pk->n));
+    const uint32_t n = pk->n, en = pk->en;
     hipStream_t st = ctx->stream;
-    ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
-    ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-    ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
-    if (const char* e = getenv("ZG_EVALH9")) p->hat = atoi(e) != 0;
+    ZG_TRY(prover_events(p));
+    if (const char* e = getenv("ZG_EVALH9")) pk->hat = atoi(e) != 0;
     if (p->use_side && !ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
+    auto dalloc = [&](auto** o, size_t count) { return dalloc_into(pk->owned, o, count); };
 
     // ---- validate and upload the circuit tables
     for (uint32_t q = 0; q < cs->n_queries; q++) {
         const zg_query& qq = cs->queries[q];
-        uint32_t lim = qq.kind == ZG_FIXED ? p->F : qq.kind == ZG_ADVICE ? p->A : qq.kind == ZG_INSTANCE ? p->I : 0;
+        uint32_t lim = qq.kind == ZG_FIXED ? pk->F : qq.kind == ZG_ADVICE ? pk->A : qq.kind == ZG_INSTANCE ? pk->I : 0;
         ZG_REQUIRE(qq.column < lim, ZG_ERR_INVALID_ARG, "zg_prover_create: query %u names column %u of kind %u", q,
                    qq.column, qq.kind);
     }
@@ -431,25 +574,29 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_REQUIRE(poly_ok(cs->gates[gi]), ZG_ERR_INVALID_ARG, "zg_prover_create: gate %u out of range", gi);
     for (uint32_t c = 0; c < cs->n_perm_columns; c++) {
         const zg_query& qq = cs->perm_columns[c];
-        uint32_t lim = qq.kind == ZG_FIXED ? p->F : qq.kind == ZG_ADVICE ? p->A : qq.kind == ZG_INSTANCE ? p->I : 0;
+        uint32_t lim = qq.kind == ZG_FIXED ? pk->F : qq.kind == ZG_ADVICE ? pk->A : qq.kind == ZG_INSTANCE ? pk->I : 0;
         ZG_REQUIRE(qq.column < lim, ZG_ERR_INVALID_ARG, "zg_prover_create: permutation column %u out of range", c);
     }
+    ZG_REQUIRE(cs->n_lookups <= 60, ZG_ERR_UNSUPPORTED, "zg_prover_create: %u lookups", cs->n_lookups);
     zg_query* d_q; DMono* d_m; zg_poly* d_g; DLookup* d_l; zg_query* d_pc;
-    ZG_TRY(dalloc(p, &d_q, cs->n_queries));
-    ZG_TRY(dalloc(p, &d_m, cs->n_monomials));
-    ZG_TRY(dalloc(p, &d_g, cs->n_gates));
-    ZG_TRY(dalloc(p, &d_l, cs->n_lookups));
-    ZG_TRY(dalloc(p, &d_pc, cs->n_perm_columns));
+    ZG_TRY(dalloc(&d_q, cs->n_queries));
+    ZG_TRY(dalloc(&d_m, cs->n_monomials));
+    ZG_TRY(dalloc(&d_g, cs->n_gates));
+    ZG_TRY(dalloc(&d_l, cs->n_lookups));
+    ZG_TRY(dalloc(&d_pc, cs->n_perm_columns));
     if (cs->n_queries) ZG_HIP(hipMemcpyAsync(d_q, cs->queries, cs->n_queries * sizeof(zg_query), hipMemcpyHostToDevice, st));
     if (cs->n_monomials) ZG_HIP(hipMemcpyAsync(d_m, monos.data(), monos.size() * sizeof(DMono), hipMemcpyHostToDevice, st));
     if (cs->n_gates) ZG_HIP(hipMemcpyAsync(d_g, cs->gates, cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice, st));
     if (cs->n_lookups) ZG_HIP(hipMemcpyAsync(d_l, lks.data(), lks.size() * sizeof(DLookup), hipMemcpyHostToDevice, st));
     if (cs->n_perm_columns) ZG_HIP(hipMemcpyAsync(d_pc, cs->perm_columns, cs->n_perm_columns * sizeof(zg_query), hipMemcpyHostToDevice, st));
     ZG_HIP(hipStreamSynchronize(st));  // the host vectors above go out of scope
-    p->dc.queries = d_q; p->dc.monos = d_m; p->dc.gates = d_g; p->dc.lookups = d_l; p->dc.perm_cols = d_pc;
-    p->dc.n_gates = cs->n_gates; p->dc.n_lookups = cs->n_lookups; p->dc.n_perm = p->P; p->dc.chunk = p->chunk;
-    p->dc.n_sets = p->sets;
-    if (p->hat) {  // evaluate_h's view: coefficients in the 2^261 form, gates factored by their common cell
+    pk->dc.queries = d_q; pk->dc.monos = d_m; pk->dc.gates = d_g; pk->dc.lookups = d_l; pk->dc.perm_cols = d_pc;
+    pk->dc.n_gates = cs->n_gates; pk->dc.n_lookups = cs->n_lookups; pk->dc.n_perm = pk->P; pk->dc.chunk = pk->chunk;
+    pk->dc.n_sets = pk->sets;
+    if (pk->hat) {  // evaluate_h's view: coefficients in the 2^261 form, gates factored by their common cell
+        // Invariant (a fault in round 1, gdb: evaluate_h9_kernel reading monos_hat[m].n_factors through a null table):
+        // hat implies that monos_hat, gates_hat, gate_common, gate_uni, uni_coef and gate_slab are ALL allocated here,
+        // whatever the circuit holds (no gates, no lookups); poly_evaluate_h refuses a launch without them.
         const Fe c261 = Fr9Params::c261_fe();
         for (auto& d : monos) d.coeff = Fr::mul(d.coeff, c261);
         std::vector<zg_poly> gates_hat(cs->n_gates);
@@ -483,30 +630,30 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
             if (!best.uc.empty()) {
                 gate_uni[gi].first = (uint32_t)uni_coef.size();
                 gate_uni[gi].count = (uint32_t)best.uc.size();
-                if (cs->queries[f].kind == ZG_FIXED) p->slab_jobs.push_back({gi, f, gate_uni[gi].first, gate_uni[gi].count});
+                if (cs->queries[f].kind == ZG_FIXED) pk->slab_jobs.push_back({gi, f, gate_uni[gi].first, gate_uni[gi].count});
                 uni_coef.insert(uni_coef.end(), best.uc.begin(), best.uc.end());
             }
             common[gi] = f;
         }
-        ZG_TRY(dalloc(p, &p->gate_uni, cs->n_gates ? cs->n_gates : 1));
-        ZG_TRY(dalloc(p, &p->uni_coef, uni_coef.size() ? uni_coef.size() : 1));
-        if (cs->n_gates) ZG_HIP(hipMemcpy(p->gate_uni, gate_uni.data(), cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice));
-        if (!uni_coef.empty()) ZG_HIP(hipMemcpy(p->uni_coef, uni_coef.data(), uni_coef.size() * sizeof(Fe), hipMemcpyHostToDevice));
-        ZG_TRY(dalloc(p, &p->monos_hat, monos.size() ? monos.size() : 1));
-        ZG_TRY(dalloc(p, &p->gates_hat, cs->n_gates ? cs->n_gates : 1));
-        ZG_TRY(dalloc(p, &p->gate_common, cs->n_gates ? cs->n_gates : 1));
-        if (!monos.empty()) ZG_HIP(hipMemcpy(p->monos_hat, monos.data(), monos.size() * sizeof(DMono), hipMemcpyHostToDevice));
+        ZG_TRY(dalloc(&pk->gate_uni, cs->n_gates ? cs->n_gates : 1));
+        ZG_TRY(dalloc(&pk->uni_coef, uni_coef.size() ? uni_coef.size() : 1));
+        if (cs->n_gates) ZG_HIP(hipMemcpy(pk->gate_uni, gate_uni.data(), cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice));
+        if (!uni_coef.empty()) ZG_HIP(hipMemcpy(pk->uni_coef, uni_coef.data(), uni_coef.size() * sizeof(Fe), hipMemcpyHostToDevice));
+        ZG_TRY(dalloc(&pk->monos_hat, monos.size() ? monos.size() : 1));
+        ZG_TRY(dalloc(&pk->gates_hat, cs->n_gates ? cs->n_gates : 1));
+        ZG_TRY(dalloc(&pk->gate_common, cs->n_gates ? cs->n_gates : 1));
+        if (!monos.empty()) ZG_HIP(hipMemcpy(pk->monos_hat, monos.data(), monos.size() * sizeof(DMono), hipMemcpyHostToDevice));
         if (cs->n_gates) {
-            ZG_HIP(hipMemcpy(p->gates_hat, gates_hat.data(), cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice));
-            ZG_HIP(hipMemcpy(p->gate_common, common.data(), cs->n_gates * sizeof(uint32_t), hipMemcpyHostToDevice));
+            ZG_HIP(hipMemcpy(pk->gates_hat, gates_hat.data(), cs->n_gates * sizeof(zg_poly), hipMemcpyHostToDevice));
+            ZG_HIP(hipMemcpy(pk->gate_common, common.data(), cs->n_gates * sizeof(uint32_t), hipMemcpyHostToDevice));
         }
     }
 
     // ---- SRS: upload + window tables, or tables shared with other provers on this device (read-only)
     if (shared_g) {
-        ZG_REQUIRE(shared_g->ctx->device == ctx->device && shared_gl->ctx->device == ctx->device, ZG_ERR_INVALID_ARG,
+        ZG_REQUIRE(shared_g->device == ctx->device && shared_gl->device == ctx->device, ZG_ERR_INVALID_ARG,
                    "zg_prover_create_shared: bases live on another device");
-        ZG_REQUIRE(shared_g->n == n && shared_gl->n == n && shared_g->c == shared_gl->c, ZG_ERR_INVALID_ARG,
+        ZG_REQUIRE(shared_g->n == shared_gl->n && shared_g->n <= n && shared_g->n >= 1 && shared_g->c == shared_gl->c, ZG_ERR_INVALID_ARG,
                    "zg_prover_create_shared: bases do not match 2^k = %u points", n);
         p->g = const_cast<zg_bases*>(shared_g);
         p->gl = const_cast<zg_bases*>(shared_gl);
@@ -520,120 +667,81 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_HIP(hipMemcpyAsync(d, g_lagrange, (size_t)n * sizeof(Affine), hipMemcpyHostToDevice, st));
         ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->gl));
     }
+    // (fewer points than 2^k: a point-range shard of the SRS; zg_prover_set_shard names the range before the first proof)
+    p->shard_lo = 0;
+    p->shard_n = (uint32_t)p->g->n;
     static const bool run_form = !(getenv("ZG_MSM_RUNS") && atoi(getenv("ZG_MSM_RUNS")) == 0);  // A/B knob
-    if (run_form && p->sets + p->NL > 0) ZG_TRY(bases_enable_runs(ctx, p->gl));
+    if (run_form && pk->sets + pk->NL > 0) ZG_TRY(bases_enable_runs(ctx, p->gl));
 
-    // ---- slabs
-    const uint32_t F = p->F, A = p->A, I = p->I, P = p->P, NL = p->NL, S = p->sets, Q = p->qpd;
-    p->ix_fixed = 0; p->ix_sigma = F; p->ix_adv = F + P; p->ix_inst = p->ix_adv + A; p->ix_pz = p->ix_inst + I;
-    p->ix_lz = p->ix_pz + S; p->ix_perm = p->ix_lz + NL; p->ix_random = p->ix_perm + 2 * NL;
-    p->ix_hpiece = p->ix_random + 1; p->ix_hpoly = p->ix_hpiece + Q;
-    p->n_polys = p->ix_hpoly + 1;
-    ZG_TRY(dalloc(p, &p->polys, (size_t)p->n_polys * n));
-    ZG_TRY(dalloc(p, &p->fixed_val, (size_t)F * n));
-    ZG_TRY(dalloc(p, &p->sigma_val, (size_t)P * n));
+    // ---- proving-key slabs
+    const uint32_t F = pk->F, P = pk->P, Q = pk->qpd;
+    ZG_TRY(dalloc(&pk->sh_polys, (size_t)(F + P) * n));
+    ZG_TRY(dalloc(&pk->fixed_val, (size_t)F * n));
+    ZG_TRY(dalloc(&pk->sigma_val, (size_t)P * n));
     // parts of the extended domain
     {
         static const bool split_env = !(getenv("ZG_SPLIT_DOMAIN") && atoi(getenv("ZG_SPLIT_DOMAIN")) == 0);  // A/B knob
         uint32_t m1 = 1;
         while (m1 * 2 <= Q) m1 *= 2;
         const uint32_t m2 = Q - m1;
-        const bool split = split_env && p->hat && m2 != 0 && (m2 & (m2 - 1)) == 0 && (m1 + m2) * n < en;
+        const bool split = split_env && pk->hat && m2 != 0 && (m2 & (m2 - 1)) == 0 && (m1 + m2) * n < en;
         auto log2u = [](uint32_t v) { uint32_t l = 0; while ((1u << l) < v) l++; return l; };
         // The single coset serves the latency configuration (a lone proof pays for the extra launches of the split
         // form in its h phase: 0.72 -> 0.93 ms), the split one the throughput configuration (-5 % ms/proof); both sets
-        // of proving-key cosets are kept (+60 % of 0.2 GB per prover) and zg_prover_set_overlap picks.
-        p->nparts = 1;
-        p->dom[0].ek = p->ext_k; p->dom[0].en = en; p->dom[0].zpow = 1;
+        // of proving-key cosets are kept (+60 % of 0.2 GB per key) and zg_prover_set_overlap picks.
+        pk->nparts = 1;
+        pk->dom[0].ek = pk->ext_k; pk->dom[0].en = en; pk->dom[0].zpow = 1;
         if (split) {
-            p->nparts = 3;
-            p->dom[1].ek = p->k + log2u(m1); p->dom[1].en = n * m1; p->dom[1].zpow = 1;
-            p->dom[2].ek = p->k + log2u(m2); p->dom[2].en = n * m2; p->dom[2].zpow = 2;
-            ZG_TRY(dalloc(p, &p->split_tmp, (size_t)3 * p->dom[2].en));
+            pk->nparts = 3;
+            pk->dom[1].ek = pk->k + log2u(m1); pk->dom[1].en = n * m1; pk->dom[1].zpow = 1;
+            pk->dom[2].ek = pk->k + log2u(m2); pk->dom[2].en = n * m2; pk->dom[2].zpow = 2;
         }
     }
-    for (uint32_t di = 0; di < p->nparts; di++) {
-        zg_prover::Dom& d = p->dom[di];
-        ZG_TRY(dalloc(p, &d.fixed_cos, (size_t)F * d.en));
-        ZG_TRY(dalloc(p, &d.sigma_cos, (size_t)P * d.en));
-        ZG_TRY(dalloc(p, &d.l0, (size_t)d.en));
-        ZG_TRY(dalloc(p, &d.llast, (size_t)d.en));
-        ZG_TRY(dalloc(p, &d.lactive, (size_t)d.en));
-        // (one block, in the order of the coefficient slab: advice, instance, permutation z, lookup z, a'/s' -- the
-        //  split form transforms all of them in one batch)
-        ZG_TRY(dalloc(p, &d.adv_cos, (size_t)(A + I + S + NL + 2 * NL) * d.en));
-        d.inst_cos = d.adv_cos + (size_t)A * d.en;
-        d.pz_cos = d.inst_cos + (size_t)I * d.en;
-        d.lz_cos = d.pz_cos + (size_t)S * d.en;
-        d.perm_cos = d.lz_cos + (size_t)NL * d.en;
-        ZG_TRY(dalloc(p, &d.h, (size_t)d.en));
+    for (uint32_t di = 0; di < pk->nparts; di++) {
+        PkDev::Dom& d = pk->dom[di];
+        ZG_TRY(dalloc(&d.fixed_cos, (size_t)F * d.en));
+        ZG_TRY(dalloc(&d.sigma_cos, (size_t)P * d.en));
+        ZG_TRY(dalloc(&d.l0, (size_t)d.en));
+        ZG_TRY(dalloc(&d.llast, (size_t)d.en));
+        ZG_TRY(dalloc(&d.lactive, (size_t)d.en));
     }
-    ZG_TRY(dalloc(p, &p->adv_val, (size_t)A * n));
-    ZG_TRY(dalloc(p, &p->inst_val, (size_t)I * n));
-    if (I) ZG_HIP(hipMemset(p->inst_val, 0, (size_t)I * n * 32));  // rows past the instance stay zero (prove refills only what it must)
-    ZG_TRY(dalloc(p, &p->pin_c, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->ptab_c, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->cin, (size_t)2 * NL * n));  // compressed inputs, then compressed tables
-    p->ctab = p->cin + (size_t)NL * n;
-    ZG_TRY(dalloc(p, &p->perm, (size_t)(2 * NL + 1) * n));  // + the vanishing argument's random polynomial
-    ZG_TRY(dalloc(p, &p->zs, (size_t)(S + NL + 1) * n));
-    const uint32_t mb = S + NL;
-    ZG_TRY(dalloc(p, &p->num, (size_t)mb * n));
-    ZG_TRY(dalloc(p, &p->den, (size_t)mb * n));
-    ZG_TRY(dalloc(p, &p->tmp, poly_grand_product_tmp_elems(n, mb)));
-    ZG_TRY(dalloc(p, &p->raw, (size_t)2 * NL * n));
-    ZG_TRY(dalloc(p, &p->sraw, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->sort_fe, (size_t)NL * n));
-    ZG_TRY(dalloc(p, &p->sort_u32, (size_t)2 * NL * n + 3 * NL + 2));
-    p->d_err = p->sort_u32 + (size_t)2 * NL * n + 2 * NL;  // behind permute_pairs' scratch: zeroed by the same fill
-    ZG_REQUIRE(NL <= 60, ZG_ERR_UNSUPPORTED, "zg_prover_create: %u lookups", NL);
-    const uint32_t max_points = 4 + (uint32_t)(p->advice_queries.size() + p->fixed_queries.size());
-    ZG_TRY(dalloc(p, &p->pw, (size_t)max_points * n + max_points));
-    const uint32_t max_evals = (uint32_t)(p->advice_queries.size() + p->fixed_queries.size()) + P + 3 * S + 5 * NL + 4;
-    ZG_TRY(dalloc(p, &p->evals, max_evals));
-    ZG_TRY(dalloc(p, &p->wpoly, (size_t)2 * max_points * n));
-    ZG_TRY(dalloc(p, &p->xyzz, std::max<size_t>(std::max<size_t>(A, 2 * NL + 1), std::max<size_t>(S + NL + 1, std::max<size_t>(Q, max_points)))));
-    ZG_TRY(dalloc(p, &p->d_idx, (size_t)4 * max_evals + 64 + (size_t)max_points * 512));
-    ZG_TRY(dalloc(p, &p->ktmp, poly_kate_tmp_elems(n, max_points)));
-    p->pinned_cap = 1u << 20;  // commitments (128 B each), evaluations, error flags
-    ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocDefault));
 
     // ---- keygen_pk's derived data: fixed / sigma polys + cosets, l_0 / l_last / l_active_row
     if (F) {
-        ZG_HIP(hipMemcpyAsync(p->fixed_val, fixed_values, (size_t)F * n * 32, hipMemcpyHostToDevice, st));
-        Fe* fp = p->polys + (size_t)p->ix_fixed * n;
-        ZG_TRY(ntt_batch_to_dev(ctx, p->fixed_val, fp, n, F, p->k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = 0; di < p->nparts; di++) {
-            zg_prover::Dom& d = p->dom[di];
-            ZG_TRY(coeff_to_coset_dev(ctx, fp, n, n, d.fixed_cos, d.en, F, d.ek, p->hat, d.zpow));
+        ZG_HIP(hipMemcpyAsync(pk->fixed_val, fixed_values, (size_t)F * n * 32, hipMemcpyHostToDevice, st));
+        Fe* fp = pk->sh_polys;
+        ZG_TRY(ntt_batch_to_dev(ctx, pk->fixed_val, fp, n, F, pk->k, pk->omega_inv, &pk->ifft_div));
+        for (uint32_t di = 0; di < pk->nparts; di++) {
+            PkDev::Dom& d = pk->dom[di];
+            ZG_TRY(coeff_to_coset_dev(ctx, fp, n, n, d.fixed_cos, d.en, F, d.ek, pk->hat, d.zpow));
         }
     }
-    if (p->hat) {
+    if (pk->hat) {
         // a gate factor that is a polynomial in a FIXED cell (a merged selector) does not depend on the
         // witness: its coset is part of the proving key here, as the unmerged selector's would have been
         std::vector<uint32_t> slab_of(cs->n_gates ? cs->n_gates : 1, 0xffffffffu);
-        ZG_TRY(dalloc(p, &p->gate_slab, slab_of.size()));
-        for (uint32_t di = 0; di < p->nparts; di++) {
-            zg_prover::Dom& d = p->dom[di];
-            ZG_TRY(dalloc(p, &d.gate_slabs, std::max<size_t>(1, p->slab_jobs.size() * (size_t)d.en)));
-            for (size_t j = 0; j < p->slab_jobs.size(); j++) {
-                const auto& job = p->slab_jobs[j];
+        ZG_TRY(dalloc(&pk->gate_slab, slab_of.size()));
+        for (uint32_t di = 0; di < pk->nparts; di++) {
+            PkDev::Dom& d = pk->dom[di];
+            ZG_TRY(dalloc(&d.gate_slabs, std::max<size_t>(1, pk->slab_jobs.size() * (size_t)d.en)));
+            for (size_t j = 0; j < pk->slab_jobs.size(); j++) {
+                const auto& job = pk->slab_jobs[j];
                 const zg_query q = cs->queries[job.query];
                 ZG_TRY(poly_gate_factor(ctx, d.fixed_cos + (size_t)q.column * d.en, (uint32_t)(q.rotation * (int32_t)(d.en / n)),
-                                        d.en, p->uni_coef + job.first, job.count, d.gate_slabs + j * (size_t)d.en));
+                                        d.en, pk->uni_coef + job.first, job.count, d.gate_slabs + j * (size_t)d.en));
                 slab_of[job.gate] = (uint32_t)j;
             }
         }
-        ZG_HIP(hipMemcpyAsync(p->gate_slab, slab_of.data(), slab_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        ZG_HIP(hipMemcpyAsync(pk->gate_slab, slab_of.data(), slab_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         ZG_HIP(hipStreamSynchronize(st));
     }
     if (P) {
-        ZG_HIP(hipMemcpyAsync(p->sigma_val, sigma_values, (size_t)P * n * 32, hipMemcpyHostToDevice, st));
-        Fe* sp = p->polys + (size_t)p->ix_sigma * n;
-        ZG_TRY(ntt_batch_to_dev(ctx, p->sigma_val, sp, n, P, p->k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = 0; di < p->nparts; di++) {
-            zg_prover::Dom& d = p->dom[di];
-            ZG_TRY(coeff_to_coset_dev(ctx, sp, n, n, d.sigma_cos, d.en, P, d.ek, p->hat, d.zpow));
+        ZG_HIP(hipMemcpyAsync(pk->sigma_val, sigma_values, (size_t)P * n * 32, hipMemcpyHostToDevice, st));
+        Fe* sp = pk->sh_polys + (size_t)F * n;
+        ZG_TRY(ntt_batch_to_dev(ctx, pk->sigma_val, sp, n, P, pk->k, pk->omega_inv, &pk->ifft_div));
+        for (uint32_t di = 0; di < pk->nparts; di++) {
+            PkDev::Dom& d = pk->dom[di];
+            ZG_TRY(coeff_to_coset_dev(ctx, sp, n, n, d.sigma_cos, d.en, P, d.ek, pk->hat, d.zpow));
         }
     }
     {
@@ -641,60 +749,134 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         Fe* t3 = ws.get<Fe>((size_t)3 * n);
         Fe* lblind = ws.get<Fe>(en);
         if (ws.failed) return ZG_ERR_OOM;
-        ZG_TRY(poly_l_cosets_init(ctx, t3, t3 + n, t3 + 2 * n, n, p->bf));
-        ZG_TRY(ntt_batch_dev(ctx, t3, n, 3, p->k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = 0; di < p->nparts; di++) {
-            zg_prover::Dom& d = p->dom[di];
-            ZG_TRY(coeff_to_coset_dev(ctx, t3, n, n, d.l0, d.en, 1, d.ek, p->hat, d.zpow));
-            ZG_TRY(coeff_to_coset_dev(ctx, t3 + n, n, n, d.llast, d.en, 1, d.ek, p->hat, d.zpow));
-            ZG_TRY(coeff_to_coset_dev(ctx, t3 + 2 * n, n, n, lblind, d.en, 1, d.ek, p->hat, d.zpow));
-            ZG_TRY(poly_lactive(ctx, d.lactive, d.llast, lblind, d.en, p->hat));
+        ZG_TRY(poly_l_cosets_init(ctx, t3, t3 + n, t3 + 2 * n, n, pk->bf));
+        ZG_TRY(ntt_batch_dev(ctx, t3, n, 3, pk->k, pk->omega_inv, &pk->ifft_div));
+        for (uint32_t di = 0; di < pk->nparts; di++) {
+            PkDev::Dom& d = pk->dom[di];
+            ZG_TRY(coeff_to_coset_dev(ctx, t3, n, n, d.l0, d.en, 1, d.ek, pk->hat, d.zpow));
+            ZG_TRY(coeff_to_coset_dev(ctx, t3 + n, n, n, d.llast, d.en, 1, d.ek, pk->hat, d.zpow));
+            ZG_TRY(coeff_to_coset_dev(ctx, t3 + 2 * n, n, n, lblind, d.en, 1, d.ek, pk->hat, d.zpow));
+            ZG_TRY(poly_lactive(ctx, d.lactive, d.llast, lblind, d.en, pk->hat));
         }
         ZG_HIP(hipStreamSynchronize(st));
     }
     // t_evaluations of EvaluationDomain: ((shift * ext_omega^i)^n - 1)^-1, one period, per part of the domain
-    ZG_TRY(get_twiddles(ctx, p->k, p->omega, &p->omega_tw));
-    for (uint32_t di = 0; di < p->nparts; di++) {
-        zg_prover::Dom& d = p->dom[di];
-        uint32_t t_len = 1u << (d.ek - p->k);
+    ZG_TRY(get_twiddles(ctx, pk->k, pk->omega, &pk->omega_tw));
+    for (uint32_t di = 0; di < pk->nparts; di++) {
+        PkDev::Dom& d = pk->dom[di];
+        uint32_t t_len = 1u << (d.ek - pk->k);
         std::vector<Fe> te(t_len);
         Fe ext_omega = host_domain_omega(d.ek);
         const Fe shift = d.zpow == 1 ? fr_zeta() : Fr::sqr(fr_zeta());
         Fe cur = Fr::pow_u64(shift, n), step = Fr::pow_u64(ext_omega, n);
         for (uint32_t i = 0; i < t_len; i++) {
             te[i] = Fr::inv(Fr::sub(cur, Fr::one()));
-            if (p->hat) te[i] = Fr::mul(te[i], Fr9Params::c261_fe());
+            if (pk->hat) te[i] = Fr::mul(te[i], Fr9Params::c261_fe());
             cur = Fr::mul(cur, step);
         }
-        ZG_TRY(dalloc(p, &d.t_eval, t_len));
+        ZG_TRY(dalloc(&d.t_eval, t_len));
         ZG_HIP(hipMemcpy(d.t_eval, te.data(), t_len * sizeof(Fe), hipMemcpyHostToDevice));
         ZG_TRY(get_twiddles(ctx, d.ek, ext_omega, &d.ext_tw));
     }
     ZG_HIP(hipStreamSynchronize(st));
+    ZG_TRY(alloc_slots(p, 1));
     *out = guard.release();
     return ZG_OK;
 }
 
-int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, size_t instance_len, uint64_t seed,
-                        uint8_t* proof, size_t proof_cap, size_t* proof_len) {
-    ZG_REQUIRE(p && proof && proof_len && (d_advice || p->A == 0), ZG_ERR_INVALID_ARG, "zg_prover_prove: null argument");
-    ZG_REQUIRE(p->I == 0 || instance || instance_len == 0, ZG_ERR_INVALID_ARG, "zg_prover_prove: instance is null");
-    ZG_REQUIRE(instance_len <= p->usable, ZG_ERR_INVALID_ARG, "zg_prover_prove: instance too large (Error::InstanceTooLarge)");
+int zg_prover_set_batch(zg_prover* p, size_t max_batch) {
+    ZG_REQUIRE(p, ZG_ERR_INVALID_ARG, "zg_prover_set_batch: null prover");
+    ZG_ENTER(p->ctx);
+    ZG_HIP(hipStreamSynchronize(p->ctx->stream));
+    if (p->ctx->side) ZG_HIP(hipStreamSynchronize(p->ctx->side->stream));
+    if (max_batch == p->cap) return ZG_OK;
+    ZG_REQUIRE(max_batch >= 1 && max_batch <= 1024, ZG_ERR_INVALID_ARG, "zg_prover_set_batch: %zu proofs", max_batch);
+    p->have_last = false;
+    return alloc_slots(p, (uint32_t)max_batch);
+}
+
+size_t zg_prover_batch(const zg_prover* p) { return p ? p->cap : 0; }
+
+void* zg_prover_advice_slot(zg_prover* p, size_t slot) {
+    if (!p || slot >= p->cap) return nullptr;
+    return p->adv_val + slot * (size_t)p->pk->A * p->pk->n;
+}
+
+int zg_prover_fork(const zg_prover* parent, zg_ctx* ctx, zg_prover** out) {
+    ZG_REQUIRE(parent && ctx && out, ZG_ERR_INVALID_ARG, "zg_prover_fork: null argument");
+    ZG_REQUIRE(ctx->device == parent->pk->device, ZG_ERR_INVALID_ARG, "zg_prover_fork: the context is on another device");
+    ZG_ENTER(ctx);
+    std::unique_ptr<zg_prover, void (*)(zg_prover*)> guard(new zg_prover(), zg_prover_destroy);
+    zg_prover* p = guard.get();
+    p->ctx = ctx;
+    p->pk = parent->pk;
+    p->g = parent->g;
+    p->gl = parent->gl;
+    p->own_bases = false;  // (the parent, or whoever registered them, keeps the tables alive)
+    p->use_side = parent->use_side;
+    p->shard_lo = parent->shard_lo; p->shard_n = parent->shard_n; p->world = parent->world; p->rank = parent->rank;
+    p->exchange = parent->exchange; p->exchange_user = parent->exchange_user;
+    ZG_TRY(prover_events(p));
+    if (p->use_side && !ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
+    ZG_TRY(alloc_slots(p, parent->cap ? parent->cap : 1));
+    *out = guard.release();
+    return ZG_OK;
+}
+
+int zg_prover_set_shard(zg_prover* p, uint32_t rank, uint32_t world, size_t first_point, zg_exchange_fn fn, void* user) {
+    ZG_REQUIRE(p, ZG_ERR_INVALID_ARG, "zg_prover_set_shard: null prover");
+    ZG_ENTER(p->ctx);
+    ZG_REQUIRE(world >= 1 && rank < world, ZG_ERR_INVALID_ARG, "zg_prover_set_shard: rank %u of %u", rank, world);
+    ZG_REQUIRE(world == 1 || fn != nullptr, ZG_ERR_INVALID_ARG, "zg_prover_set_shard: no exchange function");
+    ZG_REQUIRE(first_point + p->g->n <= p->pk->n, ZG_ERR_INVALID_ARG, "zg_prover_set_shard: points [%zu, %zu) of %u", first_point,
+               first_point + p->g->n, p->pk->n);
+    ZG_REQUIRE(world > 1 || p->g->n == p->pk->n, ZG_ERR_INVALID_ARG, "zg_prover_set_shard: a lone prover needs all 2^k points");
+    p->rank = rank;
+    p->world = world;
+    p->shard_lo = (uint32_t)first_point;
+    p->shard_n = (uint32_t)p->g->n;
+    p->exchange = fn;
+    p->exchange_user = user;
+    return ZG_OK;
+}
+
+// create_proof for `nb` circuit instances in lock step: every kernel launch below serves all nb proofs (grid rows /
+// vector groups per proof, scalars from d_pc[b]); the host keeps one transcript per proof and hands each its own
+// challenges.  nb = 1 is the single-proof path (zg_prover_prove / _dev): there is no other.
+// advice_host / advice_dev: per proof, one of them may be given (host columns are uploaded, foreign device columns
+// copied into the proof's slot); both null = the slot already holds the columns (zg_prover_advice_slot).
+static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advice_host, void* const* advice_dev,
+                            const zg_fr* const* instance, size_t instance_len, const uint8_t* keys /* [count][32] */,
+                            uint8_t* const* proofs, size_t proof_cap, size_t* proof_lens, int* statuses) {
+    ZG_REQUIRE(p && proofs && proof_lens && keys, ZG_ERR_INVALID_ARG, "zg_prover_prove: null argument");
+    const PkDev& pk = *p->pk;
+    ZG_REQUIRE(count >= 1 && count <= p->cap, ZG_ERR_INVALID_ARG, "zg_prover_prove: %zu proofs for %u slots (zg_prover_set_batch)",
+               count, p->cap);
+    ZG_REQUIRE(pk.I == 0 || instance || instance_len == 0, ZG_ERR_INVALID_ARG, "zg_prover_prove: instance is null");
+    ZG_REQUIRE(instance_len <= pk.usable, ZG_ERR_INVALID_ARG, "zg_prover_prove: instance too large (Error::InstanceTooLarge)");
+    ZG_REQUIRE(p->world > 1 || p->shard_n == pk.n, ZG_ERR_INVALID_ARG,
+               "zg_prover_prove: the base sets hold %u of %u points and no shard was declared (zg_prover_set_shard)", p->shard_n, pk.n);
     zg_ctx* ctx = p->ctx;
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     hipStream_t st = ctx->stream;
-    const uint32_t n = p->n, k = p->k, ek = p->ext_k, bf = p->bf, usable = p->usable;
-    const uint32_t F = p->F, A = p->A, I = p->I, P = p->P, NL = p->NL, S = p->sets, Q = p->qpd;
-    (void)F;
+    const uint32_t nb = (uint32_t)count;
+    const uint32_t n = pk.n, k = pk.k, ek = pk.ext_k, bf = pk.bf, usable = pk.usable;
+    const uint32_t A = pk.A, I = pk.I, P = pk.P, NL = pk.NL, S = pk.sets, Q = pk.qpd;
+    const bool hat = pk.hat;
     // extended-domain parts of this proof: the split pair in the throughput configuration, the single coset otherwise
-    const bool split = p->nparts == 3 && !p->use_side;
+    const bool split = pk.nparts == 3 && !p->use_side;
     const uint32_t dlo = split ? 1u : 0u, dhi = split ? 3u : 1u;
-    Fe* polys = p->polys;
-    auto poly_at = [&](uint32_t ix) { return polys + (size_t)ix * n; };
-    EvmTranscript tr;
+    // strides between consecutive proofs
+    const size_t pp_bs = (size_t)p->npp * n, adv_bs = (size_t)A * n, inst_bs = (size_t)I * n, perm_bs = (size_t)(2 * NL + 1) * n,
+                 zs_bs = (size_t)(S + NL + 1) * n, pw_bs = (size_t)p->max_points * n, wp_bs = (size_t)2 * p->max_points * n;
+    auto pp_at = [&](uint32_t ix) { return p->pp + (size_t)(ix - p->nsh) * n; };  // proof 0's polynomial ix (>= nsh)
+    PolySet polys;
+    polys.sh = pk.sh_polys; polys.pp = p->pp; polys.nsh = p->nsh; polys.n = n; polys.pp_bs = pp_bs;
+    std::vector<EvmTranscript> tr(nb);
+    std::vector<int> status(nb, ZG_OK);
     std::vector<Jac> pts;
     p->have_last = false;
-    p->stage_off = PIN_STAGE;
+    p->stage_off = p->pin_stage;
     using clk = std::chrono::steady_clock;
     auto t_start = clk::now(), t_prev = t_start;
     auto lap = [&](int slot) {
@@ -721,208 +903,268 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
         ZG_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
         return ZG_OK;
     };
+    // two-level layouts of the transforms: `per` arrays per proof
+    auto grouping = [](uint32_t per, size_t in_outer, size_t out_outer) {
+        Grouping g;
+        g.per = per; g.in_outer = in_outer; g.out_outer = out_outer;
+        return g;
+    };
+    // coefficient forms (ix0 .. ix0 + per) of every proof -> their slabs on each part of the extended domain
+    auto to_cosets = [&](zg_ctx* c, uint32_t ix0, uint32_t per) -> int {
+        for (uint32_t di = dlo; di < dhi; di++) {
+            const PkDev::Dom& d = pk.dom[di];
+            const Grouping g = grouping(per, pp_bs, (size_t)p->ncos * d.en);
+            ZG_TRY(coeff_to_coset_dev(c, pp_at(ix0), n, n, p->dbuf[di].cos + (size_t)(ix0 - p->ix_adv) * d.en, d.en, (size_t)nb * per,
+                                      d.ek, hat, d.zpow, &g));
+        }
+        return ZG_OK;
+    };
 
-    // ---- vk + instance values into the transcript; instance polynomial
-    tr.common_scalar(p->vk_repr);
+    // ---- advice columns into their slots
+    for (uint32_t b = 0; b < nb; b++) {
+        Fe* slot = p->adv_val + b * adv_bs;
+        if (!A) break;
+        if (advice_host && advice_host[b]) {
+            ZG_HIP(hipMemcpyAsync(slot, advice_host[b], adv_bs * 32, hipMemcpyHostToDevice, st));
+        } else if (advice_dev && advice_dev[b] && advice_dev[b] != (void*)slot) {
+            ZG_HIP(hipMemcpyAsync(slot, advice_dev[b], adv_bs * 32, hipMemcpyDeviceToDevice, st));
+        }
+    }
+
+    // ---- vk + instance values into the transcripts; instance polynomials
+    for (uint32_t b = 0; b < nb; b++) {
+        memset(&p->hpc[b], 0, sizeof(ProofConst));
+        memcpy(p->hpc[b].key, keys + 32 * (size_t)b, 32);
+        tr[b].common_scalar(pk.vk_repr);
+    }
+    ZG_TRY(upload_consts(p, nb));
     // vanishing::Argument::commit's random polynomial depends on no challenge: generate it now and
     // commit it inside the permuted-lookup batch (coefficient basis `g` next to `g_lagrange` vectors)
-    Fe* random_row = p->perm + (size_t)(2 * NL) * n;
+    Fe* random_row = p->perm + (size_t)(2 * NL) * n;  // (proof 0's; proof b's is perm_bs further)
     // (the same launch draws the blinding rows of the advice columns: commit_lagrange's input below)
-    Fe* adv = reinterpret_cast<Fe*>(d_advice);
-    ZG_TRY(poly_random_and_blind(ctx, random_row, poly_at(p->ix_random), n, seed, TAG_RANDOM_POLY, adv, n, A, usable, bf + 1,
-                                 TAG_ADVICE_BLIND));
+    Fe* adv = p->adv_val;
+    ZG_TRY(poly_random_and_blind(ctx, p->d_pc, nb, random_row, perm_bs, pp_at(p->ix_random), pp_bs, n, TAG_RANDOM_POLY, adv, adv_bs,
+                                 n, A, usable, bf + 1, TAG_ADVICE_BLIND));
     if (I) {
-        if (p->inst_filled > instance_len) ZG_HIP(hipMemsetAsync(p->inst_val, 0, (size_t)I * n * 32, st));  // (zeroed at create)
-        p->inst_filled = instance_len;
-        for (uint32_t c = 0; c < I; c++) {
-            for (size_t i = 0; i < instance_len; i++) tr.common_scalar(to_fe(&instance[c * instance_len + i]));
-            if (instance_len)
-                ZG_TRY(h2d(p, p->inst_val + (size_t)c * n, instance + c * instance_len, instance_len * 32));
+        for (uint32_t b = 0; b < nb; b++) {
+            Fe* iv = p->inst_val + b * inst_bs;
+            if (p->inst_filled[b] > instance_len) ZG_HIP(hipMemsetAsync(iv, 0, inst_bs * 32, st));  // (zeroed at create)
+            p->inst_filled[b] = instance_len;
+            for (uint32_t c = 0; c < I; c++) {
+                const zg_fr* src = instance_len ? instance[b] + (size_t)c * instance_len : nullptr;
+                for (size_t i = 0; i < instance_len; i++) tr[b].common_scalar(to_fe(&src[i]));
+                if (instance_len) ZG_TRY(h2d(p, iv + (size_t)c * n, src, instance_len * 32));
+            }
         }
     }
 
     // ---- advice: commit (Lagrange basis)
     ZG_TRY(fork());
     if (I) {
-        ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, poly_at(p->ix_inst), n, I, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi && !split; di++)
-            ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_inst), n, n, p->dom[di].inst_cos, p->dom[di].en, I, p->dom[di].ek, p->hat, p->dom[di].zpow));
+        const Grouping g = grouping(I, inst_bs, pp_bs);
+        ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, pp_at(p->ix_inst), n, (size_t)nb * I, k, pk.omega_inv, &pk.ifft_div, &g));
+        if (!split) ZG_TRY(to_cosets(sx, p->ix_inst, I));
     }
     if (A) {
-        ZG_TRY(msm_batch_dev(ctx, p->gl, adv, n, A, n, p->xyzz));
-        ZG_TRY(fetch_points(p, A, pts));
-        ZG_TRY(ntt_batch_to_dev(sx, adv, poly_at(p->ix_adv), n, A, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi && !split; di++)
-            ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_adv), n, n, p->dom[di].adv_cos, p->dom[di].en, A, p->dom[di].ek, p->hat, p->dom[di].zpow));
-        ZG_TRY(wait_points(p, A, pts));
-        for (auto& q : pts) tr.write_point(q);
+        ZG_TRY(commit(p, p->gl, nullptr, A, adv, n, A, adv_bs, (size_t)nb * A, 0));
+        const Grouping g = grouping(A, adv_bs, pp_bs);
+        ZG_TRY(ntt_batch_to_dev(sx, adv, pp_at(p->ix_adv), n, (size_t)nb * A, k, pk.omega_inv, &pk.ifft_div, &g));
+        if (!split) ZG_TRY(to_cosets(sx, p->ix_adv, A));
+        ZG_TRY(wait_points(p, (size_t)nb * A, pts));
+        for (uint32_t b = 0; b < nb; b++)
+            for (uint32_t c = 0; c < A; c++) tr[b].write_point(pts[(size_t)b * A + c]);
     }
-    const Fe theta = tr.squeeze();
+    for (uint32_t b = 0; b < nb; b++) p->hpc[b].theta = tr[b].squeeze();
+    ZG_TRY(upload_consts(p, nb));
     lap(0);
 
     Cols base_cols;
-    base_cols.fixed = p->fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
+    base_cols.fixed = pk.fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
     base_cols.log_size = k; base_cols.rot_scale = 1;
+    base_cols.adv_bs = adv_bs; base_cols.inst_bs = inst_bs;
 
     // ---- lookups: commit_permuted (+ the random polynomial's commitment)
-    Jac random_commit;
+    std::vector<Jac> random_commit(nb);
     bool have_random = false;
     if (NL) {
         // permute_expression_pair on the device: canonical keys (written by the compression kernel itself, with
         // the sentinel padding), bitonic sort of inputs and tables, scan-based construction of s' (sort.hip).
-        // raw rows [0,NL) = inputs -> a', [NL,2NL) = tables.
-        ZG_TRY(poly_lookup_compress(ctx, p->dc, base_cols, theta, p->cin, p->ctab, n, p->raw, p->raw + (size_t)NL * n, usable));
+        // raw rows [0, m) = inputs -> a', [m, 2m) = tables, m = nb * NL, row b * NL + l = lookup l of proof b.
+        const uint32_t m = nb * NL;
+        Fe *raw_in = p->raw, *raw_tab = p->raw + (size_t)m * n;
+        uint32_t* d_err = p->sort_u32 + (size_t)2 * m * n + 2 * m;  // behind permute_pairs' scratch: zeroed by the same fill
+        ZG_TRY(poly_lookup_compress(ctx, pk.dc, base_cols, p->d_pc, nb, p->cin, p->ctab, n, raw_in, raw_tab, usable));
         auto t_sort = clk::now();
-        ZG_TRY(poly_sort_keys(ctx, p->raw, n, 2 * NL));
-        ZG_TRY(poly_permute_pairs(ctx, p->raw, p->raw + (size_t)NL * n, p->sraw, n, usable, NL, p->sort_u32, p->sort_fe,
-                                  p->d_err));
+        ZG_TRY(poly_sort_keys(ctx, p->raw, n, 2 * m));
+        ZG_TRY(poly_permute_pairs(ctx, raw_in, raw_tab, p->sraw, n, usable, m, p->sort_u32, p->sort_fe, d_err));
         // perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form) on the usable rows, then the blinding tail
         // (blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j)
-        ZG_TRY(poly_permuted_finish(ctx, p->raw, p->sraw, p->perm, n, usable, bf + 1, NL, seed, TAG_PERMUTED_INPUT,
+        ZG_TRY(poly_permuted_finish(ctx, p->d_pc, nb, raw_in, p->sraw, p->perm, perm_bs, n, usable, bf + 1, NL, TAG_PERMUTED_INPUT,
                                     TAG_PERMUTED_TABLE));
         p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
         ZG_TRY(fork());
         // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
         const uint64_t sorted_runs = p->gl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
-        ZG_TRY(msm_batch3_dev(ctx, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, n, p->xyzz, sorted_runs));
-        uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pinned_cap - 256);
-        ZG_HIP(hipMemcpyAsync(h_err, p->d_err, NL * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        ZG_TRY(fetch_points(p, 2 * NL + 1, pts));
-        ZG_TRY(ntt_batch_to_dev(sx, p->perm, poly_at(p->ix_perm), n, 2 * NL, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi && !split; di++)
-            ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_perm), n, n, p->dom[di].perm_cos, p->dom[di].en, 2 * NL, p->dom[di].ek, p->hat, p->dom[di].zpow));
-        ZG_TRY(wait_points(p, 2 * NL + 1, pts));
-        for (uint32_t l = 0; l < NL; l++)
-            if (h_err[l]) {
-                set_error("zg_prover_prove: lookup %u has an input outside its table (ConstraintSystemFailure)", l);
-                (void)hipStreamSynchronize(ss);
-                return ZG_ERR_CONSTRAINT;
-            }
-        for (uint32_t i = 0; i < 2 * NL; i++) tr.write_point(pts[i]);
-        random_commit = pts[2 * NL];
+        ZG_TRY(commit(p, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs));
+        uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
+        ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        ZG_HIP(hipEventRecord(p->ev, st));  // (wait_points waits for the error words too)
+        {
+            const Grouping g = grouping(2 * NL, perm_bs, pp_bs);
+            ZG_TRY(ntt_batch_to_dev(sx, p->perm, pp_at(p->ix_perm), n, (size_t)nb * 2 * NL, k, pk.omega_inv, &pk.ifft_div, &g));
+        }
+        if (!split) ZG_TRY(to_cosets(sx, p->ix_perm, 2 * NL));
+        ZG_TRY(wait_points(p, (size_t)nb * (2 * NL + 1), pts));
+        for (uint32_t b = 0; b < nb; b++) {
+            for (uint32_t l = 0; l < NL; l++)
+                if (h_err[b * NL + l] && status[b] == ZG_OK) {
+                    set_error("zg_prover_prove: lookup %u of proof %u has an input outside its table (ConstraintSystemFailure)", l, b);
+                    status[b] = ZG_ERR_CONSTRAINT;
+                }
+            const Jac* q = &pts[(size_t)b * (2 * NL + 1)];
+            for (uint32_t i = 0; i < 2 * NL; i++) tr[b].write_point(q[i]);
+            random_commit[b] = q[2 * NL];
+        }
         have_random = true;
+        if (nb == 1 && status[0] != ZG_OK) {  // a lone proof stops here, as upstream's `?` does
+            (void)hipStreamSynchronize(ss);
+            (void)hipStreamSynchronize(st);
+            if (statuses) statuses[0] = status[0];
+            proof_lens[0] = 0;
+            return status[0];
+        }
     }
-    const Fe beta = tr.squeeze();
+    for (uint32_t b = 0; b < nb; b++) {
+        p->hpc[b].beta = tr[b].squeeze();
+        p->hpc[b].gamma = tr[b].squeeze();
+    }
+    ZG_TRY(upload_consts(p, nb));
     lap(1);
-    const Fe gamma = tr.squeeze();
 
     // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
-    Fe* pz = p->zs;
-    if (S) ZG_TRY(poly_perm_terms(ctx, p->dc, base_cols, p->sigma_val, p->omega_tw, beta, gamma, p->num, p->den, n));
+    const uint32_t mb = S + NL;
+    if (S) ZG_TRY(poly_perm_terms(ctx, pk.dc, base_cols, p->d_pc, nb, pk.sigma_val, pk.omega_tw, p->num, p->den, mb, n));
     // (a'_l / s'_l are interleaved in `perm`: two views with a stride of two columns)
-    ZG_TRY(poly_lookup_terms(ctx, p->cin, p->ctab, p->perm, p->perm + n, (size_t)2 * n, beta, gamma, p->num + (size_t)S * n,
-                             p->den + (size_t)S * n, n, NL));
-    if (S + NL) {
-        // all running products of the proof in one scan sequence; the S permutation sets are chained
+    ZG_TRY(poly_lookup_terms(ctx, p->d_pc, nb, p->cin, p->ctab, p->perm, p->perm + n, (size_t)2 * n, perm_bs, p->num, p->den, mb, S, n, NL));
+    if (mb) {
+        // all running products of the batch in one scan sequence; per proof the S permutation sets are chained
         // through row n - bf - 1, the lookup products start from one
-        ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, S + NL, S, n - bf - 1));
-        ZG_TRY(poly_blind_rows2(ctx, pz, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf, seed));  // (lz follows pz)
+        ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, nb * mb, S, n - bf - 1, mb, zs_bs));
+        ZG_TRY(poly_blind_rows2(ctx, p->d_pc, nb, p->zs, zs_bs, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf));  // (lz follows pz)
         // The products stay constant wherever a row changes nothing (every padding row of the circuit): they are
         // committed in the run form, sum_i (z_i - z_{i+1}) Q_i over the running sums Q of g_lagrange.
-        const uint64_t z_runs = p->gl->run_table && S + NL < 64 ? (1ull << (S + NL)) - 1ull : 0ull;
+        const uint64_t z_runs = p->gl->run_table && mb < 64 ? (1ull << mb) - 1ull : 0ull;
         ZG_TRY(fork());
+        uint32_t per = mb;
         if (have_random) {
-            ZG_TRY(msm_batch3_dev(ctx, p->gl, nullptr, S + NL, p->zs, n, S + NL, n, p->xyzz, z_runs));
-        } else {  // no lookups: the random polynomial rides here instead (row S+NL of zs)
-            ZG_HIP(hipMemcpyAsync(p->zs + (size_t)(S + NL) * n, random_row, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
-            ZG_TRY(msm_batch3_dev(ctx, p->gl, p->g, S + NL, p->zs, n, S + NL + 1, n, p->xyzz, z_runs));
+            ZG_TRY(commit(p, p->gl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs));
+        } else {  // no lookups: the random polynomial rides here instead (row mb of zs)
+            for (uint32_t b = 0; b < nb; b++)
+                ZG_HIP(hipMemcpyAsync(p->zs + b * zs_bs + (size_t)mb * n, random_row + b * perm_bs, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
+            per = mb + 1;
+            ZG_TRY(commit(p, p->gl, p->g, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs));
         }
-        const uint32_t npts = S + NL + (have_random ? 0 : 1);
-        ZG_TRY(fetch_points(p, npts, pts));
-        ZG_TRY(ntt_batch_to_dev(sx, p->zs, poly_at(p->ix_pz), n, S + NL, k, p->omega_inv, &p->ifft_div));
-        for (uint32_t di = dlo; di < dhi && !split; di++) {
-            const zg_prover::Dom& d = p->dom[di];
-            if (S) ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_pz), n, n, d.pz_cos, d.en, S, d.ek, p->hat, d.zpow));
-            if (NL) ZG_TRY(coeff_to_coset_dev(sx, poly_at(p->ix_lz), n, n, d.lz_cos, d.en, NL, d.ek, p->hat, d.zpow));
+        {
+            const Grouping g = grouping(mb, zs_bs, pp_bs);
+            ZG_TRY(ntt_batch_to_dev(sx, p->zs, pp_at(p->ix_pz), n, (size_t)nb * mb, k, pk.omega_inv, &pk.ifft_div, &g));
         }
-        ZG_TRY(wait_points(p, npts, pts));
-        for (uint32_t i = 0; i < S + NL; i++) tr.write_point(pts[i]);
-        if (!have_random) {
-            random_commit = pts[S + NL];
-            have_random = true;
+        if (!split) ZG_TRY(to_cosets(sx, p->ix_pz, mb));
+        ZG_TRY(wait_points(p, (size_t)nb * per, pts));
+        for (uint32_t b = 0; b < nb; b++) {
+            const Jac* q = &pts[(size_t)b * per];
+            for (uint32_t i = 0; i < mb; i++) tr[b].write_point(q[i]);
+            if (!have_random) random_commit[b] = q[mb];
         }
+        have_random = true;
     }
     if (!have_random) {  // neither lookups nor permutation: commit the random polynomial on its own
-        ZG_TRY(msm_batch_dev(ctx, p->g, random_row, n, 1, n, p->xyzz));
-        ZG_TRY(fetch_points(p, 1, pts));
-        ZG_TRY(wait_points(p, 1, pts));
-        random_commit = pts[0];
+        ZG_TRY(commit(p, p->g, nullptr, 1, random_row, n, 1, perm_bs, nb, 0));
+        ZG_TRY(wait_points(p, nb, pts));
+        for (uint32_t b = 0; b < nb; b++) random_commit[b] = pts[b];
     }
-    tr.write_point(random_commit);
+    for (uint32_t b = 0; b < nb; b++) tr[b].write_point(random_commit[b]);
     ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
-    const Fe y = tr.squeeze();
+    {
+        const Fe c261 = Fr9Params::c261_fe();
+        const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
+        for (uint32_t b = 0; b < nb; b++) {
+            ProofConst& c = p->hpc[b];
+            const Fe y = tr[b].squeeze();
+            c.eh_y = y; c.eh_beta = c.beta; c.eh_gamma = c.gamma; c.eh_theta = c.theta;
+            c.eh_delta_start[0] = Fr::mul(c.beta, zeta);   // beta * coset shift
+            c.eh_delta_start[1] = Fr::mul(c.beta, zeta2);
+            if (hat)
+                for (Fe* cst : {&c.eh_y, &c.eh_beta, &c.eh_gamma, &c.eh_theta, &c.eh_delta_start[0], &c.eh_delta_start[1]})
+                    *cst = Fr::mul(*cst, c261);
+        }
+    }
+    ZG_TRY(upload_consts(p, nb));
     lap(2);
 
     // (split form: nothing overlaps in the throughput configuration, so every witness polynomial goes to both cosets
     //  here, in one batch per coset, instead of phase by phase)
-    if (split) {
-        ZG_REQUIRE(p->ix_inst == p->ix_adv + A && p->ix_pz == p->ix_inst + I && p->ix_lz == p->ix_pz + S && p->ix_perm == p->ix_lz + NL,
-                   ZG_ERR_INVALID_ARG, "zg_prover_prove: coefficient slab out of order");
-        for (uint32_t di = dlo; di < dhi; di++)
-            ZG_TRY(coeff_to_coset_dev(ctx, poly_at(p->ix_adv), n, n, p->dom[di].adv_cos, p->dom[di].en, A + I + S + NL + 2 * NL,
-                                      p->dom[di].ek, p->hat, p->dom[di].zpow));
-    }
+    if (split) ZG_TRY(to_cosets(ctx, p->ix_adv, p->ncos));
     // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
     for (uint32_t di = dlo; di < dhi; di++) {
-        const zg_prover::Dom& d = p->dom[di];
+        const PkDev::Dom& d = pk.dom[di];
+        const Fe* cos = p->dbuf[di].cos;
         EvalHArgs a;
         memset(&a, 0, sizeof(a));
-        a.c = p->dc;
-        a.cols.fixed = d.fixed_cos; a.cols.advice = d.adv_cos; a.cols.instance = d.inst_cos;
+        a.c = pk.dc;
+        a.cols.fixed = d.fixed_cos; a.cols.advice = cos; a.cols.instance = cos + (size_t)A * d.en;
         a.cols.log_size = d.ek; a.cols.rot_scale = (int32_t)(d.en / n);
-        a.sigma_cos = d.sigma_cos; a.pz_cos = d.pz_cos; a.lz_cos = d.lz_cos;
-        // perm_cos is interleaved, [2l] = a'_l and [2l+1] = s'_l: two views with a stride of two slabs
-        a.pin_cos = d.perm_cos; a.ptab_cos = d.perm_cos + d.en; a.perm_stride = (size_t)2 * d.en;
+        a.cols.adv_bs = a.cols.inst_bs = (size_t)p->ncos * d.en;
+        a.sigma_cos = d.sigma_cos;
+        a.pz_cos = cos + (size_t)(A + I) * d.en;
+        a.lz_cos = a.pz_cos + (size_t)S * d.en;
+        // the a'/s' cosets are interleaved, [2l] = a'_l and [2l+1] = s'_l: two views with a stride of two slabs
+        a.pin_cos = a.lz_cos + (size_t)NL * d.en; a.ptab_cos = a.pin_cos + d.en; a.perm_stride = (size_t)2 * d.en;
         a.l0 = d.l0; a.llast = d.llast; a.lactive = d.lactive;
-        a.ext_tw = p->hat ? d.ext_tw + d.en : d.ext_tw;  // (the twiddle table's second half is the 2^261 form)
+        a.ext_tw = hat ? d.ext_tw + d.en : d.ext_tw;  // (the twiddle table's second half is the 2^261 form)
         a.t_eval = d.t_eval; a.t_mask = (1u << (d.ek - k)) - 1;
         a.last_rot = -(int32_t)(bf + 1);
-        a.y = y; a.beta = beta; a.gamma = gamma; a.theta = theta;
-        a.delta_start = Fr::mul(beta, d.zpow == 1 ? fr_zeta() : Fr::sqr(fr_zeta())); a.delta = fr_delta();  // beta * coset shift
-        a.hat = p->hat;
-        a.monos_hat = p->monos_hat;
-        a.gates_hat = p->gates_hat;
-        a.gate_common = p->gate_common;
-        a.gate_uni = p->gate_uni;
-        a.uni_coef = p->uni_coef;
-        a.gate_slab = p->gate_slab;
+        a.pc = p->d_pc; a.zpow = (uint32_t)d.zpow;
+        a.cos_bs = (size_t)p->ncos * d.en; a.h_bs = d.en;
+        a.delta = hat ? Fr::mul(fr_delta(), Fr9Params::c261_fe()) : fr_delta();
+        a.hat = hat;
+        a.monos_hat = pk.monos_hat;
+        a.gates_hat = pk.gates_hat;
+        a.gate_common = pk.gate_common;
+        a.gate_uni = pk.gate_uni;
+        a.uni_coef = pk.uni_coef;
+        a.gate_slab = pk.gate_slab;
         a.gate_slabs = d.gate_slabs;
-        if (p->hat) {
-            const Fe c261 = Fr9Params::c261_fe();
-            for (Fe* cst : {&a.y, &a.beta, &a.gamma, &a.theta, &a.delta_start, &a.delta}) *cst = Fr::mul(*cst, c261);
-        }
-        a.h = d.h;
-        ZG_TRY(poly_evaluate_h(ctx, a, d.en));
+        a.h = p->dbuf[di].h;
+        ZG_TRY(poly_evaluate_h(ctx, a, d.en, nb));
     }
     p->have_last = true;
     p->last_split = split;
+    p->last_nb = nb;
     if (!split) {
-        ZG_TRY(extended_to_coeff_dev(ctx, p->dom[0].h, k, ek, (size_t)Q * n, poly_at(p->ix_hpiece), p->hat));
+        ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[0].h, ek, (size_t)Q * n, pp_at(p->ix_hpiece), hat, 1, nb, pk.dom[0].en, pp_bs));
     } else {
         // h = A + (X^L1 - c1) B:  A (degree < L1) from the first coset, where X^L1 = c1 = shift1^L1;  B (degree < L2)
         // from the second, where X^L1 = c2 and X^L2 = e are constants too:  B = (h - A) / (c2 - c1) there, with A
         // folded modulo X^L2 - e before it is evaluated on those L2 points.
-        const zg_prover::Dom &d1 = p->dom[1], &d2 = p->dom[2];
+        const PkDev::Dom &d1 = pk.dom[1], &d2 = pk.dom[2];
         const uint32_t L1 = d1.en, L2 = d2.en;
         const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
         const Fe c1 = Fr::pow_u64(zeta, L1), c2 = Fr::pow_u64(zeta2, L1), e = Fr::pow_u64(zeta2, L2);
-        Fe* hp = poly_at(p->ix_hpiece);
+        Fe* hp = pp_at(p->ix_hpiece);
+        const size_t tb = (size_t)3 * L2;
         Fe *fold = p->split_tmp, *a2 = fold + L2, *bc = a2 + L2;
-        ZG_TRY(coset_to_coeff_dev(ctx, d1.h, d1.ek, L1, hp, p->hat, 1));               // A, in place of the low pieces
-        ZG_TRY(poly_fold(ctx, hp, L2, L1 / L2, e, fold));                               // A mod (X^L2 - e)
-        ZG_TRY(coeff_to_coset_dev(ctx, fold, L2, L2, a2, L2, 1, d2.ek, false, 2));      // A on the second coset
-        const Fe unhat = p->hat ? Fr::inv(Fr::from_u64(32)) : Fr::one();
-        ZG_TRY(poly_diff_scale(ctx, d2.h, unhat, a2, Fr::inv(Fr::sub(c2, c1)), a2, L2));  // B on the second coset
-        ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2));                   // B
-        ZG_TRY(poly_split_combine(ctx, hp, bc, L2, c1, L1));                            // h = A - c1 B + X^L1 B
+        ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[1].h, d1.ek, L1, hp, hat, 1, nb, L1, pp_bs));  // A, in place of the low pieces
+        ZG_TRY(poly_fold(ctx, nb, hp, pp_bs, L2, L1 / L2, e, fold, tb));                       // A mod (X^L2 - e)
+        ZG_TRY(coeff_to_coset_dev(ctx, fold, tb, L2, a2, tb, nb, d2.ek, false, 2));            // A on the second coset
+        const Fe unhat = hat ? Fr::inv(Fr::from_u64(32)) : Fr::one();
+        ZG_TRY(poly_diff_scale(ctx, nb, p->dbuf[2].h, L2, unhat, a2, tb, Fr::inv(Fr::sub(c2, c1)), a2, tb, L2));  // B on the second coset
+        ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
+        ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
     }
-    ZG_TRY(msm_batch_dev(ctx, p->g, poly_at(p->ix_hpiece), n, Q, n, p->xyzz));
-    ZG_TRY(fetch_points(p, Q, pts));
-    ZG_TRY(wait_points(p, Q, pts));
-    for (auto& q : pts) tr.write_point(q);
-    const Fe x = tr.squeeze();
-    lap(3);
-    const Fe xn = Fr::pow_u64(x, n);
+    ZG_TRY(commit(p, p->g, nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0));
+    ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
+    for (uint32_t b = 0; b < nb; b++)
+        for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
 
     // ---- evaluations
     // distinct opening points, in any order (the powers table is indexed by slot)
@@ -935,9 +1177,9 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     };
     struct Q1 { uint32_t poly, slot; };
     std::vector<Q1> evq;  // evaluations in transcript order, then h_poly at x
-    for (auto& q : p->advice_queries) evq.push_back({p->ix_adv + q.column, rot_slot(q.rotation)});
+    for (auto& q : pk.advice_queries) evq.push_back({p->ix_adv + q.column, rot_slot(q.rotation)});
     const size_t e_fixed = evq.size();
-    for (auto& q : p->fixed_queries) evq.push_back({p->ix_fixed + q.column, rot_slot(q.rotation)});
+    for (auto& q : pk.fixed_queries) evq.push_back({p->ix_fixed + q.column, rot_slot(q.rotation)});
     const size_t e_random = evq.size();
     evq.push_back({p->ix_random, 0});
     const size_t e_sigma = evq.size();
@@ -959,38 +1201,43 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
     const size_t e_written = evq.size();
     evq.push_back({p->ix_hpoly, 0});
     const size_t e_h = e_written;
+    const uint32_t npoints = (uint32_t)rots.size();
+    ZG_REQUIRE(npoints <= p->max_points, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u distinct rotations are queried (max %u)", npoints,
+               p->max_points);
+    ZG_REQUIRE(evq.size() <= p->max_evals, ZG_ERR_UNSUPPORTED, "zg_prover_prove: too many evaluations");
 
-    std::vector<Fe> points(rots.size());
-    for (size_t i = 0; i < rots.size(); i++) points[i] = rotate_omega(p, x, rots[i]);
+    for (uint32_t b = 0; b < nb; b++) {
+        ProofConst& c = p->hpc[b];
+        const Fe x = tr[b].squeeze();
+        c.xn = Fr::pow_u64(x, n);
+        for (uint32_t i = 0; i < npoints; i++) c.points[i] = rotate_omega(pk, x, rots[i]);
+    }
+    ZG_TRY(upload_consts(p, nb));
+    lap(3);
     // vanishing.evaluate: h(X) = sum_i xn^i h_i(X)
+    uint32_t* d_hlist = p->d_idx + (size_t)4 * p->max_evals;
     {
         std::vector<uint32_t> list(Q);
         for (uint32_t i = 0; i < Q; i++) list[i] = p->ix_hpiece + (Q - 1 - i);
-        uint32_t* dl = p->d_idx + (size_t)4 * (p->advice_queries.size() + p->fixed_queries.size() + P + 3 * S + 5 * NL + 4);
-        ZG_TRY(h2d_list(p, dl, list));
-        ZG_TRY(poly_horner_combine(ctx, polys, n, dl, Q, xn, fe_zero(), poly_at(p->ix_hpoly), n));
+        ZG_TRY(h2d_list(p, d_hlist, list));
+        ZG_TRY(poly_horner_combine_xn(ctx, polys, p->d_pc, nb, d_hlist, Q, pp_at(p->ix_hpoly), pp_bs, n));
     }
-    {
-        const Fe* pts_pinned = (const Fe*)stage(p, points.data(), points.size() * sizeof(Fe));
-        ZG_TRY(poly_powers(ctx, pts_pinned ? pts_pinned : points.data(), (uint32_t)points.size(), n, p->pw));
-    }
+    ZG_TRY(poly_powers(ctx, p->d_pc, nb, npoints, n, p->pw, pw_bs));
     std::vector<uint32_t> idx(2 * evq.size());
     for (size_t i = 0; i < evq.size(); i++) {
         idx[i] = evq[i].poly;
         idx[evq.size() + i] = evq[i].slot;
     }
     ZG_TRY(h2d_list(p, p->d_idx, idx));
-    ZG_TRY(poly_dot(ctx, polys, n, n, p->d_idx, p->d_idx + evq.size(), p->pw, (uint32_t)evq.size(), p->evals));
-    ZG_REQUIRE(evq.size() * sizeof(Fe) <= PIN_STAGE - PIN_EVALS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: too many evaluations");
-    const Fe* ev = reinterpret_cast<const Fe*>((char*)p->pinned + PIN_EVALS);
-    ZG_HIP(hipMemcpyAsync((void*)ev, p->evals, evq.size() * sizeof(Fe), hipMemcpyDeviceToHost, st));
+    ZG_TRY(poly_dot(ctx, polys, nb, n, p->d_idx, p->d_idx + evq.size(), p->pw, pw_bs, (uint32_t)evq.size(), p->evals, p->max_evals));
+    const Fe* ev_all = reinterpret_cast<const Fe*>((char*)p->pinned + p->pin_evals);
+    ZG_HIP(hipMemcpyAsync((void*)ev_all, p->evals, ((size_t)(nb - 1) * p->max_evals + evq.size()) * sizeof(Fe), hipMemcpyDeviceToHost, st));
     ZG_HIP(hipStreamSynchronize(st));
-    for (size_t i = 0; i < e_written; i++) tr.write_scalar(ev[i]);
 
-    // ---- opening queries in create_proof's order: (poly, point slot, eval)
-    struct OQ { uint32_t poly, slot; Fe eval; };
+    // ---- opening queries in create_proof's order: (poly, point slot, index of the evaluation)
+    struct OQ { uint32_t poly, slot; size_t ev; };
     std::vector<OQ> oq;
-    for (size_t i = 0; i < e_fixed; i++) oq.push_back({evq[i].poly, evq[i].slot, ev[i]});
+    for (size_t i = 0; i < e_fixed; i++) oq.push_back({evq[i].poly, evq[i].slot, i});
     {
         size_t e = e_pz;
         std::vector<size_t> e_last(S, 0), e_cur(S, 0), e_next(S, 0);
@@ -1000,96 +1247,138 @@ int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, siz
             if (s + 1 < S) e_last[s] = e++;
         }
         for (uint32_t s = 0; s < S; s++) {
-            oq.push_back({p->ix_pz + s, 0, ev[e_cur[s]]});
-            oq.push_back({p->ix_pz + s, 1, ev[e_next[s]]});
+            oq.push_back({p->ix_pz + s, 0, e_cur[s]});
+            oq.push_back({p->ix_pz + s, 1, e_next[s]});
         }
         for (uint32_t s = S; s-- > 0;) {
             if (s + 1 == S) continue;
-            oq.push_back({p->ix_pz + s, 3, ev[e_last[s]]});
+            oq.push_back({p->ix_pz + s, 3, e_last[s]});
         }
     }
     for (uint32_t l = 0; l < NL; l++) {
-        const Fe* e5 = &ev[e_lk + 5 * l];
-        oq.push_back({p->ix_lz + l, 0, e5[0]});
-        oq.push_back({p->ix_perm + 2 * l, 0, e5[2]});
-        oq.push_back({p->ix_perm + 2 * l + 1, 0, e5[4]});
-        oq.push_back({p->ix_perm + 2 * l, 2, e5[3]});
-        oq.push_back({p->ix_lz + l, 1, e5[1]});
+        const size_t e5 = e_lk + 5 * l;
+        oq.push_back({p->ix_lz + l, 0, e5 + 0});
+        oq.push_back({p->ix_perm + 2 * l, 0, e5 + 2});
+        oq.push_back({p->ix_perm + 2 * l + 1, 0, e5 + 4});
+        oq.push_back({p->ix_perm + 2 * l, 2, e5 + 3});
+        oq.push_back({p->ix_lz + l, 1, e5 + 1});
     }
-    for (size_t i = e_fixed; i < e_random; i++) oq.push_back({evq[i].poly, evq[i].slot, ev[i]});
-    for (uint32_t c = 0; c < P; c++) oq.push_back({p->ix_sigma + c, 0, ev[e_sigma + c]});
-    oq.push_back({p->ix_hpoly, 0, ev[e_h]});
-    oq.push_back({p->ix_random, 0, ev[e_random]});
+    for (size_t i = e_fixed; i < e_random; i++) oq.push_back({evq[i].poly, evq[i].slot, i});
+    for (uint32_t c = 0; c < P; c++) oq.push_back({p->ix_sigma + c, 0, e_sigma + c});
+    oq.push_back({p->ix_hpoly, 0, e_h});
+    oq.push_back({p->ix_random, 0, e_random});
 
-    // ---- ProverGWC::create_proof
-    const Fe v = tr.squeeze();
-    lap(4);
+    // ---- ProverGWC::create_proof: the point sets (circuit only), then per proof its v-weighted evaluation batches
+    uint32_t nsets = 0;
+    std::vector<uint32_t> lists, counts, set_slot;  // list of point set s at lists[s * 512 ..]
+    std::vector<std::vector<size_t>> set_evs;        // evaluation indices of set s, in list order
     {
         std::vector<char> done(oq.size(), 0);
-        uint32_t npts = 0;
-        std::vector<uint32_t> lists, counts;  // list of point set s at lists[s * 512 ..]
-        std::vector<Fe> open_points, eval_batches;
         for (size_t first = 0; first < oq.size(); first++) {
             if (done[first]) continue;
             const uint32_t slot = oq[first].slot;
-            lists.resize((size_t)(npts + 1) * 512, 0);
+            lists.resize((size_t)(nsets + 1) * 512, 0);
+            set_evs.emplace_back();
             uint32_t cnt = 0;
-            Fe eval_batch = fe_zero();
             for (size_t j = first; j < oq.size(); j++) {
                 if (done[j] || oq[j].slot != slot) continue;
                 done[j] = 1;
                 ZG_REQUIRE(cnt < 512, ZG_ERR_UNSUPPORTED, "zg_prover_prove: more than 512 polynomials opened at one point");
-                lists[(size_t)npts * 512 + cnt++] = oq[j].poly;
-                eval_batch = Fr::add(Fr::mul(eval_batch, v), oq[j].eval);
+                lists[(size_t)nsets * 512 + cnt++] = oq[j].poly;
+                set_evs.back().push_back(oq[j].ev);
             }
             counts.push_back(cnt);
-            eval_batches.push_back(eval_batch);
-            open_points.push_back(points[slot]);
-            npts++;
+            set_slot.push_back(slot);
+            nsets++;
         }
+    }
+    ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u opening points", nsets);
+    for (uint32_t b = 0; b < nb; b++) {
+        const Fe* ev = ev_all + (size_t)b * p->max_evals;
+        for (size_t i = 0; i < e_written; i++) tr[b].write_scalar(ev[i]);
+        ProofConst& c = p->hpc[b];
+        c.v = tr[b].squeeze();
+        for (uint32_t s = 0; s < nsets; s++) {
+            Fe eval_batch = fe_zero();
+            for (size_t e : set_evs[s]) eval_batch = Fr::add(Fr::mul(eval_batch, c.v), ev[e]);
+            c.subs[s] = eval_batch;
+        }
+    }
+    ZG_TRY(upload_consts(p, nb));
+    lap(4);
+    {
         // poly_batch of every point set in one launch: set s -> wpoly[2s]
         // (their own region of d_idx, behind the evaluation lists: nothing else writes there between proofs)
-        uint32_t* d_lists = p->d_idx + (size_t)4 * (p->advice_queries.size() + p->fixed_queries.size() + P + 3 * S + 5 * NL + 4) + 64;
+        uint32_t* d_lists = d_hlist + 64;
         ZG_TRY(h2d_list(p, d_lists, lists));
-        for (uint32_t s0 = 0; s0 < npts; s0 += HC_MAX_SETS) {
-            const uint32_t m = std::min<uint32_t>(HC_MAX_SETS, npts - s0);
-            ZG_TRY(poly_horner_combine_sets(ctx, polys, n, d_lists + (size_t)s0 * 512, 512, counts.data() + s0,
-                                            eval_batches.data() + s0, m, v, p->wpoly + (size_t)(2 * s0) * n, (size_t)2 * n, n));
-        }
-        // one batched kate_division: poly j at wpoly[2j], quotient at wpoly[2j+1]
-        const Fe* op_pinned = (const Fe*)stage(p, open_points.data(), open_points.size() * sizeof(Fe));
-        ZG_TRY(poly_kate_division(ctx, p->wpoly, (size_t)2 * n, op_pinned ? op_pinned : open_points.data(), p->wpoly + n,
-                                  (size_t)2 * n, p->ktmp, n, npts));
+        ZG_TRY(poly_horner_combine_sets(ctx, polys, p->d_pc, nb, d_lists, 512, counts.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, n));
+        // one batched kate_division: poly s at wpoly[2s], quotient at wpoly[2s+1]
+        ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
+                                  wp_bs, p->ktmp, n));
         // the witness polynomials sit at odd slots: stride 2n
-        ZG_TRY(msm_batch_dev(ctx, p->g, p->wpoly + n, (size_t)2 * n, npts, n, p->xyzz));
-        ZG_TRY(fetch_points(p, npts, pts));
-        ZG_TRY(wait_points(p, npts, pts));
-        for (auto& q : pts) tr.write_point(q);
+        ZG_TRY(commit(p, p->g, nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0));
+        ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
+        for (uint32_t b = 0; b < nb; b++)
+            for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
     }
-    ZG_REQUIRE(!tr.failed, ZG_ERR_INVALID_ARG,
-               "zg_prover_prove: a commitment is the identity point; EvmTranscript cannot absorb it");
-    ZG_REQUIRE(tr.stream.size() <= proof_cap, ZG_ERR_INVALID_ARG, "zg_prover_prove: proof buffer too small (%zu > %zu)",
-               tr.stream.size(), proof_cap);
-    memcpy(proof, tr.stream.data(), tr.stream.size());
-    *proof_len = tr.stream.size();
+    int first_bad = ZG_OK;
+    for (uint32_t b = 0; b < nb; b++) {
+        if (status[b] == ZG_OK && tr[b].failed) {
+            set_error("zg_prover_prove: a commitment of proof %u is the identity point; EvmTranscript cannot absorb it", b);
+            status[b] = ZG_ERR_INVALID_ARG;
+        }
+        if (status[b] == ZG_OK && tr[b].stream.size() > proof_cap) {
+            set_error("zg_prover_prove: proof buffer too small (%zu > %zu)", tr[b].stream.size(), proof_cap);
+            status[b] = ZG_ERR_INVALID_ARG;
+        }
+        if (status[b] == ZG_OK) {
+            memcpy(proofs[b], tr[b].stream.data(), tr[b].stream.size());
+            proof_lens[b] = tr[b].stream.size();
+        } else {
+            proof_lens[b] = 0;
+            if (first_bad == ZG_OK) first_bad = status[b];
+        }
+        if (statuses) statuses[b] = status[b];
+    }
     lap(5);
     p->phase_ms[6] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
-    return ZG_OK;
+    return first_bad;
 }
 
-int zg_prover_prove(zg_prover* p, const zg_fr* advice, const zg_fr* instance, size_t instance_len, uint64_t seed,
+int zg_prover_prove_batch(zg_prover* p, size_t count, const zg_fr* const* advice, const zg_fr* const* instance,
+                          size_t instance_len, const uint8_t* rng_keys, uint8_t* const* proofs, size_t proof_cap,
+                          size_t* proof_lens, int* statuses) {
+    return prove_batch_impl(p, count, advice, nullptr, instance, instance_len, rng_keys, proofs, proof_cap, proof_lens, statuses);
+}
+
+int zg_prover_prove_batch_dev(zg_prover* p, size_t count, void* const* d_advice, const zg_fr* const* instance,
+                              size_t instance_len, const uint8_t* rng_keys, uint8_t* const* proofs, size_t proof_cap,
+                              size_t* proof_lens, int* statuses) {
+    return prove_batch_impl(p, count, nullptr, d_advice, instance, instance_len, rng_keys, proofs, proof_cap, proof_lens, statuses);
+}
+
+int zg_prover_prove_dev(zg_prover* p, void* d_advice, const zg_fr* instance, size_t instance_len, const uint8_t rng_key[32],
+                        uint8_t* proof, size_t proof_cap, size_t* proof_len) {
+    ZG_REQUIRE(p && proof && proof_len && rng_key && (d_advice || p->pk->A == 0), ZG_ERR_INVALID_ARG, "zg_prover_prove: null argument");
+    void* adv[1] = {d_advice};
+    const zg_fr* inst[1] = {instance};
+    uint8_t* out[1] = {proof};
+    return prove_batch_impl(p, 1, nullptr, adv, instance ? inst : nullptr, instance_len, rng_key, out, proof_cap, proof_len, nullptr);
+}
+
+int zg_prover_prove(zg_prover* p, const zg_fr* advice, const zg_fr* instance, size_t instance_len, const uint8_t rng_key[32],
                     uint8_t* proof, size_t proof_cap, size_t* proof_len) {
-    ZG_REQUIRE(p && (advice || p->A == 0), ZG_ERR_INVALID_ARG, "zg_prover_prove: null argument");
-    ZG_HIP(hipSetDevice(p->ctx->device));
-    if (p->A)
-        ZG_HIP(hipMemcpyAsync(p->adv_val, advice, (size_t)p->A * p->n * 32, hipMemcpyHostToDevice, p->ctx->stream));
-    return zg_prover_prove_dev(p, p->adv_val, instance, instance_len, seed, proof, proof_cap, proof_len);
+    ZG_REQUIRE(p && proof && proof_len && rng_key && (advice || p->pk->A == 0), ZG_ERR_INVALID_ARG, "zg_prover_prove: null argument");
+    const zg_fr* adv[1] = {advice};
+    const zg_fr* inst[1] = {instance};
+    uint8_t* out[1] = {proof};
+    return prove_batch_impl(p, 1, adv, nullptr, instance ? inst : nullptr, instance_len, rng_key, out, proof_cap, proof_len, nullptr);
 }
 
 int zg_prover_set_overlap(zg_prover* p, int enable) {
     ZG_REQUIRE(p, ZG_ERR_INVALID_ARG, "zg_prover_set_overlap: null prover");
+    ZG_ENTER(p->ctx);
     if (enable && !p->ctx->side) {
-        ZG_HIP(hipSetDevice(p->ctx->device));
         ZG_TRY(zg_ctx_create(p->ctx->device, &p->ctx->side));
         p->ctx->side->profiling = p->ctx->profiling;
         p->ctx->side->prof_filter = p->ctx->prof_filter;
@@ -1105,38 +1394,42 @@ int zg_prover_phase_ms(const zg_prover* p, double* out, size_t cap) {
     return ZG_OK;
 }
 
-int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, size_t cap_elems) {
+int zg_prover_fetch_slot(zg_prover* p, size_t slot, uint32_t what, uint32_t index, zg_fr* out, size_t cap_elems) {
     ZG_REQUIRE(p && out, ZG_ERR_INVALID_ARG, "zg_prover_fetch: null argument");
+    ZG_ENTER(p->ctx);
     ZG_REQUIRE(p->have_last, ZG_ERR_INVALID_ARG, "zg_prover_fetch: no proof has been produced yet");
+    ZG_REQUIRE(slot < p->last_nb, ZG_ERR_INVALID_ARG, "zg_prover_fetch: slot %zu of a batch of %u", slot, p->last_nb);
+    const PkDev& pk = *p->pk;
     const Fe* src = nullptr;
     size_t count = 0;
-    const size_t n = p->n;
+    const size_t n = pk.n;
+    const Fe* zs = p->zs + slot * (size_t)(pk.sets + pk.NL + 1) * n;
+    const Fe* perm = p->perm + slot * (size_t)(2 * pk.NL + 1) * n;
+    const Fe* hp = p->pp + slot * (size_t)p->npp * n + (size_t)(p->ix_hpiece - p->nsh) * n;
     switch (what) {
-        case 0: src = p->dom[0].h; count = p->en; break;
-        case 1: ZG_REQUIRE(index < p->sets, ZG_ERR_INVALID_ARG, "zg_prover_fetch: set %u", index);
-                src = p->zs + (size_t)index * n; count = n; break;
-        case 2: ZG_REQUIRE(index < p->NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
-                src = p->zs + (size_t)(p->sets + index) * n; count = n; break;
-        case 3: ZG_REQUIRE(index < p->NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
-                src = p->perm + (size_t)(2 * index) * n; count = n; break;
-        case 4: ZG_REQUIRE(index < p->NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
-                src = p->perm + (size_t)(2 * index + 1) * n; count = n; break;
-        case 5: src = p->polys + (size_t)p->ix_hpiece * n; count = (size_t)p->qpd * n; break;
+        case 0: src = p->dbuf[0].h + slot * (size_t)pk.en; count = pk.en; break;
+        case 1: ZG_REQUIRE(index < pk.sets, ZG_ERR_INVALID_ARG, "zg_prover_fetch: set %u", index);
+                src = zs + (size_t)index * n; count = n; break;
+        case 2: ZG_REQUIRE(index < pk.NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
+                src = zs + (size_t)(pk.sets + index) * n; count = n; break;
+        case 3: ZG_REQUIRE(index < pk.NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
+                src = perm + (size_t)(2 * index) * n; count = n; break;
+        case 4: ZG_REQUIRE(index < pk.NL, ZG_ERR_INVALID_ARG, "zg_prover_fetch: lookup %u", index);
+                src = perm + (size_t)(2 * index + 1) * n; count = n; break;
+        case 5: src = hp; count = (size_t)pk.qpd * n; break;
         default: ZG_REQUIRE(false, ZG_ERR_INVALID_ARG, "zg_prover_fetch: unknown item %u", what);
     }
     ZG_REQUIRE(cap_elems >= count, ZG_ERR_INVALID_ARG, "zg_prover_fetch: need %zu elements", count);
-    ZG_HIP(hipSetDevice(p->ctx->device));
     if (what == 0 && p->last_split) {  // split domain: h on EvaluationDomain's coset, from its coefficients
         WsScope ws(p->ctx);
         Fe* tmp = ws.get<Fe>(count);
         if (!tmp) return ZG_ERR_OOM;
-        const Fe* hp = p->polys + (size_t)p->ix_hpiece * n;
-        ZG_TRY(coeff_to_coset_dev(p->ctx, hp, (size_t)p->qpd * n, (uint32_t)(p->qpd * n), tmp, count, 1, p->ext_k, false, 1));
+        ZG_TRY(coeff_to_coset_dev(p->ctx, hp, (size_t)pk.qpd * n, (uint32_t)(pk.qpd * n), tmp, count, 1, pk.ext_k, false, 1));
         ZG_HIP(hipStreamSynchronize(p->ctx->stream));
         ZG_HIP(hipMemcpy(out, tmp, count * 32, hipMemcpyDeviceToHost));
         return ZG_OK;
     }
-    if (what == 0 && p->hat) {  // h on the coset is kept as x * 2^261: hand back the library form
+    if (what == 0 && pk.hat) {  // h on the coset is kept as x * 2^261: hand back the library form
         WsScope ws(p->ctx);
         Fe* tmp = ws.get<Fe>(count);
         if (!tmp) return ZG_ERR_OOM;
@@ -1145,15 +1438,20 @@ int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, siz
         ZG_HIP(hipMemcpy(out, tmp, count * 32, hipMemcpyDeviceToHost));
         return ZG_OK;
     }
+    ZG_HIP(hipStreamSynchronize(p->ctx->stream));
     ZG_HIP(hipMemcpy(out, src, count * 32, hipMemcpyDeviceToHost));
     return ZG_OK;
 }
 
-// ---- stand-alone building blocks (tests) ----
+int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, size_t cap_elems) {
+    return zg_prover_fetch_slot(p, 0, what, index, out, cap_elems);
+}
+
+// ---- stand-alone building blocks ----
 int zg_grand_product_dev(zg_ctx* ctx, const void* d_num, const void* d_den, const zg_fr* z0, size_t n, void* d_z) {
     ZG_REQUIRE(ctx && d_num && d_den && d_z && z0, ZG_ERR_INVALID_ARG, "zg_grand_product_dev: null argument");
     ZG_REQUIRE(n < (1u << 28), ZG_ERR_UNSUPPORTED, "zg_grand_product_dev: n too large");
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
     Fe* tmp = ws.get<Fe>(poly_grand_product_tmp_elems((uint32_t)n, 1) + 1);
     if (ws.failed) return ZG_ERR_OOM;
@@ -1164,39 +1462,74 @@ int zg_grand_product_dev(zg_ctx* ctx, const void* d_num, const void* d_den, cons
     return ZG_OK;
 }
 
+// Host-pointer form of the same (lookup::prover::commit_product / permutation::prover::commit's running product):
+// z[0] = z0, z[i+1] = z[i] * num[i] / den[i] with BatchInvert's rule for a zero denominator (ratio 0); z has n entries.
+int zg_grand_product(zg_ctx* ctx, const zg_fr* num, const zg_fr* den, const zg_fr* z0, size_t n, zg_fr* z) {
+    ZG_REQUIRE(ctx && num && den && z0 && z, ZG_ERR_INVALID_ARG, "zg_grand_product: null argument");
+    ZG_REQUIRE(n >= 1 && n < (1u << 28), ZG_ERR_UNSUPPORTED, "zg_grand_product: n out of range");
+    ZG_ENTER(ctx);
+    WsScope ws(ctx);
+    Fe* d = ws.get<Fe>(3 * n);
+    if (ws.failed) return ZG_ERR_OOM;
+    ZG_HIP(hipMemcpyAsync(d, num, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(hipMemcpyAsync(d + n, den, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    ZG_TRY(zg_grand_product_dev(ctx, d, d + n, z0, n, d + 2 * n));
+    ZG_HIP(hipMemcpy(z, d + 2 * n, n * 32, hipMemcpyDeviceToHost));
+    return ZG_OK;
+}
+
 int zg_eval_polys_dev(zg_ctx* ctx, const void* d_polys, size_t stride_elems, size_t n, const uint32_t* poly_index,
                       const zg_fr* points, size_t count, zg_fr* out) {
     ZG_REQUIRE(ctx && d_polys && poly_index && points && out, ZG_ERR_INVALID_ARG, "zg_eval_polys_dev: null argument");
     if (!count) return ZG_OK;
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_REQUIRE(stride_elems == n || count == 0, ZG_ERR_UNSUPPORTED, "zg_eval_polys_dev: stride %zu != n %zu", stride_elems, n);
+    ZG_ENTER(ctx);
     WsScope ws(ctx);
-    // every pair gets its own powers row (callers with shared points should use the prover)
-    Fe* pw = ws.get<Fe>(count * n + count);
-    uint32_t* di = ws.get<uint32_t>(2 * count);
-    Fe* de = ws.get<Fe>(count);
+    // the pairs are served PC_MAX_POINTS at a time, every pair with a powers row of its own (callers with shared
+    // points should use the prover)
+    Fe* pw = ws.get<Fe>((size_t)PC_MAX_POINTS * n);
+    uint32_t* di = ws.get<uint32_t>(2 * PC_MAX_POINTS);
+    Fe* de = ws.get<Fe>(PC_MAX_POINTS);
+    ProofConst* dpc = ws.get<ProofConst>(1);
     if (ws.failed) return ZG_ERR_OOM;
-    std::vector<uint32_t> idx(2 * count);
-    for (size_t i = 0; i < count; i++) {
-        idx[i] = poly_index[i];
-        idx[count + i] = (uint32_t)i;
+    PolySet ps;
+    ps.sh = (const Fe*)d_polys; ps.pp = nullptr; ps.nsh = 0xffffffffu; ps.n = n; ps.pp_bs = 0;
+    for (size_t c0 = 0; c0 < count; c0 += PC_MAX_POINTS) {
+        const uint32_t m = (uint32_t)std::min<size_t>(PC_MAX_POINTS, count - c0);
+        ProofConst hc;
+        memset(&hc, 0, sizeof(hc));
+        uint32_t idx[2 * PC_MAX_POINTS];
+        for (uint32_t i = 0; i < m; i++) {
+            hc.points[i] = to_fe(&points[c0 + i]);
+            idx[i] = poly_index[c0 + i];
+            idx[m + i] = i;
+        }
+        ZG_HIP(hipMemcpyAsync(dpc, &hc, sizeof(hc), hipMemcpyHostToDevice, ctx->stream));
+        ZG_HIP(hipMemcpyAsync(di, idx, 2 * m * 4, hipMemcpyHostToDevice, ctx->stream));
+        ZG_HIP(hipStreamSynchronize(ctx->stream));  // (hc and idx are stack memory)
+        ZG_TRY(poly_powers(ctx, dpc, 1, m, (uint32_t)n, pw, 0));
+        ZG_TRY(poly_dot(ctx, ps, 1, (uint32_t)n, di, di + m, pw, 0, m, de, 0));
+        ZG_HIP(hipMemcpyAsync(out + c0, de, m * 32, hipMemcpyDeviceToHost, ctx->stream));
+        ZG_HIP(hipStreamSynchronize(ctx->stream));
     }
-    ZG_TRY(poly_powers(ctx, (const Fe*)points, (uint32_t)count, (uint32_t)n, pw));
-    ZG_HIP(hipMemcpyAsync(di, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    ZG_TRY(poly_dot(ctx, (const Fe*)d_polys, stride_elems, (uint32_t)n, di, di + count, pw, (uint32_t)count, de));
-    ZG_HIP(hipMemcpyAsync(out, de, count * 32, hipMemcpyDeviceToHost, ctx->stream));
-    ZG_HIP(hipStreamSynchronize(ctx->stream));
     return ZG_OK;
 }
 
 int zg_kate_division_dev(zg_ctx* ctx, const void* d_a, size_t n, const zg_fr* z, void* d_q) {
     ZG_REQUIRE(ctx && d_a && z && d_q && n >= 1, ZG_ERR_INVALID_ARG, "zg_kate_division_dev: bad argument");
-    ZG_HIP(hipSetDevice(ctx->device));
+    ZG_ENTER(ctx);
     ZG_REQUIRE(n < (1u << 28), ZG_ERR_UNSUPPORTED, "zg_kate_division_dev: n too large");
     WsScope ws(ctx);
     Fe* tmp = ws.get<Fe>(poly_kate_tmp_elems((uint32_t)n, 1));
+    ProofConst* dpc = ws.get<ProofConst>(1);
     if (ws.failed) return ZG_ERR_OOM;
-    Fe zz = to_fe(z);
-    ZG_TRY(poly_kate_division(ctx, (const Fe*)d_a, n, &zz, (Fe*)d_q, n, tmp, (uint32_t)n, 1));
+    ProofConst hc;
+    memset(&hc, 0, sizeof(hc));
+    hc.points[0] = to_fe(z);
+    ZG_HIP(hipMemcpyAsync(dpc, &hc, sizeof(hc), hipMemcpyHostToDevice, ctx->stream));
+    ZG_HIP(hipStreamSynchronize(ctx->stream));
+    const uint32_t slot0 = 0;
+    ZG_TRY(poly_kate_division(ctx, dpc, 1, &slot0, 1, (const Fe*)d_a, n, 0, (Fe*)d_q, n, 0, tmp, (uint32_t)n));
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     return ZG_OK;
 }

@@ -23,12 +23,24 @@ from __future__ import annotations
 
 import json
 import struct
-from dataclasses import asdict
+from dataclasses import asdict, dataclass
 
 import numpy as np
 
-from circuit import MONT, R
-from wnn_model import WnnCircuitParams
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001  # BN254 scalar field
+MONT = (1 << 256) % R
+
+
+@dataclass
+class WnnCircuitParams:
+    """gadgets/wnn.rs `WnnCircuitParams` as filled by Wnn::get_circuit_params (/root/reference/src/wnn.rs:171-181):
+    the file `zero_g` keeps next to its keys (io.rs:149-156)."""
+    p: int
+    l: int
+    n_hashes: int
+    bits_per_hash: int
+    bits_per_filter: int
+    n_classes: int
 
 G1_BYTES, G2_BYTES = 64, 128
 

@@ -1,4 +1,9 @@
-"""Point-range sharding of one MSM across ranks (one process per GPU, torch.distributed).
+"""Point-range sharding of the commitment MSMs across ranks (one process per GPU, torch.distributed).
+
+Inside create_proof (zg_prover_set_shard): every rank holds the same witness and a slice of ParamsKZG::g /
+::g_lagrange, multiplies only that slice, and per commitment phase ONE all-gather (make_exchange below) moves the
+128-byte partial sums of all the phase's commitments; every rank adds them up (zg_xyzz_sum_ranks) and goes on with
+the same transcript.  Stand-alone (ShardedBases, msm_sharded): the same for a single MSM.
 
 Rank r registers bases[lo_r:hi_r) once (zg_bases_register) and, per MSM, multiplies its scalar slice;
 the normalised 96-byte partial points are all-gathered (RCCL when the backend is "nccl", i.e. over
@@ -59,3 +64,24 @@ class ShardedBases:
             return self.ctx.msm(self.local, s)
 
         return msm_sharded(local, scalars[self.lo:self.hi], self.group, device)
+
+
+def make_exchange(dist_mod=dist, device=None, group=None):
+    """The all-gather zg_prover_set_shard asks for: exchange(send, recv) with `send` this rank's bytes and `recv`
+    room for world x len(send), rank order.  device = a cuda device: the bytes travel through HBM and RCCL (xGMI
+    between the GPUs of a node); None: gloo on the host."""
+    def exchange(send, recv):
+        world = dist_mod.get_world_size(group)
+        t = torch.frombuffer(send, dtype=torch.uint8).clone()
+        if device is not None:
+            t = t.to(device)
+            out = torch.empty(world * t.numel(), dtype=torch.uint8, device=device)
+            dist_mod.all_gather_into_tensor(out, t, group=group)
+            out = out.cpu()
+        else:
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist_mod.all_gather(parts, t, group=group)
+            out = torch.cat(parts)
+        torch.frombuffer(recv, dtype=torch.uint8).copy_(out)
+
+    return exchange

@@ -68,8 +68,21 @@ ABI_SYMBOLS = [
     "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
     "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
     "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_set_overlap", "zg_ctx_set_msm_latency",
-    "zg_prover_create_shared",
+    "zg_prover_create_shared", "zg_prover_fork", "zg_prover_set_batch", "zg_prover_batch", "zg_prover_advice_slot",
+    "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
+    "zg_grand_product", "zg_xyzz_sum_ranks",
 ]
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
+
+
+def rng_key(seed) -> bytes:
+    """The 32-byte blinding key of a proof: bytes pass through; an int (tests only) becomes its little-endian,
+    zero-padded encoding.  Production callers pass 32 bytes from a CSPRNG (os.urandom(32))."""
+    if isinstance(seed, (bytes, bytearray)):
+        assert len(seed) == 32
+        return bytes(seed)
+    return int(seed).to_bytes(32, "little")
 
 
 class KernelStat(ctypes.Structure):
@@ -131,6 +144,15 @@ def g1_sum(parts: np.ndarray) -> np.ndarray:
     return out
 
 
+def xyzz_sum_ranks(parts: np.ndarray) -> np.ndarray:
+    """parts: uint64[world, count, 16] extended-Jacobian partial sums -> uint64[count, 12] normalised sums."""
+    parts = np.ascontiguousarray(parts, dtype=np.uint64)
+    world, count = parts.shape[0], parts.shape[1]
+    out = np.zeros((count, 12), np.uint64)
+    _check(load().zg_xyzz_sum_ranks(_ptr(parts), c_size_t(world), c_size_t(count), _ptr(out)))
+    return out
+
+
 class Ctx:
     """One GPU (zg_ctx)."""
 
@@ -139,9 +161,20 @@ class Ctx:
         h = c_void_p()
         _check(self.lib.zg_ctx_create(c_int(device), ctypes.byref(h)))
         self.h = h
+        self._children = []  # weak references to the provers created on this context: they must go first
+
+    def _adopt(self, child):
+        import weakref
+
+        self._children.append(weakref.ref(child))
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in self._children:
+                child = ref()
+                if child is not None:
+                    child.close()
+            self._children = []
             self.lib.zg_ctx_destroy(self.h)
             self.h = None
 
@@ -265,6 +298,12 @@ class Ctx:
                                          c_uint32(log_n), _ptr(omega), dv))
 
     # ---- stand-alone prover building blocks (device pointers) ----
+    def grand_product(self, num: np.ndarray, den: np.ndarray, z0: np.ndarray) -> np.ndarray:
+        num, den = _fr(num).reshape(-1, 4), _fr(den).reshape(-1, 4)
+        z = np.zeros_like(num)
+        _check(self.lib.zg_grand_product(self.h, _ptr(num), _ptr(den), _ptr(_fr(z0)), c_size_t(num.shape[0]), _ptr(z)))
+        return z
+
     def grand_product_dev(self, d_num: int, d_den: int, z0: np.ndarray, n: int, d_z: int):
         _check(self.lib.zg_grand_product_dev(self.h, c_void_p(d_num), c_void_p(d_den), _ptr(_fr(z0)), c_size_t(n),
                                              c_void_p(d_z)))
@@ -314,10 +353,10 @@ def keccak256(data: bytes) -> bytes:
 
 
 class Prover:
-    """zg_prover: create_proof for one circuit (circuit.py CircuitImage) on one GPU."""
+    """zg_prover: create_proof for one circuit (circuit.py CircuitImage) on one GPU, one proof or a lock-step batch."""
 
-    def __init__(self, ctx: Ctx, image, fixed_values: np.ndarray, sigma_values: np.ndarray, g, g_lagrange,
-                 vk_repr: np.ndarray):
+    def __init__(self, ctx: Ctx, image, fixed_values: np.ndarray = None, sigma_values: np.ndarray = None, g=None,
+                 g_lagrange=None, vk_repr: np.ndarray = None, _handle=None, _keep=None):
         """g / g_lagrange: uint64[n, 8] host arrays, or two `Bases` handles shared between provers."""
         self.ctx = ctx
         self.image = image
@@ -326,42 +365,120 @@ class Prover:
         lib.zg_prover_proof_size.argtypes = [c_void_p]
         lib.zg_prover_destroy.argtypes = [c_void_p]
         lib.zg_prover_destroy.restype = None
-        fixed_values = np.ascontiguousarray(fixed_values, dtype=np.uint64)
-        sigma_values = np.ascontiguousarray(sigma_values, dtype=np.uint64)
-        h = c_void_p()
-        if isinstance(g, Bases):
-            self._bases = (g, g_lagrange)  # keep the shared tables alive
-            _check(lib.zg_prover_create_shared(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), g.h,
-                                               g_lagrange.h, _ptr(_fr(vk_repr)), ctypes.byref(h)))
+        lib.zg_prover_batch.restype = c_size_t
+        lib.zg_prover_batch.argtypes = [c_void_p]
+        lib.zg_prover_advice_slot.restype = c_void_p
+        lib.zg_prover_advice_slot.argtypes = [c_void_p, c_size_t]
+        self._keep = _keep
+        self._exchange = None
+        if _handle is not None:
+            h = _handle
         else:
-            g = np.ascontiguousarray(g, dtype=np.uint64)
-            g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64)
-            _check(lib.zg_prover_create(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), _ptr(g),
-                                        _ptr(g_lagrange), _ptr(_fr(vk_repr)), ctypes.byref(h)))
+            fixed_values = np.ascontiguousarray(fixed_values, dtype=np.uint64)
+            sigma_values = np.ascontiguousarray(sigma_values, dtype=np.uint64)
+            h = c_void_p()
+            if isinstance(g, Bases):
+                self._bases = (g, g_lagrange)  # keep the shared tables alive
+                _check(lib.zg_prover_create_shared(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), g.h,
+                                                   g_lagrange.h, _ptr(_fr(vk_repr)), ctypes.byref(h)))
+            else:
+                g = np.ascontiguousarray(g, dtype=np.uint64)
+                g_lagrange = np.ascontiguousarray(g_lagrange, dtype=np.uint64)
+                _check(lib.zg_prover_create(ctx.h, image.ptr(), _ptr(fixed_values), _ptr(sigma_values), _ptr(g),
+                                            _ptr(g_lagrange), _ptr(_fr(vk_repr)), ctypes.byref(h)))
         self.h = h
+        ctx._adopt(self)
         self.n = 1 << image.c.k
         self.n_advice = image.c.n_advice
         self.proof_cap = int(lib.zg_prover_proof_size(h))
 
-    def prove(self, advice: np.ndarray, instance: np.ndarray, seed: int) -> bytes:
-        advice = np.ascontiguousarray(advice, dtype=np.uint64)
+    def fork(self, ctx: Ctx) -> "Prover":
+        """Another prover on the same proving key and base tables (no copy), on another context of the device."""
+        h = c_void_p()
+        _check(self.ctx.lib.zg_prover_fork(self.h, ctx.h, ctypes.byref(h)))
+        return Prover(ctx, self.image, _handle=h, _keep=self)
+
+    def set_batch(self, max_batch: int):
+        _check(self.ctx.lib.zg_prover_set_batch(self.h, c_size_t(max_batch)))
+
+    @property
+    def batch(self) -> int:
+        return int(self.ctx.lib.zg_prover_batch(self.h))
+
+    def advice_slot(self, slot: int) -> int:
+        """Device address of the advice columns of proof slot `slot` ([n_advice][2^k] field elements)."""
+        return int(self.ctx.lib.zg_prover_advice_slot(self.h, c_size_t(slot)))
+
+    def set_shard(self, rank: int, world: int, first_point: int, exchange):
+        """exchange(send: bytes-like view, recv: writable view of world * len(send) bytes) = all-gather."""
+        def _cb(_user, send, nbytes, recv):
+            try:
+                src = (ctypes.c_uint8 * nbytes).from_address(send)
+                dst = (ctypes.c_uint8 * (nbytes * world)).from_address(recv)
+                exchange(src, dst)
+                return 0
+            except Exception:  # noqa: BLE001 -- nothing may propagate through the C frames
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._exchange = EXCHANGE_FN(_cb) if world > 1 else None
+        fn = self._exchange if self._exchange is not None else ctypes.cast(None, EXCHANGE_FN)
+        _check(self.ctx.lib.zg_prover_set_shard(self.h, c_uint32(rank), c_uint32(world), c_size_t(first_point), fn, None))
+
+    @staticmethod
+    def _inst(instance):
         instance = np.ascontiguousarray(instance, dtype=np.uint64)
         inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0
+        return instance, inst_len
+
+    def prove(self, advice: np.ndarray, instance: np.ndarray, seed) -> bytes:
+        advice = np.ascontiguousarray(advice, dtype=np.uint64)
+        instance, inst_len = self._inst(instance)
         buf = (ctypes.c_uint8 * self.proof_cap)()
         plen = c_size_t(0)
-        _check(self.ctx.lib.zg_prover_prove(self.h, _ptr(advice), _ptr(instance), c_size_t(inst_len),
-                                            ctypes.c_uint64(seed), buf, c_size_t(self.proof_cap), ctypes.byref(plen)))
+        _check(self.ctx.lib.zg_prover_prove(self.h, _ptr(advice), _ptr(instance), c_size_t(inst_len), rng_key(seed), buf,
+                                            c_size_t(self.proof_cap), ctypes.byref(plen)))
         return bytes(buf[: plen.value])
 
-    def prove_dev(self, d_advice: int, instance: np.ndarray, seed: int) -> bytes:
-        instance = np.ascontiguousarray(instance, dtype=np.uint64)
-        inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0
+    def prove_dev(self, d_advice: int, instance: np.ndarray, seed) -> bytes:
+        instance, inst_len = self._inst(instance)
         buf = (ctypes.c_uint8 * self.proof_cap)()
         plen = c_size_t(0)
         _check(self.ctx.lib.zg_prover_prove_dev(self.h, c_void_p(d_advice), _ptr(instance), c_size_t(inst_len),
-                                                ctypes.c_uint64(seed), buf, c_size_t(self.proof_cap),
-                                                ctypes.byref(plen)))
+                                                rng_key(seed), buf, c_size_t(self.proof_cap), ctypes.byref(plen)))
         return bytes(buf[: plen.value])
+
+    def prove_batch(self, advice, instances, seeds, device=False, raise_on_error=True):
+        """count = len(seeds) proofs in lock step.  advice: list of host arrays (device=False) or device addresses
+        (device=True); None entries (or advice=None) = the slot already holds the columns.  Returns (proofs, statuses)."""
+        count = len(seeds)
+        lib = self.ctx.lib
+        keep = []
+        if advice is None:
+            adv_ptrs = None
+        elif device:
+            adv_ptrs = (c_void_p * count)(*[c_void_p(a) if a else None for a in advice])
+        else:
+            keep = [np.ascontiguousarray(a, dtype=np.uint64) if a is not None else None for a in advice]
+            adv_ptrs = (c_void_p * count)(*[c_void_p(a.ctypes.data) if a is not None else None for a in keep])
+        insts, inst_len = [], 0
+        for b in range(count):
+            i, inst_len = self._inst(instances[b])
+            insts.append(i)
+        inst_ptrs = (c_void_p * count)(*[c_void_p(i.ctypes.data) for i in insts])
+        keys = b"".join(rng_key(s) for s in seeds)
+        bufs = [(ctypes.c_uint8 * self.proof_cap)() for _ in range(count)]
+        out_ptrs = (c_void_p * count)(*[ctypes.addressof(b) for b in bufs])
+        lens = (c_size_t * count)()
+        sts = (c_int * count)()
+        fn = lib.zg_prover_prove_batch_dev if device else lib.zg_prover_prove_batch
+        st = fn(self.h, c_size_t(count), adv_ptrs, inst_ptrs, c_size_t(inst_len), keys, out_ptrs,
+                c_size_t(self.proof_cap), lens, sts)
+        if st != 0 and raise_on_error:
+            _check(st)
+        return [bytes(bufs[b][: lens[b]]) for b in range(count)], list(sts)
 
     def set_overlap(self, enable: bool):
         """True (default): transforms on a side stream (latency); False: one stream per proof (throughput)."""
@@ -372,9 +489,10 @@ class Prover:
         _check(self.ctx.lib.zg_prover_phase_ms(self.h, out, c_size_t(8)))
         return list(out)
 
-    def fetch(self, what: int, index: int, count: int) -> np.ndarray:
+    def fetch(self, what: int, index: int, count: int, slot: int = 0) -> np.ndarray:
         out = np.zeros((count, 4), np.uint64)
-        _check(self.ctx.lib.zg_prover_fetch(self.h, c_uint32(what), c_uint32(index), _ptr(out), c_size_t(count)))
+        _check(self.ctx.lib.zg_prover_fetch_slot(self.h, c_size_t(slot), c_uint32(what), c_uint32(index), _ptr(out),
+                                                 c_size_t(count)))
         return out
 
     def close(self):

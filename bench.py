@@ -1,40 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- create_proof of zero_g's WNN circuit on MI355X (BASELINE.json metric).
 
-A "step" is one batch of `--streams` (default 16) full create_proofs, one per proof stream of the GPU,
-all in flight together; K steps = K x streams proofs, and value = proofs / hour.  One create_proof
-(zg_prover_prove_dev) goes from the assigned advice columns, resident in HBM, to the proof bytes -- 30
-commitment MSMs, 21 iNTT + 21 coset NTT + 1 extended iNTT, the 4 lookup arguments (compression,
-permutation, grand products), the 2-set permutation argument, evaluate_h over the 2^17-point extended
-coset, 67 polynomial evaluations, the 4 GWC openings and the Keccak-256 EvmTranscript -- for zero_g's
-WnnCircuit of model_28input_256entry_1hash_1bpi (k = 14) on benches/example_image_7.png: the real
-constraint system and the real inference witness (0g-halo2_amd/wnn_circuit.py restates WnnChip; the
-class scores it proves are the reference's snapshot, tests/test_wnn_circuit.py).  The SRS tables, the
-proving key (fixed / sigma polynomials and cosets) and the witness are in HBM before the timed region,
-as in the reference's own bench (benches/bench.rs:30-36 times only `wnn.proof`).
+A "step" is `--provers` (default 2) lock-step batches of `--batch` (default 16) full create_proofs each: every
+prover works on its own HIP stream from its own host thread (while one batch waits for its transcript hashes on
+the host, the other keeps the GPU busy) and makes its B proofs with ONE launch sequence (zg_prover_prove_batch: the
+commitments of a phase are one MSM over B x columns vectors, evaluate_h one grid with a row of workgroups per
+proof, ...).  K steps = K x provers x batch proofs, and value = proofs / hour.  One create_proof goes from the
+assigned advice columns, resident in HBM, to the proof bytes -- 30 commitment MSMs, 21 iNTT + 21 coset NTT + 1
+extended iNTT, the 4 lookup arguments (compression, permutation, grand products), the 2-set permutation argument,
+evaluate_h over the extended domain, 67 polynomial evaluations, the 4 GWC openings and the Keccak-256
+EvmTranscript -- for zero_g's WnnCircuit of model_28input_256entry_1hash_1bpi (k = 14) on
+benches/example_image_7.png: the real constraint system and the real inference witness
+(harness/wnn_circuit.py restates WnnChip; the class scores it proves are the reference's snapshot,
+tests/test_wnn_circuit.py).  The SRS tables, the proving key (fixed / sigma polynomials and cosets, ONE copy shared
+by the provers) and the witness are in HBM before the timed region, as in the reference's own bench
+(benches/bench.rs:30-36 times only `wnn.proof`).  What is timed is what is checked: after the timed region the proofs
+of the last step are compared byte for byte with the oracle's and pairing-verified ("verified" in the line).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1 via torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W [--mode replicas|shard-msm]   (N > 1 via torch.distributed.run)
 
-Prints ONE JSON line (rank 0).  value = proofs/hour over all ranks.  N > 1 runs independent proofs
-per GPU (weak scaling, no data-path collective: proofs do not shard below the MSM, and a 2^14-point
-MSM is too small to split -- SURVEY.md 8e / DESIGN.md); the sharded-MSM path is exercised by
-tests/test_multi_gpu.py.
+Prints ONE JSON line (rank 0).  value = proofs/hour over all ranks.
+  --mode replicas (default): N > 1 runs independent proofs per GPU (weak scaling, no data-path collective).
+  --mode shard-msm: the commitments of every proof are sharded by point range over the N GPUs
+      (zg_prover_set_shard: each rank multiplies its slice of ParamsKZG::g / ::g_lagrange, one all-gather of the
+      partial sums per commitment phase over RCCL, local EC additions); transforms and evaluate_h stay per GPU, every
+      rank ends with the same proof bytes.  Strong scaling of the MSM share of a proof only.
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
-# ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the
-# proof streams (main + side stream each) need their own queues or they serialise behind each other.
-# Must be set before the HIP runtime initialises (i.e. before torch touches the GPU).
-# 16 proof streams -> 16 queues; RCCL (N > 1: barrier + max over ranks) brings streams of its own, and
-# with them 20 queues measure best (tools/sweep_dist.sh: 16 -> 2.06, 20 -> 1.77, 24 -> 1.90 ms/proof).
-_dist = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ZG_BENCH_FORCE_DIST") == "1"
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "20" if _dist else "16")
+sys.path.insert(0, os.path.join(ROOT, "harness"))
+# ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); every prover stream
+# should have a queue of its own, next to torch's and RCCL's.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
 import torch
@@ -45,10 +49,15 @@ import zg_halo2 as zg
 
 R = zg.FR_MODULUS
 MONT = (1 << 256) % R
+PROFILES = os.path.join(ROOT, "profiles", "r02")
 # the four configurations of BASELINE.json: (k, model); "large" is a seeded stand-in of the same shape
 # because model_49input_8192entry_4hash_6bpi.hdf5 is not in the reference checkout (.MISSING_LARGE_BLOBS)
 MODELS = {"tiny": wnn_model.MNIST_TINY, "small": wnn_model.MNIST_SMALL, "medium": wnn_model.MNIST_MEDIUM,
           "large": wnn_model.MNIST_LARGE}
+# chip constants (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E peak; a SIMD issues one wave64 VALU instruction
+# every 2 cycles (SIMD-32 datapath), 256 CUs x 4 SIMDs at 2.4 GHz
+HBM_PEAK_GBPS = 8000.0
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2
 
 
 def limbs(x):
@@ -65,13 +74,14 @@ def host_cores() -> int:
 
 
 class Circuit:
-    """Host-side material shared by every proof stream: circuit image, pk values, witness, SRS."""
+    """Host-side material of one model: circuit image, pk values, witness, SRS (point range [lo, hi) of it)."""
 
-    def __init__(self, ctx: zg.Ctx, model: str):
+    def __init__(self, ctx: zg.Ctx, model: str, shard=(0, 1)):
         self.k, self.model_name = MODELS[model]
+        self.model = model
         wnn = wnn_model.synthetic_wnn() if model == "large" else wnn_model.load_checked_in(self.model_name)
         # zero_g's WnnCircuit for this model, synthesised on benches/example_image_7.png: the real
-        # constraint system, fixed / sigma columns and witness (wnn_circuit.py restates WnnChip)
+        # constraint system, fixed / sigma columns and witness (harness/wnn_circuit.py restates WnnChip)
         self.cs, self.asg, self.ilen, self.scores = wnn_circuit.build(
             wnn, wnn_model.load_test_image(), self.k, compress_selectors=os.environ.get("ZG_BENCH_NO_SELECTOR_COMPRESSION") != "1")
         k = self.k
@@ -82,31 +92,65 @@ class Circuit:
         self.vk_repr = np.array(limbs(0xC0FFEE * MONT % R), dtype=np.uint64)
         self.s = np.array(limbs(0x5EED5EED5EED5EED * MONT % R), dtype=np.uint64)
         self.g, self.gl = ctx.params_new(k, self.s)  # ParamsKZG::new(k) on the GPU
-        # one read-only copy of the MSM window tables per device, shared by every proof stream
-        self.g_bases = ctx.register_bases(self.g)
-        self.gl_bases = ctx.register_bases(self.gl)
+        rank, world = shard
+        n = 1 << k
+        self.lo, self.hi = rank * n // world, (rank + 1) * n // world
+        # one read-only copy of the MSM window tables per device, shared by every prover
+        self.g_bases = ctx.register_bases(self.g[self.lo:self.hi])
+        self.gl_bases = ctx.register_bases(self.gl[self.lo:self.hi])
 
 
-class ProofJob:
-    """One proof stream: its own context (HIP stream + workspace) and prover, pk + witness resident
-    in HBM; step() = one create_proof."""
+class Stream:
+    """One proof stream: a prover (own context = own HIP stream + workspace; proving key shared with the others) with
+    `batch` slots whose advice columns are resident in HBM; step() = one lock-step batch of create_proofs."""
 
-    def __init__(self, ctx: zg.Ctx, dev: torch.device, c: Circuit, stream_id: int):
-        self.ctx, self.c, self.k, self.cs = ctx, c, c.k, c.cs
-        self.prover = zg.Prover(ctx, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
-        self.prover.set_overlap(False)  # throughput configuration: one HIP stream per proof
-        self.d_advice = torch.from_numpy(c.advice.view(np.int64)).to(dev)
-        torch.cuda.synchronize(dev)
-        self.instance = c.instance
-        self.seed = 1000 * stream_id
-        self.last = b""
+    def __init__(self, ctx: zg.Ctx, prover: zg.Prover, c: Circuit, batch: int, stream_id: int, exchange=None, shard=(0, 1)):
+        self.ctx, self.prover, self.c, self.batch = ctx, prover, c, batch
+        prover.set_batch(batch)
+        prover.set_overlap(False)  # throughput configuration: one HIP stream per prover, split extended domain
+        if shard[1] > 1:
+            prover.set_shard(shard[0], shard[1], c.lo, exchange)
+        # the witness into every slot, once: a proof rewrites only the last blinding_factors+1 rows of its advice
+        # columns and reads the rest, so the slots can be proved from again (inputs resident in HBM, as the contract asks)
+        self.seed0 = 1_000_000 * stream_id
+        self.steps = 0
+        self.last = self.prover.prove_batch([c.advice] * batch, [c.instance] * batch, self.seeds())[0]
+
+    def seeds(self):
+        return [self.seed0 + 1000 * self.steps + b for b in range(self.batch)]
 
     def step(self):
-        # the last blinding_factors+1 rows of every advice column are rewritten by each proof, the
-        # other rows are only read: the buffer can be proved from again without a fresh copy
-        self.seed += 1
-        self.last = self.prover.prove_dev(self.d_advice.data_ptr(), self.instance, self.seed)
+        self.steps += 1
+        self.last_seeds = self.seeds()
+        self.last = self.prover.prove_batch(None, [self.c.instance] * self.batch, self.last_seeds, device=True)[0]
         return self.last
+
+
+def make_streams(dev_index: int, c: Circuit, ctx0: zg.Ctx, nprovers: int, batch: int, rank: int, exchange=None, shard=(0, 1)):
+    ctxs = [ctx0] + [zg.Ctx(dev_index) for _ in range(nprovers - 1)]
+    first = zg.Prover(ctx0, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
+    provers = [first] + [first.fork(x) for x in ctxs[1:]]
+    return ctxs, [Stream(ctxs[i], provers[i], c, batch, rank * 64 + i, exchange, shard) for i in range(nprovers)]
+
+
+def run_steps(streams, steps):
+    """`steps` batches per stream, one host thread per stream (ctypes drops the GIL inside the library)."""
+    errors = []
+
+    def work(s):
+        try:
+            for _ in range(steps):
+                s.step()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=work, args=(s,)) for s in streams]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if errors:
+        raise errors[0]
 
 
 def algorithmic_bytes_per_proof(cs) -> float:
@@ -126,28 +170,28 @@ def algorithmic_bytes_per_proof(cs) -> float:
     return float(msm + intt + ext + ext_inv + gp + eh)
 
 
-def valu_utilisation(ms_per_proof: float):
-    """VALU issue utilisation: wave-instructions one proof issues (rocprofv3 --pmc SQ_INSTS_VALU, committed
-    under profiles/) per second, against the chip's issue rate of one wave-instruction per SIMD every 4
-    cycles (256 CUs x 4 SIMDs x 2.4 GHz / 4).  The multiply-adds that dominate (v_mad_u64_u32 /
-    v_mad_i64_i32) occupy the pipe ~1.5x longer than that, so the true pipe occupancy is higher."""
+FAMILIES = {"msm": ("msm_",), "ntt": ("ntt_",), "evaluate_h": ("evaluate_h",), "sort": ("sort_", "permute_"),
+            "products": ("grand_product", "lookup_", "perm_terms", "permuted_finish", "blind_rows", "random_poly"),
+            "openings": ("eval_dot", "powers", "horner_combine", "kate_", "fold", "diff_scale", "split_combine")}
+
+
+def family_of(kernel: str) -> str:
+    for fam, prefixes in FAMILIES.items():
+        if kernel.startswith(prefixes):
+            return fam
+    return "other"
+
+
+def load_pmc():
+    """Counter figures of the same configuration (rocprofv3 --pmc passes, tools/pmc_round.py; committed under
+    profiles/r02): HBM bytes per launch per kernel and VALU wave-instructions per proof."""
     try:
-        v = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["valu"]
-        per_proof = float(v["wave_instructions_per_proof"])
-    except (OSError, KeyError, ValueError):
+        return json.load(open(os.path.join(PROFILES, "pmc_traffic.json")))
+    except (OSError, ValueError):
         return None
-    peak = 256 * 4 * 2.4e9 / 4
-    # tools/microbench.hip on this chip: a full-rate VALU op (v_add_co_u32) sustains 3.13e13 lane-ops/s =
-    # 4.9e11 wave-instructions/s (the clock under load is ~1.9 GHz, not 2.4); v_mad_u64_u32 / v_mad_i64_i32
-    # run at 0.87x that
-    measured_peak = 31263.2e9 / 64
-    achieved = per_proof / (ms_per_proof * 1e-3)
-    return {"wave_instructions_per_proof": per_proof, "achieved_wave_instr_per_s": achieved,
-            "issue_peak_wave_instr_per_s": peak, "frac": achieved / peak,
-            "measured_issue_peak_wave_instr_per_s": measured_peak, "frac_of_measured_peak": achieved / measured_peak}
 
 
-def cpu_baseline(job: ProofJob, threads: int):
+def cpu_baseline(c: Circuit, proof_len: int, threads: int):
     """The oracle's create_proof (CPU restatement of halo2's algorithms, OpenMP over MSM chunks, FFT
     butterflies and row loops) timed on this box's host cores on the SAME circuit and witness (its own
     seeded SRS of the same size).  kind = "port": halo2's own Rust prover cannot be built here (no cargo/rustc)."""
@@ -155,19 +199,76 @@ def cpu_baseline(job: ProofJob, threads: int):
     import orc
 
     orc.load().orc_set_threads(threads)
-    c = job.c
-    params = orc.params_new(job.k, 0x5EED)
+    params = orc.params_new(c.k, 0x5EED)
     pk = orc.ProvingKey(c.img, c.fixed, c.sigma, params, c.vk_repr)
     t0 = time.perf_counter()
     st, proof, _ = orc.create_proof(pk, c.advice, c.instance, 1)
     dt = time.perf_counter() - t0
-    assert st == 0 and len(proof) == len(job.last)
+    assert st == 0 and len(proof) == proof_len
     return {
         "value": 3600.0 / dt, "unit": "proofs/hour", "cores": threads, "kind": "port",
-        "sample": f"1 full create_proof of the same k={job.k} circuit in {dt:.2f} s: oracle/prover.c "
+        "sample": f"1 full create_proof of the same k={c.k} circuit in {dt:.2f} s: oracle/prover.c "
                   f"(plain-C restatement of halo2 create_proof, OpenMP {threads} threads)",
         "wall_s": dt,
     }
+
+
+def verify_last_step(c: Circuit, streams, threads: int) -> dict:
+    """What was timed is what is checked: the proofs the streams made in the LAST timed step against the oracle --
+    byte for byte for the first and the last proof of stream 0's batch and the first of every other stream, the public
+    pairing equation for one of them.  (The oracle's SRS is rebuilt from the bench's toxic scalar.)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orc
+
+    orc.load().orc_set_threads(threads)
+    params = orc.params_from_scalar(c.k, c.s)
+    pk = orc.ProvingKey(c.img, c.fixed, c.sigma, params, c.vk_repr)
+    checked = 0
+    picks = [(0, 0), (0, streams[0].batch - 1)] + [(i, 0) for i in range(1, len(streams))]
+    for i, b in dict.fromkeys(picks):
+        s = streams[i]
+        st, want, _ = orc.create_proof(pk, c.advice, c.instance, s.last_seeds[b])
+        if st != 0 or want != s.last[b]:
+            return {"verified": False, "detail": f"stream {i} proof {b} differs from the oracle"}
+        checked += 1
+    pick = streams[-1].last[-1]
+    if orc.verify_proof_pairing(pk, c.instance, pick) != 1:
+        return {"verified": False, "detail": "pairing check failed"}
+    return {"verified": True, "detail": f"{checked} proofs of the last timed step byte-identical to the oracle's, 1 pairing-verified"}
+
+
+def measure(streams, ctxs, steps, warmup, barrier, profile=False):
+    run_steps(streams, max(warmup, 1))
+    for x in ctxs:
+        x.profile(profile)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(streams, steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    stats = {}
+    for x in ctxs:
+        if profile:
+            for name, (l, ms, by) in x.profile_collect().items():
+                a = stats.get(name, (0, 0.0, 0.0))
+                stats[name] = (a[0] + l, a[1] + ms, a[2] + by)
+        x.profile(False)
+    return dt, stats
+
+
+def latency_probe(stream: Stream):
+    """One proof alone: transforms overlapped on a side stream, several lanes per EC addition (set_overlap(True))."""
+    p, c = stream.prover, stream.c
+    p.set_overlap(True)
+    for _ in range(2):
+        p.prove_dev(p.advice_slot(0), c.instance, 1)
+    t0 = time.perf_counter()
+    for i in range(3):
+        p.prove_dev(p.advice_slot(0), c.instance, 2 + i)
+    latency_s = (time.perf_counter() - t0) / 3
+    phases = p.phase_ms()
+    p.set_overlap(False)
+    return latency_s, phases
 
 
 def main():
@@ -177,11 +278,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", choices=sorted(MODELS), default="tiny",
                     help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
-    ap.add_argument("--streams", type=int, default=16,
-                    help="proofs per step = independent proofs in flight per GPU (each on its own HIP stream)")
+    ap.add_argument("--batch", type=int, default=16, help="proofs per lock-step batch (zg_prover_prove_batch)")
+    ap.add_argument("--provers", type=int, default=2, help="proof streams per GPU (provers sharing one proving key)")
+    ap.add_argument("--mode", choices=["replicas", "shard-msm"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true",
-                    help="no HIP events on the dominant kernel's launches in the timed region (no roofline object)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other three models")
+    ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -210,144 +313,162 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    import threading
+    sharded = args.mode == "shard-msm" and world > 1
+    shard = (rank, world) if sharded else (0, 1)
+    nprov = 1 if sharded else max(1, args.provers)  # (the exchange is a collective: one stream of batches per rank)
+    batch = max(1, args.batch)
+    exchange = None
+    if sharded:
+        import multi_gpu
 
-    nstreams = max(1, args.streams)
-    ctxs = [zg.Ctx(local_rank) for _ in range(nstreams)]
-    circuit = Circuit(ctxs[0], args.model)
-    jobs = [ProofJob(ctxs[i], dev, circuit, rank * 64 + i) for i in range(nstreams)]
-    job = jobs[0]
+        exchange = multi_gpu.make_exchange(dist, dev)
+
+    ctx0 = zg.Ctx(local_rank)
+    circuit = Circuit(ctx0, args.model, shard)
+    ctxs, streams = make_streams(local_rank, circuit, ctx0, nprov, batch, rank, exchange, shard)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        for c in ctxs:
-            c.sync()
+        for x in ctxs:
+            x.sync()
 
-    def run(steps):
-        """`steps` batches: every proof stream proves `steps` witnesses back to back, one host thread
-        per stream (ctypes drops the GIL inside the library; streams do not wait for each other)."""
-
-        def work(j, cnt):
-            for _ in range(cnt):
-                j.step()
-
-        th = [threading.Thread(target=work, args=(jobs[i], steps)) for i in range(nstreams)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-
-    run(max(args.warmup, 1))
-    # single-proof latency: one stream alone (transforms overlapped on its side stream), a few proofs;
-    # with every launch timed by HIP events once, to learn the per-kernel split and which dominates
-    job.prover.set_overlap(True)
-    for _ in range(2):
-        job.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        job.step()
-    latency_s = (time.perf_counter() - t0) / 3
-    phases = job.prover.phase_ms()
-    ctxs[0].profile(True)
-    for _ in range(2):
-        job.step()
-    split = ctxs[0].profile_collect()
-    ctxs[0].profile(False)
-    # the kernel the roofline object describes: the bucket accumulation of the MSM (most field products
-    # and most algorithmic bytes of a proof; the top kernel of the rocprofv3 summaries under load).  A lone
-    # proof's device-time split can put a latency-bound reduction kernel (a few workgroups) level with
-    # it, so the choice is pinned unless another kernel clearly exceeds it.
-    top = max(split.items(), key=lambda kv: kv[1][1])[0]
-    dominant = "msm_accumulate"
-    if dominant not in split or split[top][1] > 1.5 * split[dominant][1]:
-        dominant = top
-    job.prover.set_overlap(False)  # throughput configuration: one HIP stream per proof
-    # timed region: only the dominant kernel's dispatches carry a start / stop event (on the proof's own
-    # stream, hipExtLaunchKernelGGL); timing all ~150 launches of a proof costs ~0.7 ms of host time per proof
-    for c in ctxs:
-        c.profile_filter(dominant)
-        c.profile(not args.no_kernel_events)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    stats = {}
-    for c in ctxs:
-        for name, (l, ms, by) in c.profile_collect().items():
-            a = stats.get(name, (0, 0.0, 0.0))
-            stats[name] = (a[0] + l, a[1] + ms, a[2] + by)
-        c.profile(False)
-        c.profile_filter(None)
-
+    latency_s, phases = latency_probe(streams[0]) if not sharded else (None, [0.0] * 8)
+    # timed region: every launch carries its own start / stop event (hipExtLaunchKernelGGL on the prover's stream): a
+    # lock-step batch is ~100 launches for `batch` proofs, so timing them all costs nothing measurable
+    dt, stats = measure(streams, ctxs, args.steps, args.warmup, barrier, profile=not args.no_kernel_events)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    out = None
     if rank == 0:
+        proofs_per_step = nprov * batch
+        n_proofs = args.steps * proofs_per_step * (1 if sharded else world)
         ms_per_step = dt / args.steps * 1e3
-        ms_per_proof = ms_per_step / nstreams
-        proofs_per_hour = world * args.steps * nstreams / dt * 3600.0
-        # dominant kernel by device time: its algorithmic bytes per launch / its average duration
-        if not stats:
-            stats = {"(kernel events disabled)": (1, 0.0, 0.0)}
-        name, (launches, total_ms, abytes) = max(stats.items(), key=lambda kv: kv[1][1])
-        avg_ms = total_ms / max(launches, 1)
-        achieved = (abytes / max(launches, 1)) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = None
-        try:  # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/, separate runs)
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))["kernels"]
-            if args.model == "tiny" and name in pmc:
-                traffic = pmc[name]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
-        roofline = {
-            "bound": "hbm", "kernel": name, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_ms": avg_ms,
-            "launches_per_proof": launches / (args.steps * nstreams),
-            "note": "BASELINE asks for the HBM roofline; the kernels are integer-ALU bound "
-                    "(254-bit Montgomery products), see DESIGN.md",
-        }
-        kernel_ms = sum(v[1] for v in split.values()) / 2
+        ms_per_proof = dt / (args.steps * proofs_per_step) * 1e3
+        proofs_per_hour = n_proofs / dt * 3600.0
+        pmc = load_pmc() if args.model == "tiny" and not sharded else None
+        launches_per_proof = sum(v[0] for v in stats.values()) / max(1, args.steps * proofs_per_step)
+        # per kernel and per family: device time, algorithmic bytes (DESIGN.md's per-unit figures x units per launch),
+        # algorithmic GB/s against the HBM peak, counter bytes / algorithmic bytes
+        kernels, fam = {}, {}
+        for name, (l, ms, by) in stats.items():
+            k_pmc = (pmc or {}).get("kernels", {}).get(name)
+            kernels[name] = {"launches": l, "total_ms": round(ms, 3), "avg_launch_ms": ms / max(l, 1),
+                             "algo_bytes_per_launch": by / max(l, 1),
+                             "algo_GBps": (by / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
+                             "hbm_bytes_per_launch": k_pmc["hbm_bytes_per_launch"] if k_pmc else None}
+            f = fam.setdefault(family_of(name), {"total_ms": 0.0, "algo_bytes": 0.0, "hbm_bytes": 0.0, "hbm_known": True})
+            f["total_ms"] += ms
+            f["algo_bytes"] += by
+            if k_pmc:
+                f["hbm_bytes"] += k_pmc["hbm_bytes_per_launch"] * l
+            else:
+                f["hbm_known"] = False
+        device_ms = sum(v[1] for v in stats.values())
+        families = {}
+        for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["total_ms"]):
+            gbps = f["algo_bytes"] / (f["total_ms"] * 1e-3) / 1e9 if f["total_ms"] > 0 else 0.0
+            families[name] = {"share_of_device_time": f["total_ms"] / device_ms if device_ms else 0.0,
+                              "algo_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+                              "counter_over_algorithmic_bytes": (f["hbm_bytes"] / f["algo_bytes"]) if f["hbm_known"] and f["algo_bytes"] else None}
+        roofline = None
+        if stats:
+            # the dominant kernel = the one with the largest device time in THIS run's timed region
+            name = max(stats.items(), key=lambda kv: kv[1][1])[0]
+            kd = kernels[name]
+            achieved = kd["algo_bytes_per_launch"] / (kd["avg_launch_ms"] * 1e-3) / 1e9 if kd["avg_launch_ms"] > 0 else 0.0
+            roofline = {
+                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": kd["hbm_bytes_per_launch"],
+                "avg_launch_ms": kd["avg_launch_ms"], "algo_bytes_per_launch": kd["algo_bytes_per_launch"],
+                "share_of_device_time": kd["total_ms"] / device_ms if device_ms else 0.0,
+                "launches_per_proof": kd["launches"] / (args.steps * proofs_per_step),
+                "proofs_per_launch": batch,
+                "families": families,
+                "note": "BASELINE asks for the HBM roofline; the kernels are integer-ALU bound "
+                        "(254-bit Montgomery products), see DESIGN.md and `valu`",
+            }
+        valu = None
+        if pmc and "valu" in pmc:
+            per_proof = float(pmc["valu"]["wave_instructions_per_proof"])
+            ach = per_proof / (ms_per_proof * 1e-3)
+            valu = {"wave_instructions_per_proof": per_proof, "achieved_wave_instr_per_s": ach,
+                    "issue_peak_wave_instr_per_s": VALU_ISSUE_PEAK, "frac": ach / VALU_ISSUE_PEAK,
+                    "peak_note": "one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32), 256 CUs x 4 SIMDs x 2.4 GHz",
+                    "v_add_co_u32_stream_rate_wave_instr_per_s": 31263.2e9 / 64,
+                    "frac_of_v_add_co_u32_stream_rate": ach / (31263.2e9 / 64),
+                    "source": pmc["valu"].get("source")}
+        cs = circuit.cs
         out = {
             "metric": f"create_proof proofs/hour, {circuit.model_name}",
             "value": proofs_per_hour, "unit": "proofs/hour", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)",
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)",
             "data": ("checked-in model + benches/example_image_7.png (fixtures from the reference checkout), "
                      "seeded SRS" if args.model != "large" else "synthetic (seeded stand-in model), seeded SRS"),
             "config": {"workload": f"full create_proof of zero_g's WnnCircuit for {circuit.model_name} on "
-                                   f"example_image_7.png ({job.cs.n_advice} advice, {job.cs.n_fixed} fixed, {len(job.cs.gates)} gates, "
-                                   f"{len(job.cs.lookups)} lookups, {len(job.cs.perm_columns)} equality columns, degree {job.cs.degree()}), "
-                                   f"k={circuit.k}, EvaluationDomain's extended domain 2^{job.cs.extended_k()} (the throughput form "
-                                   f"takes the same quotient from {job.cs.degree() - 1}n points on two cosets), proof {len(job.last)} B"
+                                   f"example_image_7.png ({cs.n_advice} advice, {cs.n_fixed} fixed, {len(cs.gates)} gates, "
+                                   f"{len(cs.lookups)} lookups, {len(cs.perm_columns)} equality columns, degree {cs.degree()}), "
+                                   f"k={circuit.k}, EvaluationDomain's extended domain 2^{cs.extended_k()} (the throughput form "
+                                   f"takes the same quotient from {cs.degree() - 1}n points on two cosets), proof {len(streams[0].last[0])} B"
                                    + (" [seeded stand-in model: the file is absent from the reference]"
                                       if args.model == "large" else ""),
                        "class_scores": circuit.scores,
-                       "proofs_per_step": nstreams,
-                       "parallelism": f"{world} GPU(s) x {nstreams} independent proof stream(s) per GPU"},
-            "proofs_per_step": nstreams, "ms_per_proof": ms_per_proof,
-            "create_proof_wall_s": latency_s,
-            "streams_per_gpu": nstreams,
-            "algorithmic_GBps": algorithmic_bytes_per_proof(job.cs) / (ms_per_proof * 1e-3) / 1e9,
-            "single_proof_gpu_kernel_ms": kernel_ms,
-            "roofline": roofline,
-            # the kernels are VALU-bound: measured instruction count per proof against the issue rate
-            "valu": valu_utilisation(ms_per_proof) if args.model == "tiny" else None,
-            "single_proof_kernels_ms": {k_: round(v[1] / 2, 4)
-                                        for k_, v in sorted(split.items(), key=lambda kv: -kv[1][1])},
+                       "proofs_per_step": proofs_per_step,
+                       "parallelism": (f"{world} GPU(s), commitments sharded by point range (one all-gather per phase), "
+                                       f"1 lock-step batch of {batch} proofs in flight" if sharded else
+                                       f"{world} GPU(s) x {nprov} prover stream(s) x lock-step batches of {batch} proofs")},
+            "mode": args.mode if world > 1 else "single-gpu",
+            "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
+            "create_proof_wall_s": latency_s, "provers_per_gpu": nprov, "batch": batch,
+            "launches_per_proof": launches_per_proof,
+            "algorithmic_GBps": algorithmic_bytes_per_proof(cs) / (ms_per_proof * 1e-3) / 1e9,
+            "device_ms_per_proof": device_ms / max(1, args.steps * proofs_per_step),
+            "roofline": roofline, "valu": valu,
+            "kernels": {k_: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "share": round(v["total_ms"] / device_ms, 4) if device_ms else 0,
+                             "algo_GBps": round(v["algo_GBps"], 1), "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
+                        for k_, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])},
             "single_proof_phase_ms": dict(zip(["advice", "lookups_permuted", "products", "h", "evals", "gwc",
                                                "total", "host_sort"], [round(x, 3) for x in phases])),
         }
+        if not args.no_verify:
+            out.update(verify_last_step(circuit, streams, host_cores()) if not sharded else
+                       verify_last_step_sharded(circuit, streams, host_cores()))
+    # the other three models of BASELINE.json: a few steps each, same driver (after the headline's timed region)
+    if not args.no_other_configs and not sharded and args.model == "tiny" and world == 1:
+        others = {}
+        for s in streams:
+            s.prover.close()
+        for m in ("small", "medium", "large"):
+            c2 = Circuit(ctx0, m)
+            b2 = batch if m != "large" else max(1, batch // 2)
+            cx, st2 = make_streams(local_rank, c2, ctx0, nprov, b2, rank)
+            lat, _ = latency_probe(st2[0])
+            dt2, _ = measure(st2, cx, 3, 1, barrier)
+            others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * nprov * b2) * 1e3,
+                         "create_proof_wall_s": lat, "batch": b2, "provers": nprov,
+                         "proofs_per_hour": 3 * nprov * b2 / dt2 * 3600.0}
+            for s in st2:
+                s.prover.close()
+            c2.g_bases.free()
+            c2.gl_bases.free()
+            for x in cx[1:]:
+                x.close()
+        out["other_configs"] = others
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(job, host_cores())
+            out["cpu_baseline"] = cpu_baseline(circuit, len(streams[0].last[0]), host_cores())
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def verify_last_step_sharded(c: Circuit, streams, threads: int) -> dict:
+    return verify_last_step(c, streams, threads)
 
 
 if __name__ == "__main__":

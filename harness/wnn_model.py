@@ -9,9 +9,10 @@ from __future__ import annotations
 
 import math
 import os
-from dataclasses import dataclass
 
 import numpy as np
+
+from formats import WnnCircuitParams  # the product package's on-disk formats own this record (io.rs:149-156)
 
 ATTRS = ["num_classes", "num_inputs", "bits_per_input", "num_filter_inputs", "num_filter_entries",
          "num_filter_hashes", "p"]
@@ -21,17 +22,6 @@ MNIST_TINY = (14, "model_28input_256entry_1hash_1bpi")
 MNIST_SMALL = (15, "model_28input_1024entry_2hash_2bpi")
 MNIST_MEDIUM = (15, "model_28input_2048entry_2hash_3bpi")
 MNIST_LARGE = (17, "model_49input_8192entry_4hash_6bpi")  # file absent from the reference checkout
-
-
-@dataclass
-class WnnCircuitParams:
-    """gadgets/wnn.rs `WnnCircuitParams` as filled by Wnn::get_circuit_params (wnn.rs:171-181)."""
-    p: int
-    l: int
-    n_hashes: int
-    bits_per_hash: int
-    bits_per_filter: int
-    n_classes: int
 
 
 class Wnn:

@@ -22,6 +22,10 @@
  *     Upstream MSM/FFT are infallible apart from length asserts; the Rust shim maps nonzero to panic!.
  *   - pointers are borrowed for the duration of the call unless a handle is returned.
  *   - one zg_ctx drives one GPU (one process per GPU; multi-GPU composition is in INTEGRATION.md).
+ *   - thread safety: every entry point that takes a zg_ctx (or a zg_prover / zg_bases created on one) holds that
+ *     context's lock for the whole call, so calls on ONE context serialise and calls on DIFFERENT contexts run
+ *     concurrently (e.g. from rayon workers, each with its own context).  Objects that are only read -- zg_bases
+ *     tables, the proving key of forked provers -- may be shared by all contexts of their device.
  *   - *_dev entry points take DEVICE pointers (HBM-resident data, e.g. torch tensors' data_ptr())
  *     and are asynchronous on the context stream; call zg_ctx_sync() before reading results.
  */
@@ -59,7 +63,9 @@ const char *zg_version(void);
 
 /* ------------------------------------------------------------------ context */
 /* Creates a context on HIP device `device_id`.  Fails with ZG_ERR_NO_DEVICE when no GPU is
- * visible: there is deliberately no CPU fallback. */
+ * visible: there is deliberately no CPU fallback.  (SURVEY.md's sketch had zg_ctx_create(n_devices, device_ids):
+ * here a context is ONE device -- one process per GPU -- and several GPUs are several contexts, composed by the
+ * caller through zg_prover_set_shard / whole proofs per GPU.) */
 int zg_ctx_create(int device_id, zg_ctx **out);
 void zg_ctx_destroy(zg_ctx *ctx);
 int zg_ctx_sync(zg_ctx *ctx);
@@ -105,6 +111,8 @@ uint32_t zg_bases_window_bits(const zg_bases *b);
  * zg_prover_set_overlap sets it together with the prover's own scheduling. */
 int zg_ctx_set_msm_latency(zg_ctx *ctx, int latency);
 
+/* A base set may be used from any context of the device it was registered on (the tables are read-only); it must
+ * outlive every prover created on it, and zg_bases_free waits for the device to go idle. */
 /* out = sum_i scalars[i] * bases[i], i < n <= zg_bases_len; == best_multiexp(scalars, &bases[..n]) */
 int zg_msm(zg_ctx *ctx, const zg_bases *bases, const zg_fr *scalars, size_t n, zg_g1 *out);
 /* `batch` scalar vectors against the same bases in one launch sequence; out[batch]. */
@@ -215,10 +223,12 @@ typedef struct {
  * EvmTranscript of snark-verifier (wnn.rs:21,249).  Witness synthesis (the Rust WnnChip) stays on the
  * caller's side: advice arrives as column values.
  *
- * Randomness: upstream draws blinding scalars from OsRng (wnn.rs:256), so real proofs are not
- * reproducible.  Here every blinding scalar is a pure function of (rng_seed, purpose tag, index) --
- * SplitMix64 + rejection sampling, documented in DESIGN.md -- so that the oracle reproduces the same
- * proof bytes. */
+ * Randomness: upstream draws every blinding scalar from OsRng (wnn.rs:256).  Here each one is
+ * rand_fr(key, purpose tag, index): the ChaCha20 (RFC 7539) keystream under a 32-byte key supplied by the caller,
+ * nonce = (tag, index), rejection-sampled below r.  A caller who passes 32 fresh bytes from its own
+ * CSPRNG (the Rust shim: OsRng.fill_bytes) gets blinding that is as hidden as that key; a fixed key makes the proof
+ * reproducible, which is what lets the oracle produce the same bytes -- tests use small integers as keys
+ * (little-endian, zero-padded), production callers must not. */
 typedef struct zg_prover zg_prover;
 
 /* Uploads the proving key material and derives what keygen_pk derives (fixed/sigma polys and their
@@ -232,19 +242,60 @@ int zg_prover_create(zg_ctx *ctx, const zg_circuit *circuit, const zg_fr *fixed_
 /* Same, with base tables registered once per device (zg_bases_register on any context of that device)
  * and shared read-only by several provers / proof streams: the window tables are the largest resident
  * object (2 * W * 2^k * 64 B) and sharing them keeps them in the Infinity Cache.  The bases must outlive
- * the prover and use the same window size. */
+ * the prover and use the same window size.  Base sets with FEWER than 2^k points are a point-range shard of the
+ * SRS: see zg_prover_set_shard. */
 int zg_prover_create_shared(zg_ctx *ctx, const zg_circuit *circuit, const zg_fr *fixed_values,
                             const zg_fr *sigma_values, const zg_bases *g, const zg_bases *g_lagrange,
                             const zg_fr *vk_repr, zg_prover **out);
+/* A second prover on the SAME proving key (no copy: the key's HBM is shared and freed with its last prover) and
+ * the same base tables, on another context of the device -- another stream of proofs or proof batches. */
+int zg_prover_fork(const zg_prover *parent, zg_ctx *ctx, zg_prover **out);
 void zg_prover_destroy(zg_prover *p);
-/* advice: [n_advice][2^k] column values (host); the last blinding_factors+1 rows are overwritten with
- * blinding scalars as create_proof does.  instance: [n_instance][instance_len] public inputs.
- * proof: receives the transcript bytes (EvmTranscript layout). */
+
+/* Lock-step batches.  A prover has `max_batch` proof slots (1 after creation); zg_prover_prove_batch makes up to
+ * that many proofs of the same circuit AT ONCE: every kernel launch of create_proof serves all of them (the
+ * commitments of a phase are one MSM over batch x columns vectors, the transforms one NTT batch, evaluate_h one
+ * grid with a row of workgroups per proof ...), while each proof keeps its own transcript, challenges and
+ * blinding key.  Proof bytes are those of the one-at-a-time calls. */
+int zg_prover_set_batch(zg_prover *p, size_t max_batch);
+size_t zg_prover_batch(const zg_prover *p);
+/* Device address of slot `slot`'s advice columns, [n_advice][2^k] (a witness generator may write there directly). */
+void *zg_prover_advice_slot(zg_prover *p, size_t slot);
+/* count <= max_batch proofs.  advice[b]: [n_advice][2^k] column values of proof b (host), or NULL when the slot
+ * already holds them; the last blinding_factors+1 rows are overwritten with blinding scalars as create_proof does.
+ * instance[b]: [n_instance][instance_len].  rng_keys: count x 32 bytes.  proofs[b] (proof_cap bytes each) receives
+ * proof b's transcript bytes, proof_lens[b] their length (0 on failure), statuses[b] (optional) its zg_status: a
+ * witness that fails a lookup fails ITS proof (ZG_ERR_CONSTRAINT), the others complete.  Returns the first
+ * non-zero status. */
+int zg_prover_prove_batch(zg_prover *p, size_t count, const zg_fr *const *advice, const zg_fr *const *instance,
+                          size_t instance_len, const uint8_t *rng_keys, uint8_t *const *proofs, size_t proof_cap,
+                          size_t *proof_lens, int *statuses);
+/* Same with the advice columns in HBM: d_advice[b] is a device pointer (copied into the slot unless it IS the slot,
+ * zg_prover_advice_slot) or NULL = the slot as it stands; d_advice itself may be NULL. */
+int zg_prover_prove_batch_dev(zg_prover *p, size_t count, void *const *d_advice, const zg_fr *const *instance,
+                              size_t instance_len, const uint8_t *rng_keys, uint8_t *const *proofs,
+                              size_t proof_cap, size_t *proof_lens, int *statuses);
+/* One proof (the batch of one).  advice: [n_advice][2^k] column values (host).  instance: [n_instance][instance_len]
+ * public inputs.  proof: receives the transcript bytes (EvmTranscript layout). */
 int zg_prover_prove(zg_prover *p, const zg_fr *advice, const zg_fr *instance, size_t instance_len,
-                    uint64_t rng_seed, uint8_t *proof, size_t proof_cap, size_t *proof_len);
-/* Same with the advice columns already in HBM ([n_advice][2^k], clobbered). */
+                    const uint8_t rng_key[32], uint8_t *proof, size_t proof_cap, size_t *proof_len);
+/* Same with the advice columns already in HBM ([n_advice][2^k]; copied into slot 0 unless they are slot 0). */
 int zg_prover_prove_dev(zg_prover *p, void *d_advice, const zg_fr *instance, size_t instance_len,
-                        uint64_t rng_seed, uint8_t *proof, size_t proof_cap, size_t *proof_len);
+                        const uint8_t rng_key[32], uint8_t *proof, size_t proof_cap, size_t *proof_len);
+
+/* Point-range shard of the commitments across `world` GPUs (one process and one prover per GPU):
+ * this prover's base sets hold points [first_point, first_point + zg_bases_len) of ParamsKZG::g / ::g_lagrange, it
+ * multiplies only that range of every scalar vector, and per commitment phase the ranks exchange their partial sums
+ * -- `exchange` is an ALL-GATHER: `bytes` bytes of `send` from every rank, rank order, into recv[world * bytes]
+ * (torch.distributed / RCCL on the caller's side; EC addition is not a reduction operator, so it is a gather plus
+ * local additions, never an all-reduce).  Every rank runs the rest of create_proof (transforms, evaluate_h) itself and
+ * ends with the same proof bytes. */
+typedef int (*zg_exchange_fn)(void *user, const void *send, size_t bytes, void *recv);
+/* Host helper, the additions behind that all-gather: parts = world x count partial sums in the MSM's extended
+ * Jacobian form (X, Y, ZZ, ZZZ; 128 B each, as zg_msm_batch_dev leaves them), out[i] = normalised sum over the ranks. */
+int zg_xyzz_sum_ranks(const void *parts, size_t world, size_t count, zg_g1 *out);
+int zg_prover_set_shard(zg_prover *p, uint32_t rank, uint32_t world, size_t first_point, zg_exchange_fn exchange,
+                        void *user);
 /* Upper bound of the proof size in bytes for this circuit. */
 size_t zg_prover_proof_size(const zg_prover *p);
 /* Test hook: copies an intermediate of the LAST proof to the host.  what: 0 = h(X) on the extended
@@ -252,6 +303,8 @@ size_t zg_prover_proof_size(const zg_prover *p);
  * 2 = lookup z (index = lookup) [2^k Lagrange], 3 = permuted input a' (index = lookup),
  * 4 = permuted table s' (index = lookup), 5 = h pieces in coefficient form [5 * 2^k]. */
 int zg_prover_fetch(zg_prover *p, uint32_t what, uint32_t index, zg_fr *out, size_t cap_elems);
+/* ... of proof `slot` of the last batch. */
+int zg_prover_fetch_slot(zg_prover *p, size_t slot, uint32_t what, uint32_t index, zg_fr *out, size_t cap_elems);
 
 /* Host wall-clock milliseconds the LAST proof spent per phase (diagnostics): 0 instance+advice
  * commitments, 1 lookup compression + permutation (of which out[7] is the host sort) + commitments,
@@ -268,8 +321,11 @@ int zg_prover_phase_ms(const zg_prover *p, double *out, size_t cap);
  * not depend on it. */
 int zg_prover_set_overlap(zg_prover *p, int enable);
 
-/* Stand-alone building blocks of the above (device pointers, context stream), exposed for tests. */
-/* z[0] = z0, z[i+1] = z[i] * num[i] / den[i]  (lookup::prover::commit_product / permutation commit). */
+/* Stand-alone building blocks of the above. */
+/* z[0] = z0, z[i+1] = z[i] * num[i] / den[i], i + 1 < n  (the running product of lookup::prover::commit_product and
+ * permutation::prover::commit; a zero denominator gives ratio 0, as halo2's BatchInvert leaves zeros alone).
+ * Host pointers / device pointers. */
+int zg_grand_product(zg_ctx *ctx, const zg_fr *num, const zg_fr *den, const zg_fr *z0, size_t n, zg_fr *z);
 int zg_grand_product_dev(zg_ctx *ctx, const void *d_num, const void *d_den, const zg_fr *z0, size_t n,
                          void *d_z);
 /* eval_polynomial: out[j] = polys[j](points[j]) for `count` (poly, point) pairs; polys at

@@ -219,7 +219,7 @@ class Trace(ctypes.Structure):
 
 
 class ProvingKey:
-    """orc_pk: circuit image (0g-halo2_amd/circuit.py CircuitImage), fixed/sigma values, SRS."""
+    """orc_pk: circuit image (harness/circuit.py CircuitImage), fixed/sigma values, SRS."""
 
     def __init__(self, image, fixed_values: np.ndarray, sigma_values: np.ndarray, params: Params,
                  vk_repr: np.ndarray):
@@ -243,7 +243,7 @@ def proof_size(image) -> int:
     return int(f(image.ptr()))
 
 
-def create_proof(pk: ProvingKey, advice: np.ndarray, instance: np.ndarray, seed: int, want_trace=False):
+def create_proof(pk: ProvingKey, advice: np.ndarray, instance: np.ndarray, seed, want_trace=False):
     """Returns (status, proof bytes, Trace | None)."""
     advice = np.ascontiguousarray(advice, dtype=np.uint64)
     instance = np.ascontiguousarray(instance, dtype=np.uint64)
@@ -253,7 +253,7 @@ def create_proof(pk: ProvingKey, advice: np.ndarray, instance: np.ndarray, seed:
     plen = c_size_t(0)
     tr = Trace() if want_trace else None
     st = load().orc_create_proof(ctypes.byref(pk.c), _p(advice), _p(instance), c_size_t(inst_len),
-                                 c_uint64(seed), buf, c_size_t(cap), ctypes.byref(plen),
+                                 rng_key(seed), buf, c_size_t(cap), ctypes.byref(plen),
                                  ctypes.byref(tr) if tr is not None else None)
     return st, bytes(buf[: plen.value]), tr
 
@@ -285,10 +285,24 @@ def keccak256(data: bytes) -> bytes:
     return bytes(out)
 
 
-def rand_fr(seed: int, tag: int, index: int) -> np.ndarray:
+def rng_key(seed) -> bytes:
+    """The 32-byte blinding key: bytes pass through, an int (tests) becomes its little-endian encoding."""
+    if isinstance(seed, (bytes, bytearray)):
+        assert len(seed) == 32
+        return bytes(seed)
+    return int(seed).to_bytes(32, "little")
+
+
+def rand_fr(seed, tag: int, index: int) -> np.ndarray:
     out = np.zeros(4, np.uint64)
-    load().orc_rand_fr(_p(out), c_uint64(seed), c_uint32(tag), c_uint64(index))
+    load().orc_rand_fr(_p(out), rng_key(seed), c_uint32(tag), c_uint64(index))
     return out
+
+
+def chacha20_block(key: bytes, counter: int, nonce) -> bytes:
+    out = (ctypes.c_uint32 * 16)()
+    load().orc_chacha20_block(key, c_uint32(counter), (ctypes.c_uint32 * 3)(*nonce), out)
+    return b"".join(int(w).to_bytes(4, "little") for w in out)
 
 
 def grand_product(num: np.ndarray, den: np.ndarray, z0: np.ndarray) -> np.ndarray:

@@ -10,30 +10,62 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------ randomness */
-static inline uint64_t mix64(uint64_t z) {
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
-    return z ^ (z >> 31);
+/* ChaCha20 block function (RFC 7539 section 2.3: 32-byte key, 32-bit block counter, 96-bit nonce). */
+static inline uint32_t rotl32(uint32_t x, int s) { return (x << s) | (x >> (32 - s)); }
+#define ORC_QR(a, b, c, d)                                       \
+    do {                                                         \
+        a += b; d ^= a; d = rotl32(d, 16);                       \
+        c += d; b ^= c; b = rotl32(b, 12);                       \
+        a += b; d ^= a; d = rotl32(d, 8);                        \
+        c += d; b ^= c; b = rotl32(b, 7);                        \
+    } while (0)
+
+void orc_chacha20_block(const uint8_t key[32], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]) {
+    uint32_t st[16], x[16];
+    st[0] = 0x61707865u; st[1] = 0x3320646eu; st[2] = 0x79622d32u; st[3] = 0x6b206574u;
+    for (int i = 0; i < 8; i++)
+        st[4 + i] = (uint32_t)key[4 * i] | ((uint32_t)key[4 * i + 1] << 8) | ((uint32_t)key[4 * i + 2] << 16) |
+                    ((uint32_t)key[4 * i + 3] << 24);
+    st[12] = counter;
+    st[13] = nonce[0]; st[14] = nonce[1]; st[15] = nonce[2];
+    memcpy(x, st, sizeof(x));
+    for (int r = 0; r < 10; r++) {
+        ORC_QR(x[0], x[4], x[8], x[12]);
+        ORC_QR(x[1], x[5], x[9], x[13]);
+        ORC_QR(x[2], x[6], x[10], x[14]);
+        ORC_QR(x[3], x[7], x[11], x[15]);
+        ORC_QR(x[0], x[5], x[10], x[15]);
+        ORC_QR(x[1], x[6], x[11], x[12]);
+        ORC_QR(x[2], x[7], x[8], x[13]);
+        ORC_QR(x[3], x[4], x[9], x[14]);
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + st[i];
 }
 
-void orc_rand_fr(orc_fr *out, uint64_t seed, uint32_t tag, uint64_t index) {
-    uint64_t st = mix64(seed + 0x9e3779b97f4a7c15ULL * (uint64_t)(tag + 1)) ^
-                  mix64(index + 0xd1b54a32d192ed03ULL * (uint64_t)(tag + 1));
+/* Blinding scalar (key, tag, index): ChaCha20 keystream with nonce = (tag, index_lo, index_hi), block counter =
+ * attempt; each 64-byte block offers two 254-bit candidates (words 0-7, then 8-15, top word masked to 30 bits,
+ * little-endian); the first one below r is taken (acceptance 0.76 per candidate). */
+void orc_rand_fr(orc_fr *out, const uint8_t key[32], uint32_t tag, uint64_t index) {
+    const uint32_t nonce[3] = {tag, (uint32_t)index, (uint32_t)(index >> 32)};
     uint64_t v[4];
-    for (;;) {
-        for (int i = 0; i < 4; i++) {
-            st += 0x9e3779b97f4a7c15ULL;
-            v[i] = mix64(st);
+    for (uint32_t attempt = 0;; attempt++) {
+        uint32_t blk[16];
+        orc_chacha20_block(key, attempt, nonce, blk);
+        for (int half = 0; half < 2; half++) {
+            const uint32_t *w = blk + 8 * half;
+            for (int i = 0; i < 4; i++) v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+            v[3] &= 0x3fffffffffffffffULL;
+            int lt = 0;
+            for (int i = 3; i >= 0; i--) {
+                if (v[i] < ORC_FR_MODULUS[i]) { lt = 1; break; }
+                if (v[i] > ORC_FR_MODULUS[i]) break;
+            }
+            if (lt) {
+                orc_fr_from_raw(out, v);
+                return;
+            }
         }
-        v[3] &= 0x3fffffffffffffffULL;
-        int lt = 0;
-        for (int i = 3; i >= 0; i--) {
-            if (v[i] < ORC_FR_MODULUS[i]) { lt = 1; break; }
-            if (v[i] > ORC_FR_MODULUS[i]) break;
-        }
-        if (lt) break;
     }
-    orc_fr_from_raw(out, v);
 }
 
 /* ------------------------------------------------------------------ EvmTranscript (snark-verifier) */
@@ -283,7 +315,7 @@ typedef struct {
 
 /* ------------------------------------------------------------------ create_proof */
 int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *instance_in, size_t instance_len,
-                     uint64_t seed, uint8_t *proof, size_t cap, size_t *proof_len, orc_trace *trace) {
+                     const uint8_t seed[32], uint8_t *proof, size_t cap, size_t *proof_len, orc_trace *trace) {
     const zg_circuit *cs = pk->cs;
     const size_t n = (size_t)1 << cs->k;
     const size_t bf = cs->blinding_factors;

@@ -29,8 +29,10 @@ extern "C" {
 
 void orc_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
 
-/* Blinding scalar = pure function of (seed, tag, index): SplitMix64 stream + rejection sampling of a
- * canonical value < r, returned in Montgomery form (DESIGN.md "randomness"). */
+/* Blinding scalar = pure function of (key, tag, index): ChaCha20 (RFC 7539) keystream under the caller's 32-byte
+ * key, nonce = (tag, index), rejection sampling of a canonical value < r, returned in Montgomery form
+ * (DESIGN.md "randomness").  Upstream draws from OsRng (/root/reference/src/wnn.rs:256); a caller that wants
+ * the same hiding passes 32 fresh random bytes, tests pass fixed keys. */
 enum {
     ORC_TAG_ADVICE_BLIND = 1,     /* index = column * (bf + 1) + j                    */
     ORC_TAG_PERMUTED_INPUT = 2,   /* index = lookup * (bf + 1) + j                    */
@@ -39,7 +41,8 @@ enum {
     ORC_TAG_LOOKUP_Z = 5,         /* index = lookup * bf + j                          */
     ORC_TAG_RANDOM_POLY = 6       /* index = coefficient                              */
 };
-void orc_rand_fr(orc_fr *out, uint64_t seed, uint32_t tag, uint64_t index);
+void orc_chacha20_block(const uint8_t key[32], uint32_t counter, const uint32_t nonce[3], uint32_t out[16]);
+void orc_rand_fr(orc_fr *out, const uint8_t key[32], uint32_t tag, uint64_t index);
 
 /* Proving key material, as keygen_pk leaves it (all host arrays, Lagrange values). */
 typedef struct {
@@ -67,7 +70,7 @@ void orc_trace_free(orc_trace *t);
  * (plonk::Error::ConstraintSystemFailure), or ZG_ERR_INVALID_ARG.  advice: [n_advice][n], not
  * modified.  trace may be NULL. */
 int orc_create_proof(const orc_pk *pk, const orc_fr *advice, const orc_fr *instance, size_t instance_len,
-                     uint64_t seed, uint8_t *proof, size_t cap, size_t *proof_len, orc_trace *trace);
+                     const uint8_t seed[32], uint8_t *proof, size_t cap, size_t *proof_len, orc_trace *trace);
 
 /* plonk::verify_proof restated (VerifierGWC + SingleStrategy), with the final pairing
  * e(W, [s]_2 - z[1]_2) = e(C - v[1]_1, [1]_2) checked in G1 through the known toxic scalar:

@@ -1,4 +1,4 @@
-"""Test circuits built with the host-side ConstraintSystem mirror (0g-halo2_amd/circuit.py)."""
+"""Test circuits built with the host-side ConstraintSystem mirror (harness/circuit.py)."""
 import random
 
 from circuit import ADVICE, FIXED, INSTANCE, R, Assignment, ConstraintSystem

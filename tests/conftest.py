@@ -7,6 +7,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "harness"))  # the caller side restated (circuit, layouter, Wnn model)
 sys.path.insert(0, ROOT)
 
 

@@ -18,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
+sys.path.insert(0, os.path.join(ROOT, "harness"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np

@@ -279,24 +279,27 @@ def test_real_wnn_circuit_small_k15_verifies(ctx, zg, orc):
 
 def test_real_wnn_circuit_medium_k15_verifies(ctx, zg, orc):
     """model_28input_2048entry_2hash_3bpi (BASELINE configs[3], k = 15; the layout fills 32 738 of the 32 762
-    usable rows): GPU proof in the throughput configuration, pairing verifier."""
+    usable rows): GPU proof bytes == oracle in both schedules (split 4n + n domain / single 8n coset), pairing verifier."""
     import wnn_model
 
     orc.load().orc_set_threads(16)
     cs, asg, ilen, scores, pk, prover = _real_model(orc, zg, ctx, wnn_model.MNIST_MEDIUM)
     assert scores == [29, 21, 40, 47, 45, 41, 28, 82, 35, 66]
-    prover.set_overlap(False)
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
-    got = prover.prove(adv, inst, 11)
+    st, want, _ = orc.create_proof(pk, adv, inst, 11)
+    assert st == 0
+    prover.set_overlap(False)
+    assert prover.prove(adv, inst, 11) == want
     prover.set_overlap(True)
-    assert prover.prove(adv, inst, 11) == got
-    assert orc.verify_proof_pairing(pk, inst, got) == 1
+    assert prover.prove(adv, inst, 11) == want
+    assert orc.verify_proof_pairing(pk, inst, want) == 1
     prover.close()
 
 
 def test_large_shape_k17_verifies(ctx, zg, orc):
     """The k = 17 configuration (BASELINE configs[4]; seeded stand-in for the absent 49-input model): 2^17 rows,
-    2^20-point extended domain -- GPU proof, pairing verifier."""
+    2^20-point extended domain, 15-bit MSM windows -- GPU proof bytes == oracle in both schedules and in a batch of two,
+    pairing verifier."""
     import wnn_circuit
     import wnn_model
 
@@ -311,7 +314,14 @@ def test_large_shape_k17_verifies(ctx, zg, orc):
     fixed, sigma = asg.fixed_values(), asg.sigma_values()
     prover = zg.Prover(ctx, img, fixed, sigma, params.g_np(), params.g_lagrange_np(), vk_repr)
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
-    proof = prover.prove(adv, inst, 3)
-    prover.close()
     pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
-    assert orc.verify_proof_pairing(pk, inst, proof) == 1
+    st, want, _ = orc.create_proof(pk, adv, inst, 3)
+    assert st == 0
+    assert prover.prove(adv, inst, 3) == want          # single 2^20-point coset, side stream
+    prover.set_overlap(False)
+    assert prover.prove(adv, inst, 3) == want          # split 4n + n domain
+    prover.set_batch(2)
+    got, _ = prover.prove_batch([adv, adv], [inst, inst], [3, 4])
+    assert got[0] == want and got[1] == orc.create_proof(pk, adv, inst, 4)[1]
+    prover.close()
+    assert orc.verify_proof_pairing(pk, inst, want) == 1

@@ -195,3 +195,39 @@ def test_msm_vs_naive_and_srs_consistency(orc):
     assert np.array_equal(orc.msm(ev, gl), want)
     # g[0] = G = (1, 2); g[1] = s*G
     assert orc.fq_to_int(g[0][:4]) == 1 and orc.fq_to_int(g[0][4:]) == 2
+
+
+def test_chacha20_block_rfc7539(orc):
+    """The blinding generator's block function against RFC 7539 section 2.3.2 (key 00..1f, nonce 000000090000004a00000000,
+    block counter 1)."""
+    key = bytes(range(32))
+    nonce = bytes([0, 0, 0, 9, 0, 0, 0, 0x4A, 0, 0, 0, 0])
+    words = [int.from_bytes(nonce[4 * i:4 * i + 4], "little") for i in range(3)]
+    want = ("10f1e7e4d13b5915500fdd1fa32071c4c7d1f4c733c068030422aa9ac3d46c4e"
+            "d2826446079faa0914c2d705d98b02a2b5129cd1de164eb9cbd083e8a2503c4e")
+    assert orc.chacha20_block(key, 1, words).hex() == want
+
+
+def test_rand_fr_is_the_first_keystream_candidate_below_r(orc):
+    """rand_fr(key, tag, index): nonce = (tag, index_lo, index_hi), block counter = attempt, two 254-bit candidates per
+    block, the first one below r; returned in Montgomery form."""
+    r = orc.FR_MODULUS if hasattr(orc, "FR_MODULUS") else 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    key = bytes(range(100, 132))
+    seen_second, seen_retry = False, False
+    for tag, index in [(1, 0), (6, 12345), (3, (7 << 32) | 9)] + [(2, i) for i in range(40)]:
+        want = None
+        for attempt in range(8):
+            blk = orc.chacha20_block(key, attempt, [tag, index & 0xFFFFFFFF, index >> 32])
+            for half in range(2):
+                v = int.from_bytes(blk[32 * half:32 * half + 32], "little") & ((1 << 254) - 1)
+                if v < r:
+                    want = v
+                    seen_second |= half == 1
+                    seen_retry |= attempt > 0
+                    break
+            if want is not None:
+                break
+        got = orc.rand_fr(key, tag, index)
+        mont = sum(int(got[i]) << (64 * i) for i in range(4))
+        assert mont * pow(1 << 256, -1, r) % r == want
+    assert seen_second  # (the rejection path is exercised: 24 % of first candidates are >= r)

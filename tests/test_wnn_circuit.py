@@ -1,4 +1,4 @@
-"""zero_g's WnnCircuit restated (0g-halo2_amd/wnn_circuit.py over layouter.py) on the checked-in models.
+"""zero_g's WnnCircuit restated (harness/wnn_circuit.py over layouter.py) on the checked-in models.
 
 What the reference's own tests pin on this side of the path, reproduced here:
   * `mock_proof_mnist_{tiny,small,medium}` (tests/integration_test.rs:6,24,42): the circuit is satisfied for

@@ -1,4 +1,4 @@
-"""Host-side WNN model mirror (0g-halo2_amd/wnn_model.py) against the values the reference's own tests
+"""Host-side WNN model mirror (harness/wnn_model.py) against the values the reference's own tests
 pin: tests/integration_test.rs:19,36,53 `snapshot_mnist_*_predictions` (Wnn::predict on
 benches/example_image_7.png), via the fixtures extracted from the checked-in model files."""
 import json

@@ -8,7 +8,7 @@ library exists in this image, so this is a minimal reader for exactly what those
 superblock, version-1 object headers with continuation blocks, one symbol-table group, contiguous
 unfiltered datasets, version-1 attributes.  Output per model: an .npz holding the seven attributes, the
 bloom filter bits (packed), the f32 binarization thresholds and the input permutation -- data only;
-the quantisation and everything else the loader does is restated in 0g-halo2_amd/wnn_model.py.
+the quantisation and everything else the loader does is restated in harness/wnn_model.py.
 The 28x28 test image (benches/example_image_7.png, 254 B) is decoded with zlib and stored as raw u8.
 """
 import os
