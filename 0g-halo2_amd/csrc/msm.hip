@@ -33,7 +33,10 @@ int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
 int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
 
-constexpr uint32_t MSM_K = 16;       // max points per accumulate task
+#ifndef ZG_MSM_K
+#define ZG_MSM_K 16
+#endif
+constexpr uint32_t MSM_K = ZG_MSM_K;  // max points per accumulate task
 constexpr uint32_t MSM_MAX_C = 16;
 constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
 

@@ -16,7 +16,7 @@ from ctypes import POINTER, c_char_p, c_int, c_size_t, c_uint32, c_void_p
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libzg_halo2.so")
+LIB_PATH = os.environ.get("ZG_HALO2_LIB") or os.path.join(_HERE, "libzg_halo2.so")  # (the override is for A/B builds)
 
 FR_MODULUS = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
 FQ_MODULUS = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- create_proof of zero_g's WNN circuit on MI355X (BASELINE.json metric).
 
-A "step" is `--provers` (default 2) lock-step batches of `--batch` (default 16) full create_proofs each: every
+A "step" is `--provers` (default 4) lock-step batches of `--batch` (default 16) full create_proofs each: every
 prover works on its own HIP stream from its own host thread (while one batch waits for its transcript hashes on
 the host, the other keeps the GPU busy) and makes its B proofs with ONE launch sequence (zg_prover_prove_batch: the
 commitments of a phase are one MSM over B x columns vectors, evaluate_h one grid with a row of workgroups per
@@ -130,7 +130,9 @@ def make_streams(dev_index: int, c: Circuit, ctx0: zg.Ctx, nprovers: int, batch:
     ctxs = [ctx0] + [zg.Ctx(dev_index) for _ in range(nprovers - 1)]
     first = zg.Prover(ctx0, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
     provers = [first] + [first.fork(x) for x in ctxs[1:]]
-    return ctxs, [Stream(ctxs[i], provers[i], c, batch, rank * 64 + i, exchange, shard) for i in range(nprovers)]
+    # (ranks of a sharded proof work on the SAME proofs -- same witness, same blinding keys; replicas differ by rank)
+    base = 0 if shard[1] > 1 else rank * 64
+    return ctxs, [Stream(ctxs[i], provers[i], c, batch, base + i, exchange, shard) for i in range(nprovers)]
 
 
 def run_steps(streams, steps):
@@ -279,12 +281,13 @@ def main():
     ap.add_argument("--model", choices=sorted(MODELS), default="tiny",
                     help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
     ap.add_argument("--batch", type=int, default=16, help="proofs per lock-step batch (zg_prover_prove_batch)")
-    ap.add_argument("--provers", type=int, default=2, help="proof streams per GPU (provers sharing one proving key)")
+    ap.add_argument("--provers", type=int, default=4, help="proof streams per GPU (provers sharing one proving key)")
     ap.add_argument("--mode", choices=["replicas", "shard-msm"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other three models")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-latency-probe", action="store_true", help="skip the lone-proof latency measurement (counter passes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -292,7 +295,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # (rehearsal knobs for a one-GPU box: ZG_BENCH_DEVICE=0 puts every rank on the same card, ZG_BENCH_BACKEND=gloo
+    #  replaces RCCL, which refuses two ranks on one GPU)
+    dev_index = int(os.environ.get("ZG_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("ZG_BENCH_BACKEND", "nccl")
+    dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1 or os.environ.get("ZG_BENCH_FORCE_DIST") == "1":  # (the env knob rehearses the RCCL path on one GPU)
@@ -305,7 +312,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -321,11 +331,11 @@ def main():
     if sharded:
         import multi_gpu
 
-        exchange = multi_gpu.make_exchange(dist, dev)
+        exchange = multi_gpu.make_exchange(dist, dev if backend == "nccl" else None)
 
-    ctx0 = zg.Ctx(local_rank)
+    ctx0 = zg.Ctx(dev_index)
     circuit = Circuit(ctx0, args.model, shard)
-    ctxs, streams = make_streams(local_rank, circuit, ctx0, nprov, batch, rank, exchange, shard)
+    ctxs, streams = make_streams(dev_index, circuit, ctx0, nprov, batch, rank, exchange, shard)
 
     def barrier():
         if dist is not None:
@@ -334,12 +344,12 @@ def main():
         for x in ctxs:
             x.sync()
 
-    latency_s, phases = latency_probe(streams[0]) if not sharded else (None, [0.0] * 8)
+    latency_s, phases = latency_probe(streams[0]) if not (sharded or args.no_latency_probe) else (None, [0.0] * 8)
     # timed region: every launch carries its own start / stop event (hipExtLaunchKernelGGL on the prover's stream): a
     # lock-step batch is ~100 launches for `batch` proofs, so timing them all costs nothing measurable
     dt, stats = measure(streams, ctxs, args.steps, args.warmup, barrier, profile=not args.no_kernel_events)
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -446,7 +456,7 @@ def main():
         for m in ("small", "medium", "large"):
             c2 = Circuit(ctx0, m)
             b2 = batch if m != "large" else max(1, batch // 2)
-            cx, st2 = make_streams(local_rank, c2, ctx0, nprov, b2, rank)
+            cx, st2 = make_streams(dev_index, c2, ctx0, nprov, b2, rank)
             lat, _ = latency_probe(st2[0])
             dt2, _ = measure(st2, cx, 3, 1, barrier)
             others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * nprov * b2) * 1e3,

@@ -83,6 +83,13 @@ def params_new(k: int, seed: int = 0x5EED) -> Params:
     return p
 
 
+def params_from_scalar(k: int, s: np.ndarray) -> Params:
+    """ParamsKZG::new(k) for a given toxic scalar (Montgomery limbs)."""
+    p = Params()
+    load().orc_params_new(ctypes.byref(p), c_uint32(k), _p(np.ascontiguousarray(s, dtype=np.uint64)))
+    return p
+
+
 def fill_fr(seed: int, n: int) -> np.ndarray:
     out = np.zeros((n, 4), np.uint64)
     load().orc_fill_fr(c_uint64(seed), _p(out), c_size_t(n))

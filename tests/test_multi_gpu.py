@@ -1,7 +1,9 @@
-"""N > 1 path: one MSM sharded by point range over ranks, partials all-gathered and added.
+"""N > 1 path: commitments sharded by point range over ranks, partial sums all-gathered and added.
 
-CPU (gloo, world_size 2): the per-rank partial comes from the oracle, the exchange + EC add are the
-product's (multi_gpu.py + zg_g1_sum).  GPU: two gloo ranks each drive their own context on cuda:0."""
+CPU (gloo, world_size 2): the per-rank partial comes from the oracle, the exchange + EC additions are the
+product's (multi_gpu.py: make_exchange / msm_sharded, zg_xyzz_sum_ranks / zg_g1_sum).  GPU: two gloo ranks each drive
+their own context on cuda:0 -- a stand-alone sharded MSM, and create_proof with the shard INSIDE the prover
+(zg_prover_set_shard): both ranks must end with the single-GPU proof bytes."""
 import os
 import sys
 
@@ -15,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _init(rank, world, port):
-    for p in (os.path.join(ROOT, "0g-halo2_amd"), os.path.join(ROOT, "oracle")):
+    for p in (os.path.join(ROOT, "0g-halo2_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "harness"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -95,4 +97,108 @@ def test_sharded_msm_two_ranks_on_gpu():
     with mp.Manager() as m:
         ret = m.dict()
         mp.spawn(_gpu_worker, args=(world, 29533, ret), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world))
+
+
+def _xyzz_of(orc, jac):
+    """normalised Jacobian (uint64[12]) -> extended Jacobian (X, Y, ZZ, ZZZ) with a rank-dependent scaling, as the MSM
+    kernels leave their results (Python integers)."""
+    import zg_halo2 as zg
+
+    q = zg.FQ_MODULUS
+    x, y, z = (zg.fq_to_int(jac[4 * i:4 * i + 4]) for i in range(3))
+    if z == 0:
+        vals = (0, 1, 0, 0)
+    else:
+        lam = 0x1234567 + x % 97  # any non-zero scaling: (x l^2, y l^3, l^2, l^3)
+        vals = (x * lam * lam % q, y * pow(lam, 3, q) % q, lam * lam % q, pow(lam, 3, q))
+    return np.concatenate([zg.fq_from_int(v) for v in vals])
+
+
+def _exchange_worker(rank, world, port, ret):
+    _init(rank, world, port)
+    import ctypes
+
+    import multi_gpu
+    import orc
+    import zg_halo2 as zg
+
+    zg.load()
+    prm = orc.params_new(7)
+    g = prm.g_np()
+    n, count = g.shape[0], 3
+    ex = multi_gpu.make_exchange(dist)
+    lo, hi = multi_gpu.shard_range(n, rank, world)
+    scal = [orc.fill_fr(40 + i, n) for i in range(count)]
+    mine = np.stack([_xyzz_of(orc, orc.msm(s[lo:hi], g[lo:hi])) for s in scal])  # this rank's partial sums
+    send = (ctypes.c_uint8 * mine.nbytes).from_buffer_copy(mine.tobytes())
+    recv = (ctypes.c_uint8 * (mine.nbytes * world))()
+    ex(send, recv)
+    parts = np.frombuffer(bytes(recv), dtype=np.uint64).reshape(world, count, 16)
+    assert np.array_equal(parts[rank], mine)
+    got = zg.xyzz_sum_ranks(parts)
+    ret[rank] = all(np.array_equal(got[i], orc.msm(scal[i], g)) for i in range(count))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_phase_exchange_and_rank_sum_gloo_world2():
+    """What a sharded commitment phase does between the ranks: ONE all-gather of every commitment's partial sum
+    (128-byte extended Jacobian points), then the per-commitment additions -- on the host, so it runs here."""
+    world = 2
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_exchange_worker, args=(world, 29577, ret), nprocs=world, join=True)
+        assert all(ret[r] for r in range(world))
+
+
+def _sharded_prover_worker(rank, world, port, ret):
+    _init(rank, world, port)
+    import multi_gpu
+    import orc
+    import zg_halo2 as zg
+    from circuits import toy_circuit
+
+    ok = True
+    ctx = zg.Ctx(0)
+    for k, force_degree in ((7, 6), (9, None)):
+        cs, asg, ilen = toy_circuit(k, force_degree=force_degree)
+        img = cs.to_c()
+        params = orc.params_new(k, 0xABCDEF)
+        vk_repr = orc.fr_from_int(0x1234567)
+        fixed, sigma = asg.fixed_values(), asg.sigma_values()
+        pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
+        n = 1 << k
+        lo, hi = multi_gpu.shard_range(n, rank, world)
+        gb = ctx.register_bases(params.g_np()[lo:hi])
+        glb = ctx.register_bases(params.g_lagrange_np()[lo:hi])
+        prover = zg.Prover(ctx, img, fixed, sigma, gb, glb, vk_repr)
+        adv, inst = asg.advice_values(), asg.instance_values(ilen)
+        try:  # a slice of the SRS without a declared shard is refused
+            prover.prove(adv, inst, 1)
+            ok = False
+        except zg.ZgError:
+            pass
+        prover.set_shard(rank, world, lo, multi_gpu.make_exchange(dist))
+        prover.set_batch(3)
+        for overlap in (True, False):
+            prover.set_overlap(overlap)
+            seeds = [21, 22, 23]
+            got, _ = prover.prove_batch([adv] * 3, [inst] * 3, seeds)
+            ok = ok and got == [orc.create_proof(pk, adv, inst, s)[1] for s in seeds]
+        prover.close()
+        gb.free()
+        glb.free()
+    ret[rank] = ok
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_commitments_inside_create_proof_two_ranks_on_gpu():
+    world = 2
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_sharded_prover_worker, args=(world, 29541, ret), nprocs=world, join=True)
         assert all(ret[r] for r in range(world))
