@@ -45,9 +45,16 @@ def test_proof_with_output_json(tmp_path):
     scores = [9, 6, 13, 10, 17, 10, 9, 26, 11, 16]
     pw = formats.ProofWithOutput(bytes(range(200)), scores)
     path = str(tmp_path / "proof.json")
-    pw.write(path)
+    pw.write(path, form="hex")
     d = json.load(open(path))
     assert d["proof"][:3] == [0, 1, 2] and d["output"][0] == "0x09" + "00" * 31
+    back = formats.ProofWithOutput.read(path)
+    assert back.proof == pw.proof and back.output == scores
+    # the other candidate encoding: four Montgomery limbs per element (the ABI's zg_fr); read() takes either
+    pw.write(path)
+    d = json.load(open(path))
+    R_ = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+    assert sum(l << (64 * j) for j, l in enumerate(d["output"][0])) == 9 * (1 << 256) % R_
     back = formats.ProofWithOutput.read(path)
     assert back.proof == pw.proof and back.output == scores
     m = back.output_mont()
@@ -56,3 +63,50 @@ def test_proof_with_output_json(tmp_path):
     assert sum(int(m[0, 7, j]) << (64 * j) for j in range(4)) == 26 * (1 << 256) % R
     with pytest.raises(ValueError):
         formats.fr_from_repr_hex("0x" + "ff" * 32)
+
+
+def test_proving_key_file_roundtrip_and_layout(tmp_path, orc):
+    """ProvingKey::write(RawBytes) (io.rs:159-162): written field by field as documented in formats.py, read back, and the
+    two families zg_prover_create consumes (fixed values, sigma values) handed on unchanged."""
+    from circuits import toy_circuit
+
+    k = 5
+    cs, asg, ilen = toy_circuit(k, force_degree=6)
+    n, en = 1 << k, 1 << cs.extended_k()
+    fixed, sigma = asg.fixed_values(), asg.sigma_values()
+    F, P = fixed.shape[0], sigma.shape[0]
+    rng = np.random.default_rng(3)
+    num_selectors = 3
+    sel = rng.integers(0, 2, size=(num_selectors, n)).astype(bool)
+
+    def rnd(*shape):
+        return rng.integers(0, 1 << 62, size=shape + (4,), dtype=np.uint64)
+
+    pk = formats.ProvingKeyFile(
+        k, fixed_commitments=rng.integers(0, 1 << 62, size=(F, 8), dtype=np.uint64),
+        permutation_commitments=rng.integers(0, 1 << 62, size=(P, 8), dtype=np.uint64), selectors=sel,
+        l0=rnd(en), l_last=rnd(en), l_active_row=rnd(en), fixed_values=fixed, fixed_polys=rnd(F, n), fixed_cosets=rnd(F, en),
+        permutations=sigma, permutation_polys=rnd(P, n), permutation_cosets=rnd(P, en))
+    path = str(tmp_path / "pk.bin")
+    formats.write_pk(path, pk)
+    raw = open(path, "rb").read()
+    # header: k and the fixed-commitment count, both u32 big-endian
+    assert struct.unpack(">II", raw[:8]) == (k, F)
+    sel_at = 8 + 64 * (F + P)
+    assert raw[sel_at] == sum(int(sel[0, i]) << i for i in range(8))  # 8 rows per byte, lowest row = bit 0
+    l0_at = sel_at + num_selectors * (n // 8)
+    assert struct.unpack(">I", raw[l0_at:l0_at + 4])[0] == en
+    total = 8 + 64 * (F + P) + num_selectors * n // 8 + 3 * (4 + 32 * en) + 2 * (4 + F * (4 + 32 * n)) + (4 + F * (4 + 32 * en)) \
+        + 2 * (4 + P * (4 + 32 * n)) + (4 + P * (4 + 32 * en))
+    assert len(raw) == total
+    back = formats.read_pk(path, num_selectors, P)
+    assert back.k == k
+    for f in formats.ProvingKeyFile.FIELDS:
+        assert np.array_equal(np.asarray(getattr(back, f)), np.asarray(getattr(pk, f))), f
+    # what the backend takes from the file is what keygen produced
+    assert np.array_equal(back.fixed_values, fixed) and np.array_equal(back.permutations, sigma)
+    with pytest.raises(ValueError):
+        formats.read_pk(path, num_selectors + 1, P)
+    open(path, "ab").write(b"\0")
+    with pytest.raises(ValueError):
+        formats.read_pk(path, num_selectors, P)
