@@ -34,9 +34,9 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                    size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
 
 #ifndef ZG_MSM_K
-#define ZG_MSM_K 16
+#define ZG_MSM_K 32
 #endif
-constexpr uint32_t MSM_K = ZG_MSM_K;  // max points per accumulate task
+constexpr uint32_t MSM_K = ZG_MSM_K;  // max points per accumulate task (32 halves the partials the reduction merges; 16 measured 2 % slower)
 constexpr uint32_t MSM_MAX_C = 16;
 constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
 
@@ -350,12 +350,15 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     }
     const uint32_t k = lo;
     const uint32_t j = t - to[k];
-    // bucket k's entries are contiguous: [tot[k], tot[k+1])  (exclusive entry offsets)
+    // bucket k's entries are contiguous: [tot[k], tot[k+1])  (exclusive entry offsets); its nt = ceil(total / K)
+    // tasks share them EVENLY (sizes differ by one at most): a wave's lanes then run nearly the same number of
+    // additions, where a full / full / ... / remainder split leaves the remainder's lane idle for most of the loop
     const uint32_t first = tot[(size_t)b * (nb + 2) + k];
     const uint32_t total = tot[(size_t)b * (nb + 2) + k + 1] - first;
-    const uint32_t start = first + j * MSM_K;
-    uint32_t len = total - j * MSM_K;
-    if (len > MSM_K) len = MSM_K;
+    const uint32_t nt = to[k + 1] - to[k];
+    const uint32_t share = total / nt, extra = total % nt;
+    const uint32_t start = first + j * share + (j < extra ? j : extra);
+    const uint32_t len = share + (j < extra ? 1u : 0u);
     const uint32_t* so = sorted + (size_t)b * windows * n + start;
     XYZZ9* dst = partial + (size_t)b * max_tasks + t;
     bool inf = true;
@@ -562,6 +565,97 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
         st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
         tickets[b] = 0;                                  // ready for the next launch on this stream
     }
+}
+
+// ---- the throughput form of the reduction: least work.  sum_k k B_k over the buckets k = 1 .. nb of one vector.
+// Stage 1, one LANE per strip of MSM_STRIP consecutive buckets [jS + 1, (j + 1) S], highest bucket first:
+//     B = the bucket's task partials merged (hot buckets arrive merged from msm_heavy);  run += B;  loc += run
+// leaves run = U_j (the strip's sum) and loc = sum_s (s + 1) B_(jS + s + 1), so that
+//     sum_k k B_k = sum_j loc_j + S * sum_j j U_j.
+// Two additions per bucket on top of the merges, where the Hillis-Steele scan of the latency form spends
+// log2(256) + 3: a lock-step batch brings hundreds of vectors per launch, so the parallelism that scan was bought
+// for comes from the batch instead.  Stage 2, one workgroup per vector: lane l folds `per` consecutive strip sums the
+// same way (C_l = their sum, w_l = sum_t t U_(l per + t)), a suffix scan + tree over the 256 lanes gives
+// W = sum_l l C_l, and  result = sum_j loc_j + S * (sum_l w_l + per * W)  with the factors S and per (powers of two)
+// applied by doublings.
+constexpr uint32_t MSM_STRIP = 4;
+constexpr uint32_t MSM_STRIP_LANES = 256;  // stage-2 workgroup
+
+__global__ __launch_bounds__(256) void msm_strip_kernel(const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff,
+                                                        const uint32_t* __restrict__ hmap, const XYZZ9* __restrict__ hsum,
+                                                        uint32_t max_tasks, uint32_t max_heavy, uint32_t c, uint32_t nstrips,
+                                                        XYZZ9* __restrict__ strip_u, XYZZ9* __restrict__ strip_loc) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (j >= nstrips) return;
+    const uint32_t nb = 1u << (c - 1);
+    const uint32_t* to = toff + (size_t)b * (nb + 2);
+    const XYZZ9* pp = partial + (size_t)b * max_tasks;
+    XYZZ9 run = xyzz9_identity(), loc = xyzz9_identity();
+    for (uint32_t s = MSM_STRIP; s-- > 0;) {
+        const uint32_t k = j * MSM_STRIP + s + 1;
+        if (k <= nb) {
+            const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
+            if (hs < max_heavy) {
+                run = xyzz9_add(run, ld_xyzz9(hsum + (size_t)b * max_heavy + hs));
+            } else {
+                const uint32_t t0 = to[k], t1 = to[k + 1];
+                for (uint32_t t = t0; t < t1; t++) run = xyzz9_add(run, ld_xyzz9(pp + t));
+            }
+        }
+        loc = xyzz9_add(loc, run);
+    }
+    st_xyzz9(strip_u + (size_t)b * nstrips + j, run);
+    st_xyzz9(strip_loc + (size_t)b * nstrips + j, loc);
+}
+
+__global__ __launch_bounds__(MSM_STRIP_LANES) void msm_strip_sum_kernel(const XYZZ9* __restrict__ strip_u,
+                                                                       const XYZZ9* __restrict__ strip_loc, uint32_t nstrips,
+                                                                       uint32_t per, XYZZ* __restrict__ out) {
+    __shared__ XYZZ9 sh[MSM_STRIP_LANES];
+    const uint32_t l = threadIdx.x, b = blockIdx.x;
+    const XYZZ9* U = strip_u + (size_t)b * nstrips;
+    const XYZZ9* L = strip_loc + (size_t)b * nstrips;
+    // this lane's strips [l per, (l + 1) per): C = their sum, w = sum_t t U_t, a = sum of their loc
+    XYZZ9 C = xyzz9_identity(), w = xyzz9_identity(), a = xyzz9_identity();
+    for (uint32_t t = per; t-- > 0;) {
+        const uint32_t jj = l * per + t;
+        if (jj >= nstrips) continue;
+        w = xyzz9_add(w, C);
+        C = xyzz9_add(C, ld_xyzz9(U + jj));
+        a = xyzz9_add(a, ld_xyzz9(L + jj));
+    }
+    auto tree = [&](XYZZ9 v) {  // sum over the workgroup, result in every lane's return value of lane 0 only
+        sh[l] = v;
+        __syncthreads();
+        for (uint32_t o = MSM_STRIP_LANES / 2; o > 0; o >>= 1) {
+            if (l < o) sh[l] = xyzz9_add(sh[l], sh[l + o]);
+            __syncthreads();
+        }
+        XYZZ9 r = sh[0];
+        __syncthreads();
+        return r;
+    };
+    // W = sum_l l C_l = sum over l >= 1 of the suffix sums of C (Hillis-Steele through LDS)
+    sh[l] = C;
+    __syncthreads();
+    for (uint32_t o = 1; o < MSM_STRIP_LANES; o <<= 1) {
+        XYZZ9 v = xyzz9_identity();
+        const bool has = l + o < MSM_STRIP_LANES;
+        if (has) v = sh[l + o];
+        __syncthreads();
+        if (has) sh[l] = xyzz9_add(sh[l], v);
+        __syncthreads();
+    }
+    XYZZ9 sfx = l >= 1 ? sh[l] : xyzz9_identity();
+    __syncthreads();
+    XYZZ9 W = tree(sfx);
+    const XYZZ9 wsum = tree(w);
+    const XYZZ9 asum = tree(a);
+    if (l != 0) return;
+    for (uint32_t d = per; d > 1; d >>= 1) W = xyzz9_add(W, W);            // per * W   (equal operands: the doubling case)
+    XYZZ9 V = xyzz9_add(W, wsum);                                           // sum_j j U_j
+    for (uint32_t d = MSM_STRIP; d > 1; d >>= 1) V = xyzz9_add(V, V);      // S * V
+    st_xyzz(out + b, xyzz9_to_xyzz(xyzz9_add(V, asum), false));
 }
 
 static uint32_t default_window_bits(size_t n) {
@@ -852,10 +946,23 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     } else {
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<1>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
-        ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
-                  toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
-        ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
-                  blk_w, nblk, ctx->msm_tickets, d_out);
+        static const bool strips = !(getenv("ZG_MSM_STRIPS") && atoi(getenv("ZG_MSM_STRIPS")) == 0);  // A/B knob
+        if (strips) {
+            // (sfx has room for nb points per vector: the strip sums and strip-local weighted sums share it)
+            const uint32_t nstrips = (nb + MSM_STRIP - 1) / MSM_STRIP;
+            uint32_t per = 1;
+            while (per * MSM_STRIP_LANES < nstrips) per <<= 1;
+            XYZZ9 *strip_u = sfx, *strip_loc = sfx + (size_t)B * nstrips;
+            ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_strip_kernel, dim3((nstrips + 255) / 256, B), dim3(256), 0, partial,
+                      toff, hmap, hsum, max_tasks, max_heavy, c, nstrips, strip_u, strip_loc);
+            ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_strip_sum_kernel, dim3(B), dim3(MSM_STRIP_LANES), 0, strip_u, strip_loc,
+                      nstrips, per, d_out);
+        } else {
+            ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
+                      toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
+            ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
+                      blk_w, nblk, ctx->msm_tickets, d_out);
+        }
     }
     ZG_HIP(hipGetLastError());
     return ZG_OK;

@@ -153,6 +153,23 @@ def xyzz_sum_ranks(parts: np.ndarray) -> np.ndarray:
     return out
 
 
+import atexit
+import weakref
+
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _close_contexts_at_exit():
+    # contexts (and their provers) must be torn down while the HIP runtime is still alive, not by the garbage
+    # collector after the interpreter has started unloading libraries
+    for c in list(_live_contexts):
+        try:
+            c.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 class Ctx:
     """One GPU (zg_ctx)."""
 
@@ -162,6 +179,7 @@ class Ctx:
         _check(self.lib.zg_ctx_create(c_int(device), ctypes.byref(h)))
         self.h = h
         self._children = []  # weak references to the provers created on this context: they must go first
+        _live_contexts.add(self)
 
     def _adopt(self, child):
         import weakref

@@ -28,6 +28,14 @@ def load() -> ctypes.CDLL:
         if not os.path.exists(LIB_PATH):
             build()
         _lib = ctypes.CDLL(LIB_PATH)
+        # OpenMP would start one thread per core of the MACHINE; a box that grants this process a share of them
+        # (cgroup / affinity) then thrashes -- 35 s instead of 0.3 s for a k = 9 proof on the GPU box.  Default to the
+        # cores this process may use, 16 at most; callers may raise or lower it (orc_set_threads).
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        _lib.orc_set_threads(max(1, min(cores, 16)))
     return _lib
 
 

@@ -6,6 +6,7 @@ import threading
 
 import numpy as np
 import pytest
+import torch  # (before the first HIP call of the process: torch ships its own HIP runtime and wants to be the one that loads it)
 
 from circuits import toy_circuit
 
@@ -103,8 +104,6 @@ def test_batch_with_one_failing_lookup(ctx, zg, orc):
 def test_batch_from_device_slots(ctx, zg, orc):
     """Advice written straight into the prover's slots (zg_prover_advice_slot) and proved in place, twice: a proof
     rewrites only the blinding rows of its columns."""
-    import torch
-
     cs, asg, ilen, pk, prover = _toy(orc, zg, ctx, 7, force_degree=6)
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
     prover.set_batch(3)
