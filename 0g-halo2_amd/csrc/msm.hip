@@ -33,10 +33,10 @@ int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
 int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
 
-#ifndef ZG_MSM_K
-#define ZG_MSM_K 32
-#endif
-constexpr uint32_t MSM_K = ZG_MSM_K;  // max points per accumulate task (32 halves the partials the reduction merges; 16 measured 2 % slower)
+// Max points per accumulate task.  Throughput form: 32 (half the partials for the reduction to merge: 0.847 -> 0.830
+// ms/proof); latency form: 16 (a lone proof's accumulate launch fills the chip only once or twice over, so shorter
+// tasks = shorter launch: 3.0 vs 3.85 ms).
+constexpr uint32_t MSM_K_THROUGHPUT = 32, MSM_K_LATENCY = 16;
 constexpr uint32_t MSM_MAX_C = 16;
 constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
 
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ toff, uint32_t* __restrict__ tot,
                                                         uint32_t* __restrict__ ttotal, uint32_t* __restrict__ hmap,
                                                         uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
-                                                        uint32_t max_heavy, uint32_t* __restrict__ off) {
+                                                        uint32_t max_heavy, uint32_t* __restrict__ off, uint32_t MSM_K) {
     extern __shared__ uint32_t scan_smem[];  // [nb+2] bucket totals -> entry offsets
     __shared__ uint32_t se[1024], st[1024];
     __shared__ uint32_t hcount;
@@ -814,6 +814,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         return ZG_OK;
     }
+    const uint32_t MSM_K = ctx->msm_pair ? MSM_K_LATENCY : MSM_K_THROUGHPUT;
     const uint64_t entries = (uint64_t)N * W;
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
     uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
@@ -892,7 +893,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
-              ttotal, hmap, hlist, nheavy, max_heavy, off);
+              ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K);
     if (getenv("ZG_MSM_DEBUG")) {  // tuning aid: hot buckets and tasks per vector
         std::vector<uint32_t> hn(B), tt(B);
         ZG_HIP(hipStreamSynchronize(ctx->stream));

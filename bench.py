@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- create_proof of zero_g's WNN circuit on MI355X (BASELINE.json metric).
 
-A "step" is `--provers` (default 4) lock-step batches of `--batch` (default 16) full create_proofs each: every
+A "step" is `--provers` (default 8) lock-step batches of `--batch` (default 16) full create_proofs each: every
 prover works on its own HIP stream from its own host thread (while one batch waits for its transcript hashes on
 the host, the other keeps the GPU busy) and makes its B proofs with ONE launch sequence (zg_prover_prove_batch: the
 commitments of a phase are one MSM over B x columns vectors, evaluate_h one grid with a row of workgroups per
@@ -38,7 +38,7 @@ sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
 sys.path.insert(0, os.path.join(ROOT, "harness"))
 # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); every prover stream
 # should have a queue of its own, next to torch's and RCCL's.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 import torch
@@ -126,13 +126,28 @@ class Stream:
         return self.last
 
 
-def make_streams(dev_index: int, c: Circuit, ctx0: zg.Ctx, nprovers: int, batch: int, rank: int, exchange=None, shard=(0, 1)):
+def make_streams(dev_index: int, c: Circuit, ctx0: zg.Ctx, nprovers: int, batch: int, rank: int, exchange=None, shard=(0, 1),
+                 probe=None):
+    """The provers of one GPU: the first, then its forks (same proving key and base tables) on contexts of their own.
+    ORDER MATTERS: HIP hands out hardware queues in stream-creation order and the chip runs four compute pipes, so
+    streams whose queue indices are equal mod 4 share a pipe.  The four throughput streams are therefore created first
+    and back to back (queues 0-3: one pipe each; any other order measured 0.89 instead of 0.83 ms/proof), and the lone
+    proof of the latency probe runs on a further fork created after them, whose main and side stream land on queues 4
+    and 5 -- two different pipes again (3.0 ms; 3.8 ms when the pair shares one)."""
+    base = 0 if shard[1] > 1 else rank * 64  # (ranks of a sharded proof prove the SAME statements with the same keys)
     ctxs = [ctx0] + [zg.Ctx(dev_index) for _ in range(nprovers - 1)]
     first = zg.Prover(ctx0, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
+    first.set_overlap(False)  # (before forking: a fork of a single-stream prover creates no side stream of its own)
     provers = [first] + [first.fork(x) for x in ctxs[1:]]
-    # (ranks of a sharded proof work on the SAME proofs -- same witness, same blinding keys; replicas differ by rank)
-    base = 0 if shard[1] > 1 else rank * 64
-    return ctxs, [Stream(ctxs[i], provers[i], c, batch, base + i, exchange, shard) for i in range(nprovers)]
+    streams = [Stream(ctxs[i], provers[i], c, batch, base + i, exchange, shard) for i in range(nprovers)]
+    probed = None
+    if probe:
+        pctx = zg.Ctx(dev_index)
+        lone = Stream(pctx, first.fork(pctx), c, 1, base + 63)
+        probed = probe(lone)
+        lone.prover.close()
+        pctx.close()
+    return ctxs, streams, probed
 
 
 def run_steps(streams, steps):
@@ -281,7 +296,7 @@ def main():
     ap.add_argument("--model", choices=sorted(MODELS), default="tiny",
                     help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
     ap.add_argument("--batch", type=int, default=16, help="proofs per lock-step batch (zg_prover_prove_batch)")
-    ap.add_argument("--provers", type=int, default=4, help="proof streams per GPU (provers sharing one proving key)")
+    ap.add_argument("--provers", type=int, default=8, help="proof streams per GPU (provers sharing one proving key)")
     ap.add_argument("--mode", choices=["replicas", "shard-msm"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
@@ -335,7 +350,9 @@ def main():
 
     ctx0 = zg.Ctx(dev_index)
     circuit = Circuit(ctx0, args.model, shard)
-    ctxs, streams = make_streams(dev_index, circuit, ctx0, nprov, batch, rank, exchange, shard)
+    want_probe = not (sharded or args.no_latency_probe)
+    ctxs, streams, probed = make_streams(dev_index, circuit, ctx0, nprov, batch, rank, exchange, shard,
+                                         probe=latency_probe if want_probe else None)
 
     def barrier():
         if dist is not None:
@@ -344,7 +361,7 @@ def main():
         for x in ctxs:
             x.sync()
 
-    latency_s, phases = latency_probe(streams[0]) if not (sharded or args.no_latency_probe) else (None, [0.0] * 8)
+    latency_s, phases = probed if probed else (None, [0.0] * 8)
     # timed region: every launch carries its own start / stop event (hipExtLaunchKernelGGL on the prover's stream): a
     # lock-step batch is ~100 launches for `batch` proofs, so timing them all costs nothing measurable
     dt, stats = measure(streams, ctxs, args.steps, args.warmup, barrier, profile=not args.no_kernel_events)
@@ -453,15 +470,18 @@ def main():
         others = {}
         for s in streams:
             s.prover.close()
+        for x in ctxs[1:]:
+            x.close()
+        ctxs = ctxs[:1]
         for m in ("small", "medium", "large"):
             c2 = Circuit(ctx0, m)
             b2 = batch if m != "large" else max(1, batch // 2)
-            cx, st2 = make_streams(dev_index, c2, ctx0, nprov, b2, rank)
-            lat, _ = latency_probe(st2[0])
+            np2 = min(nprov, 4)  # (memory: a k = 17 slot is 1.4 GiB)
+            cx, st2, (lat, _) = make_streams(dev_index, c2, ctx0, np2, b2, rank, probe=latency_probe)
             dt2, _ = measure(st2, cx, 3, 1, barrier)
-            others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * nprov * b2) * 1e3,
-                         "create_proof_wall_s": lat, "batch": b2, "provers": nprov,
-                         "proofs_per_hour": 3 * nprov * b2 / dt2 * 3600.0}
+            others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * np2 * b2) * 1e3,
+                         "create_proof_wall_s": lat, "batch": b2, "provers": np2,
+                         "proofs_per_hour": 3 * np2 * b2 / dt2 * 3600.0}
             for s in st2:
                 s.prover.close()
             c2.g_bases.free()
