@@ -954,9 +954,9 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
             uint32_t per = 1;
             while (per * MSM_STRIP_LANES < nstrips) per <<= 1;
             XYZZ9 *strip_u = sfx, *strip_loc = sfx + (size_t)B * nstrips;
-            ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, msm_strip_kernel, dim3((nstrips + 255) / 256, B), dim3(256), 0, partial,
+            ZG_LAUNCH(ctx, "msm_strip", msm_bytes, msm_strip_kernel, dim3((nstrips + 255) / 256, B), dim3(256), 0, partial,
                       toff, hmap, hsum, max_tasks, max_heavy, c, nstrips, strip_u, strip_loc);
-            ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, msm_strip_sum_kernel, dim3(B), dim3(MSM_STRIP_LANES), 0, strip_u, strip_loc,
+            ZG_LAUNCH(ctx, "msm_strip_sum", msm_bytes, msm_strip_sum_kernel, dim3(B), dim3(MSM_STRIP_LANES), 0, strip_u, strip_loc,
                       nstrips, per, d_out);
         } else {
             ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
