@@ -33,11 +33,13 @@ int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
 int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
 
-// Max points per accumulate task.  Throughput form: 32 (half the partials for the reduction to merge: 0.847 -> 0.830
-// ms/proof); latency form: 16 (a lone proof's accumulate launch fills the chip only once or twice over, so shorter
-// tasks = shorter launch: 3.0 vs 3.85 ms).
-constexpr uint32_t MSM_K_THROUGHPUT = 32, MSM_K_LATENCY = 16;
+// Max points per accumulate task.  Throughput form: 48 -- the fewer tasks, the fewer partial sums the reduction has
+// to merge, and since lanes take tasks in length-sorted order (msm_scan_kernel) longer tasks cost no lane
+// utilisation (tools/ab_bench.sh: 24 / 32 / 48 / 64 / 96 -> 0.779 / 0.779 / 0.771 / 0.780 / 0.778 ms/proof).  Latency
+// form: 16 (a lone proof's accumulate launch fills the chip only once or twice over: shorter tasks, shorter launch).
+constexpr uint32_t MSM_K_THROUGHPUT = 48, MSM_K_LATENCY = 16;
 constexpr uint32_t MSM_MAX_C = 16;
+constexpr uint32_t MSM_LEN_BINS = 128;  // task-length classes of the accumulate launch (lengths <= task size + 1 < 128)
 constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
 
 __device__ __forceinline__ Fe ld_fe_g(const Fe* p) {
@@ -222,16 +224,19 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ toff, uint32_t* __restrict__ tot,
                                                         uint32_t* __restrict__ ttotal, uint32_t* __restrict__ hmap,
                                                         uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
-                                                        uint32_t max_heavy, uint32_t* __restrict__ off, uint32_t MSM_K) {
+                                                        uint32_t max_heavy, uint32_t* __restrict__ off, uint32_t MSM_K,
+                                                        uint32_t* __restrict__ stoff, uint32_t* __restrict__ sbucket) {
     extern __shared__ uint32_t scan_smem[];  // [nb+2] bucket totals -> entry offsets
     __shared__ uint32_t se[1024], st[1024];
     __shared__ uint32_t hcount;
+    __shared__ uint32_t bins[MSM_LEN_BINS], bcur[MSM_LEN_BINS];
     const uint32_t nb = 1u << (c - 1);
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     uint32_t* to = toff + (size_t)b * (nb + 2);
     uint32_t* tt = tot + (size_t)b * (nb + 2);
     uint32_t* le = scan_smem;
     if (tid == 0) hcount = 0;
+    if (tid < MSM_LEN_BINS) bins[tid] = 0;
     const uint32_t* cb = cnt + (size_t)b * windows * (nb + 1);
     for (uint32_t k = tid; k <= nb; k += 1024) {
         uint32_t v = 0;
@@ -248,11 +253,62 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     for (uint32_t k = lo; k < hi; k++) {
         uint32_t v = le[k];
         es += v;
-        ts += (v + MSM_K - 1) / MSM_K;
+        const uint32_t nt = (v + MSM_K - 1) / MSM_K;
+        ts += nt;
+        atomicAdd(&bins[nt ? v / nt : 0u], 1u);  // (a bucket's tasks hold v / nt or one more entries: its length class)
     }
     se[tid] = es;
     st[tid] = ts;
     __syncthreads();
+    // ---- the order in which lanes take tasks: buckets by DESCENDING task length (a counting sort over the <= K + 1
+    // length classes), so that the 64 tasks of a wave run the same number of additions (+- 1); in bucket order the
+    // lengths of neighbouring buckets differ by up to a fifth and a wave runs as long as its longest task.  The
+    // partial sums keep their bucket-order slots (toff): only the lane -> task map changes.
+    uint32_t* sto = stoff + (size_t)b * (nb + 2);
+    uint32_t* sbk = sbucket + (size_t)b * (nb + 1);
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t l = MSM_LEN_BINS; l-- > 0;) {
+            bcur[l] = run;
+            run += bins[l];
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = lo; k < hi; k++) {
+        const uint32_t v = le[k];
+        const uint32_t nt = (v + MSM_K - 1) / MSM_K;
+        const uint32_t pos = atomicAdd(&bcur[nt ? v / nt : 0u], 1u);
+        sbk[pos] = k;
+        sto[pos] = nt;  // (task counts in sorted order: scanned into offsets below)
+    }
+    __syncthreads();
+    {
+        uint32_t sum = 0;
+        for (uint32_t q = lo; q < hi; q++) sum += sto[q];
+        // (se / st are still needed below: a third scan array would cost LDS, so this scan runs through registers and
+        //  the bins array's neighbour -- 1024 partial sums do not fit there either; reuse st after saving ts)
+        const uint32_t keep_t = st[tid];
+        __syncthreads();
+        st[tid] = sum;
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {
+            uint32_t v = 0;
+            if (tid >= o) v = st[tid - o];
+            __syncthreads();
+            st[tid] += v;
+            __syncthreads();
+        }
+        uint32_t base = st[tid] - sum;
+        for (uint32_t q = lo; q < hi; q++) {
+            const uint32_t v = sto[q];
+            sto[q] = base;
+            base += v;
+        }
+        if (tid == 1023) sto[nb + 1] = st[1023];
+        __syncthreads();
+        st[tid] = keep_t;
+        __syncthreads();
+    }
     for (uint32_t o = 1; o < 1024; o <<= 1) {
         uint32_t ve = 0, vt = 0;
         if (tid >= o) {
@@ -329,7 +385,8 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     uint32_t c, uint32_t windows, uint32_t n,
     const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
     const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ9* __restrict__ partial,
-    const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask, uint32_t per) {
+    const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask, uint32_t per,
+    const uint32_t* __restrict__ stoff, const uint32_t* __restrict__ sbucket) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = PAIR ? lane >> 1 : lane;
     const bool role_a = !PAIR || (lane & 1u) == 0;
@@ -341,15 +398,18 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* table = vj < split ? (runs ? run_a : table_a) : (runs ? run_b : table_b);
     const uint32_t nb = 1u << (c - 1);
     const uint32_t* to = toff + (size_t)b * (nb + 2);
-    // largest k with to[k] <= t  (to is non-decreasing, to[nb+1] = total > t)
+    // Lane t takes task t of the LENGTH-SORTED order (msm_scan_kernel): largest position q with sto[q] <= t (sto is
+    // non-decreasing, strictly increasing over the non-empty buckets, which come first; sto[nb+1] = total > t), the
+    // bucket at that position, and the task's index inside the bucket.
+    const uint32_t* sto = stoff + (size_t)b * (nb + 2);
     uint32_t lo = 0, hi = nb + 1;
     while (hi - lo > 1) {
         uint32_t mid = (lo + hi) >> 1;
-        if (to[mid] <= t) lo = mid;
+        if (sto[mid] <= t) lo = mid;
         else hi = mid;
     }
-    const uint32_t k = lo;
-    const uint32_t j = t - to[k];
+    const uint32_t k = sbucket[(size_t)b * (nb + 1) + lo];
+    const uint32_t j = t - sto[lo];
     // bucket k's entries are contiguous: [tot[k], tot[k+1])  (exclusive entry offsets); its nt = ceil(total / K)
     // tasks share them EVENLY (sizes differ by one at most): a wave's lanes then run nearly the same number of
     // additions, where a full / full / ... / remainder split leaves the remainder's lane idle for most of the loop
@@ -360,7 +420,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const uint32_t start = first + j * share + (j < extra ? j : extra);
     const uint32_t len = share + (j < extra ? 1u : 0u);
     const uint32_t* so = sorted + (size_t)b * windows * n + start;
-    XYZZ9* dst = partial + (size_t)b * max_tasks + t;
+    XYZZ9* dst = partial + (size_t)b * max_tasks + to[k] + j;  // (the bucket-order slot the reduction reads)
     bool inf = true;
     if constexpr (PAIR) {
         PairAcc acc;
@@ -814,7 +874,8 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         return ZG_OK;
     }
-    const uint32_t MSM_K = ctx->msm_pair ? MSM_K_LATENCY : MSM_K_THROUGHPUT;
+    static const uint32_t k_env = getenv("ZG_MSM_K") ? (uint32_t)atoi(getenv("ZG_MSM_K")) : 0;  // A/B knob
+    const uint32_t MSM_K = ctx->msm_pair ? MSM_K_LATENCY : (k_env >= 4 && k_env <= 120 ? k_env : MSM_K_THROUGHPUT);
     const uint64_t entries = (uint64_t)N * W;
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
     uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
@@ -854,6 +915,8 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     uint32_t* toff = ws.get<uint32_t>((size_t)B * (nb + 2));
     uint32_t* tot = ws.get<uint32_t>((size_t)B * (nb + 2));
     uint32_t* ttotal = ws.get<uint32_t>(B);
+    uint32_t* stoff = ws.get<uint32_t>((size_t)B * (nb + 2));
+    uint32_t* sbucket = ws.get<uint32_t>((size_t)B * (nb + 1));
     uint32_t* sorted = ws.get<uint32_t>((size_t)B * entries);
     XYZZ9* partial = ws.get<XYZZ9>((size_t)B * max_tasks);
     XYZZ9* blk_w = ws.get<XYZZ9>((size_t)B * nblk);
@@ -893,7 +956,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
-              ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K);
+              ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket);
     if (getenv("ZG_MSM_DEBUG")) {  // tuning aid: hot buckets and tasks per vector
         std::vector<uint32_t> hn(B), tt(B);
         ZG_HIP(hipStreamSynchronize(ctx->stream));
@@ -916,11 +979,11 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     if (ctx->msm_pair) {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<true>, dim3((2 * max_tasks + 255) / 256, B), dim3(256),
                   0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket);
     } else {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<false>, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
                   bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket);
     }
     // hot buckets are few (repeated or tiny scalars put one or two per window at most); the kernel strides over
     // the list, so a small grid serves any count -- and costs microseconds, not tens of them, when there are none

@@ -287,8 +287,15 @@ void free_slots(zg_prover* p) {
     p->uploaded_lists.clear();
 }
 
-// (re)allocates every per-proof buffer for `cap` proofs in flight
+int alloc_slots_impl(zg_prover* p, uint32_t cap);
+// (re)allocates every per-proof buffer for `cap` proofs in flight; on failure the prover is left without slots
+// (zg_prover_prove* then refuse with "0 slots") rather than with half of them
 int alloc_slots(zg_prover* p, uint32_t cap) {
+    const int st = alloc_slots_impl(p, cap);
+    if (st != ZG_OK) free_slots(p);
+    return st;
+}
+int alloc_slots_impl(zg_prover* p, uint32_t cap) {
     const PkDev& k = *p->pk;
     ZG_REQUIRE(cap >= 1 && cap <= 1024, ZG_ERR_INVALID_ARG, "zg_prover: batch of %u proofs", cap);
     free_slots(p);
