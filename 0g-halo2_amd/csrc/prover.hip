@@ -129,7 +129,16 @@ struct zg_prover {
     zg_ctx* ctx = nullptr;
     std::shared_ptr<PkDev> pk;
     zg_bases *g = nullptr, *gl = nullptr;
-    bool own_bases = true;  // false: tables shared with other provers of the same device
+    // base tables the prover registered itself (zg_prover_create): owned jointly with its forks, freed with the last
+    // of them; null when the caller registered the tables (zg_prover_create_shared) and keeps them alive
+    struct OwnedBases {
+        zg_bases *g = nullptr, *gl = nullptr;
+        ~OwnedBases() {
+            if (g) zg_bases_free(g);
+            if (gl) zg_bases_free(gl);
+        }
+    };
+    std::shared_ptr<OwnedBases> owned_bases;
     bool use_side = true;   // coefficient / coset forms on a side stream (latency) or inline (throughput)
     // point-range shard of the commitments (zg_prover_set_shard): this prover's base sets hold points
     // [shard_lo, shard_lo + shard_n) of the SRS; partial commitments of all ranks are exchanged and summed
@@ -465,10 +474,7 @@ void zg_prover_destroy(zg_prover* p) {
         (void)hipStreamSynchronize(p->ctx->stream);
         if (p->ctx->side) (void)hipStreamSynchronize(p->ctx->side->stream);
         free_slots(p);
-        if (p->own_bases) {
-            if (p->g) zg_bases_free(p->g);
-            if (p->gl) zg_bases_free(p->gl);
-        }
+        p->owned_bases.reset();  // (the tables go with the last prover that uses them)
         if (p->ev) (void)hipEventDestroy(p->ev);
         if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
         if (p->ev_join) (void)hipEventDestroy(p->ev_join);
@@ -664,15 +670,17 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
                    "zg_prover_create_shared: bases do not match 2^k = %u points", n);
         p->g = const_cast<zg_bases*>(shared_g);
         p->gl = const_cast<zg_bases*>(shared_gl);
-        p->own_bases = false;
     } else {
+        p->owned_bases = std::make_shared<zg_prover::OwnedBases>();
         WsScope ws(ctx);
         Affine* d = ws.get<Affine>(n);
         if (!d) return ZG_ERR_OOM;
         ZG_HIP(hipMemcpyAsync(d, g, (size_t)n * sizeof(Affine), hipMemcpyHostToDevice, st));
-        ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->g));
+        ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->owned_bases->g));
         ZG_HIP(hipMemcpyAsync(d, g_lagrange, (size_t)n * sizeof(Affine), hipMemcpyHostToDevice, st));
-        ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->gl));
+        ZG_TRY(bases_register_dev(ctx, d, n, 0, &p->owned_bases->gl));
+        p->g = p->owned_bases->g;
+        p->gl = p->owned_bases->gl;
     }
     // (fewer points than 2^k: a point-range shard of the SRS; zg_prover_set_shard names the range before the first proof)
     p->shard_lo = 0;
@@ -819,7 +827,7 @@ int zg_prover_fork(const zg_prover* parent, zg_ctx* ctx, zg_prover** out) {
     p->pk = parent->pk;
     p->g = parent->g;
     p->gl = parent->gl;
-    p->own_bases = false;  // (the parent, or whoever registered them, keeps the tables alive)
+    p->owned_bases = parent->owned_bases;  // (joint ownership; null when the caller registered the tables)
     p->use_side = parent->use_side;
     p->shard_lo = parent->shard_lo; p->shard_n = parent->shard_n; p->world = parent->world; p->rank = parent->rank;
     p->exchange = parent->exchange; p->exchange_user = parent->exchange_user;

@@ -248,7 +248,9 @@ int zg_prover_create_shared(zg_ctx *ctx, const zg_circuit *circuit, const zg_fr 
                             const zg_fr *sigma_values, const zg_bases *g, const zg_bases *g_lagrange,
                             const zg_fr *vk_repr, zg_prover **out);
 /* A second prover on the SAME proving key (no copy: the key's HBM is shared and freed with its last prover) and
- * the same base tables, on another context of the device -- another stream of proofs or proof batches. */
+ * the same base tables (tables the parent registered itself are owned jointly and freed with the last prover; tables
+ * the caller registered stay the caller's), on another context of the device -- another stream of proofs or proof
+ * batches. */
 int zg_prover_fork(const zg_prover *parent, zg_ctx *ctx, zg_prover **out);
 void zg_prover_destroy(zg_prover *p);
 

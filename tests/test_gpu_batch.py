@@ -245,3 +245,34 @@ def test_threads_sharing_one_context_serialise(ctx, zg, orc):
         assert proof == orc.create_proof(pk, adv, inst, 10 * s + r)[1]
     bases.free()
     prover.close()
+
+
+@pytest.mark.parametrize("kind", ["no_lookup", "gates_only", "wide_lookup", "advice_factor", "merged_selectors"])
+def test_batch_of_circuit_variants(ctx, zg, orc, kind):
+    """The prover's less common paths in batch form: no lookups (the random polynomial rides with the permutation
+    products), neither lookups nor permutation (it is committed on its own), no instance column, two instance columns,
+    width-2 lookups, factored gates -- three proofs per batch under different keys, both scheduling forms."""
+    from circuits import variant_circuit
+
+    k = 6
+    cs, asg, ilen = variant_circuit(kind, k=k)
+    img = cs.to_c()
+    params = orc.params_new(k, 0xABCDEF)
+    vk_repr = orc.fr_from_int(99)
+    fixed, sigma = asg.fixed_values(), asg.sigma_values()
+    pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
+    prover = zg.Prover(ctx, img, fixed, sigma, params.g_np(), params.g_lagrange_np(), vk_repr)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    prover.set_batch(3)
+    seeds = [31, 32, 33]
+    want = []
+    for s in seeds:
+        st, proof, _ = orc.create_proof(pk, adv, inst, s)
+        assert st == 0
+        want.append(proof)
+    for overlap in (True, False):
+        prover.set_overlap(overlap)
+        got, sts = prover.prove_batch([adv] * 3, [inst] * 3, seeds)
+        assert sts == [0, 0, 0] and got == want, (kind, overlap)
+    assert orc.verify_proof_pairing(pk, inst, want[2]) == 1
+    prover.close()
