@@ -100,6 +100,9 @@ class Circuit:
         self.gl_bases = ctx.register_bases(self.gl[self.lo:self.hi])
 
 
+HOST_ADVICE = False  # --host-advice: measure the PCIe-inclusive rate (never the headline `value`)
+
+
 class Stream:
     """One proof stream: a prover (own context = own HIP stream + workspace; proving key shared with the others) with
     `batch` slots whose advice columns are resident in HBM; step() = one lock-step batch of create_proofs."""
@@ -122,7 +125,10 @@ class Stream:
     def step(self):
         self.steps += 1
         self.last_seeds = self.seeds()
-        self.last = self.prover.prove_batch(None, [self.c.instance] * self.batch, self.last_seeds, device=True)[0]
+        if HOST_ADVICE:  # the host-pointer entry: every proof's columns cross PCIe (3 MiB per proof at k = 14)
+            self.last = self.prover.prove_batch([self.c.advice] * self.batch, [self.c.instance] * self.batch, self.last_seeds)[0]
+        else:
+            self.last = self.prover.prove_batch(None, [self.c.instance] * self.batch, self.last_seeds, device=True)[0]
         return self.last
 
 
@@ -302,9 +308,13 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other three models")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--host-advice", action="store_true",
+                    help="every proof uploads its advice columns from host memory (PCIe-inclusive rate, for DESIGN.md)")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the lone-proof latency measurement (counter passes)")
     args = ap.parse_args()
 
+    global HOST_ADVICE
+    HOST_ADVICE = args.host_advice
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -450,6 +460,7 @@ def main():
                                        f"1 lock-step batch of {batch} proofs in flight" if sharded else
                                        f"{world} GPU(s) x {nprov} prover stream(s) x lock-step batches of {batch} proofs")},
             "mode": args.mode if world > 1 else "single-gpu",
+            "inputs": "host memory, uploaded per proof" if HOST_ADVICE else "resident in HBM",
             "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
             "create_proof_wall_s": latency_s, "provers_per_gpu": nprov, "batch": batch,
             "launches_per_proof": launches_per_proof,
@@ -494,6 +505,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(circuit, len(streams[0].last[0]), host_cores())
         print(json.dumps(out))
     if dist is not None:
+        dist.barrier()  # (rank 0 checks its proofs against the oracle after the timed region: the others wait here)
         dist.destroy_process_group()
 
 
