@@ -352,6 +352,8 @@ def main():
     shard = (rank, world) if sharded else (0, 1)
     nprov = 1 if sharded else max(1, args.provers)  # (the exchange is a collective: one stream of batches per rank)
     batch = max(1, args.batch)
+    if args.model == "large":
+        batch = min(batch, 8)  # (a k = 17 proof slot is 1.4 GiB; 8 provers x 8 slots + workspaces stay well inside 288 GB)
     exchange = None
     if sharded:
         import multi_gpu

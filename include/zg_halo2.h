@@ -261,7 +261,8 @@ void zg_prover_destroy(zg_prover *p);
  * blinding key.  Proof bytes are those of the one-at-a-time calls. */
 int zg_prover_set_batch(zg_prover *p, size_t max_batch);
 size_t zg_prover_batch(const zg_prover *p);
-/* Device address of slot `slot`'s advice columns, [n_advice][2^k] (a witness generator may write there directly). */
+/* Device address of slot `slot`'s advice columns, [n_advice][2^k] (a witness generator may write there directly);
+ * valid until the next zg_prover_set_batch. */
 void *zg_prover_advice_slot(zg_prover *p, size_t slot);
 /* count <= max_batch proofs.  advice[b]: [n_advice][2^k] column values of proof b (host), or NULL when the slot
  * already holds them; the last blinding_factors+1 rows are overwritten with blinding scalars as create_proof does.
