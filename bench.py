@@ -195,7 +195,7 @@ def algorithmic_bytes_per_proof(cs) -> float:
 
 FAMILIES = {"msm": ("msm_",), "ntt": ("ntt_",), "evaluate_h": ("evaluate_h",), "sort": ("sort_", "permute_"),
             "products": ("grand_product", "lookup_", "perm_terms", "permuted_finish", "blind_rows", "random_poly"),
-            "openings": ("eval_dot", "powers", "horner_combine", "kate_", "fold", "diff_scale", "split_combine")}
+            "openings": ("eval_dot", "powers", "horner_combine", "kate_", "fold", "diff_scale", "split_combine")}  # (ZG_LAUNCH labels)
 
 
 def family_of(kernel: str) -> str:

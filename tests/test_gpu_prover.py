@@ -121,20 +121,30 @@ def test_unsatisfied_witness_still_proves_but_does_not_verify(ctx, zg, orc):
     prover.close()
 
 
+@pytest.mark.parametrize("latency_form", [True, False])
 @pytest.mark.parametrize("n", [1, 2, 5, 1000, 1024, 1025, 1 << 14, (1 << 17) + 3])
-def test_grand_product(ctx, zg, orc, n):
+def test_grand_product(ctx, zg, orc, n, latency_form):
+    """Both forms of the scan: block-local Hillis-Steele (latency) and one strip per lane (throughput)."""
     num, den = orc.fill_fr(1, n), orc.fill_fr(2, n)
     if n > 4:
         den[3] = 0  # BatchInvert leaves zeros alone -> that ratio is zero
+    if n > 2000:
+        den[1500] = 0
     z0 = orc.fill_fr(3, 1)[0]
     dn, dd = dev(num), dev(den)
     dz = torch.empty_like(dn)
-    ctx.grand_product_dev(dn.data_ptr(), dd.data_ptr(), z0, n, dz.data_ptr())
-    assert np.array_equal(host(dz), orc.grand_product(num, den, z0))
+    ctx.set_msm_latency(latency_form)
+    try:
+        ctx.grand_product_dev(dn.data_ptr(), dd.data_ptr(), z0, n, dz.data_ptr())
+        assert np.array_equal(host(dz), orc.grand_product(num, den, z0))
+        assert np.array_equal(ctx.grand_product(num, den, z0), orc.grand_product(num, den, z0))  # host-pointer entry
+    finally:
+        ctx.set_msm_latency(True)
 
 
-@pytest.mark.parametrize("n", [1, 7, 1 << 10, 1 << 14])
-def test_eval_polys_and_kate_division(ctx, zg, orc, n):
+@pytest.mark.parametrize("latency_form", [True, False])
+@pytest.mark.parametrize("n", [1, 7, 1 << 10, (1 << 10) + 5, 1 << 14, (1 << 15) + 1])
+def test_eval_polys_and_kate_division(ctx, zg, orc, n, latency_form):
     polys = np.stack([orc.fill_fr(10 + i, n) for i in range(3)])
     pts = orc.fill_fr(99, 4)
     d = dev(polys)
@@ -143,7 +153,11 @@ def test_eval_polys_and_kate_division(ctx, zg, orc, n):
     for j, pi in enumerate(idx):
         assert np.array_equal(got[j], orc.eval_poly(polys[pi], pts[j]))
     dq = torch.empty((n, 4), dtype=torch.int64, device="cuda")
-    ctx.kate_division_dev(d.data_ptr(), n, pts[0], dq.data_ptr())
+    ctx.set_msm_latency(latency_form)
+    try:
+        ctx.kate_division_dev(d.data_ptr(), n, pts[0], dq.data_ptr())
+    finally:
+        ctx.set_msm_latency(True)
     assert np.array_equal(host(dq), orc.kate_division(polys[0], pts[0]))
 
 

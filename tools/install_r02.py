@@ -35,8 +35,10 @@ def launch_name(kernel: str) -> str:
         return "ntt_cols" if cols else ("ntt_single" if first else "ntt_rows")
     k = k.split("(")[0].split("<")[0]
     k = re.sub(r"_kernel$", "", k)
-    alias = {"gp_local": "grand_product_local", "gp_totals": "grand_product_totals", "gp_apply": "grand_product_apply",
-             "dot": "eval_dot", "kd_local": "kate_local", "kd_heads": "kate_heads", "kd_apply": "kate_apply",
+    alias = {"gp_strip_scan": "grand_product_scan", "gp_strip_apply": "grand_product_apply", "gp_local": "grand_product_local",
+             "gp_totals": "grand_product_totals", "gp_apply": "grand_product_apply", "kd_local": "kate_local",
+             "kd_heads": "kate_heads", "kd_apply": "kate_apply",
+             "dot": "eval_dot", "kd_strip": "kate_division",
              "pp_flags": "permute_flags", "pp_scan": "permute_scan", "pp_leftover": "permute_leftover",
              "pp_build": "permute_build", "random_and_blind": "random_poly", "evaluate_h9": "evaluate_h",
              "horner_combine_sets": "horner_combine", "sort_global_fused": "sort_global", "gate_factor9": "gate_factor"}
@@ -55,7 +57,7 @@ def batches(path, counter):
             out.append(cur)
         if cur is not None:
             cur.append((n, float(r["Counter_Value"])))
-    return [b for b in out if any(n == "kate_apply" for n, _ in b)]  # complete ones
+    return [b for b in out if any(n == "kate_division" for n, _ in b)]  # complete ones
 
 
 def per_launch(path, counter):
