@@ -287,6 +287,57 @@ int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
     return zg_xyzz_sum_ranks(all.data(), p->world, count, reinterpret_cast<zg_g1*>(out.data()));
 }
 
+// the scalars evaluate_h reads, in the form it computes in (theta, beta, gamma already in c)
+void evalh_consts(ProofConst& c, const Fe& y, bool hat) {
+    const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
+    c.eh_y = y; c.eh_beta = c.beta; c.eh_gamma = c.gamma; c.eh_theta = c.theta;
+    c.eh_delta_start[0] = Fr::mul(c.beta, zeta);   // beta * coset shift
+    c.eh_delta_start[1] = Fr::mul(c.beta, zeta2);
+    if (hat) {
+        const Fe c261 = Fr9Params::c261_fe();
+        for (Fe* cst : {&c.eh_y, &c.eh_beta, &c.eh_gamma, &c.eh_theta, &c.eh_delta_start[0], &c.eh_delta_start[1]})
+            *cst = Fr::mul(*cst, c261);
+    }
+}
+
+// evaluate_h's arguments for part `di` of the extended domain: the proving key's slabs, the per-proof slabs of this
+// prover's slots (proof b at b * cos_bs), scalars from d_pc
+EvalHArgs evalh_args(const zg_prover* p, uint32_t di) {
+    const PkDev& pk = *p->pk;
+    const uint32_t n = pk.n, k = pk.k, bf = pk.bf, A = pk.A, I = pk.I, NL = pk.NL, S = pk.sets;
+    const bool hat = pk.hat;
+    const PkDev::Dom& d = pk.dom[di];
+    const Fe* cos = p->dbuf[di].cos;
+    EvalHArgs a;
+    memset(&a, 0, sizeof(a));
+    a.c = pk.dc;
+    a.cols.fixed = d.fixed_cos; a.cols.advice = cos; a.cols.instance = cos + (size_t)A * d.en;
+    a.cols.log_size = d.ek; a.cols.rot_scale = (int32_t)(d.en / n);
+    a.cols.adv_bs = a.cols.inst_bs = (size_t)p->ncos * d.en;
+    a.sigma_cos = d.sigma_cos;
+    a.pz_cos = cos + (size_t)(A + I) * d.en;
+    a.lz_cos = a.pz_cos + (size_t)S * d.en;
+    // the a'/s' cosets are interleaved, [2l] = a'_l and [2l+1] = s'_l: two views with a stride of two slabs
+    a.pin_cos = a.lz_cos + (size_t)NL * d.en; a.ptab_cos = a.pin_cos + d.en; a.perm_stride = (size_t)2 * d.en;
+    a.l0 = d.l0; a.llast = d.llast; a.lactive = d.lactive;
+    a.ext_tw = hat ? d.ext_tw + d.en : d.ext_tw;  // (the twiddle table's second half is the 2^261 form)
+    a.t_eval = d.t_eval; a.t_mask = (1u << (d.ek - k)) - 1;
+    a.last_rot = -(int32_t)(bf + 1);
+    a.pc = p->d_pc; a.zpow = (uint32_t)d.zpow;
+    a.cos_bs = (size_t)p->ncos * d.en; a.h_bs = d.en;
+    a.delta = hat ? Fr::mul(fr_delta(), Fr9Params::c261_fe()) : fr_delta();
+    a.hat = hat;
+    a.monos_hat = pk.monos_hat;
+    a.gates_hat = pk.gates_hat;
+    a.gate_common = pk.gate_common;
+    a.gate_uni = pk.gate_uni;
+    a.uni_coef = pk.uni_coef;
+    a.gate_slab = pk.gate_slab;
+    a.gate_slabs = d.gate_slabs;
+    a.h = p->dbuf[di].h;
+    return a;
+}
+
 void free_slots(zg_prover* p) {
     for (void* q : p->slot_owned) (void)hipFree(q);
     p->slot_owned.clear();
@@ -1099,20 +1150,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     }
     for (uint32_t b = 0; b < nb; b++) tr[b].write_point(random_commit[b]);
     ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
-    {
-        const Fe c261 = Fr9Params::c261_fe();
-        const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
-        for (uint32_t b = 0; b < nb; b++) {
-            ProofConst& c = p->hpc[b];
-            const Fe y = tr[b].squeeze();
-            c.eh_y = y; c.eh_beta = c.beta; c.eh_gamma = c.gamma; c.eh_theta = c.theta;
-            c.eh_delta_start[0] = Fr::mul(c.beta, zeta);   // beta * coset shift
-            c.eh_delta_start[1] = Fr::mul(c.beta, zeta2);
-            if (hat)
-                for (Fe* cst : {&c.eh_y, &c.eh_beta, &c.eh_gamma, &c.eh_theta, &c.eh_delta_start[0], &c.eh_delta_start[1]})
-                    *cst = Fr::mul(*cst, c261);
-        }
-    }
+    for (uint32_t b = 0; b < nb; b++) evalh_consts(p->hpc[b], tr[b].squeeze(), hat);
     ZG_TRY(upload_consts(p, nb));
     lap(2);
 
@@ -1121,36 +1159,8 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     if (split) ZG_TRY(to_cosets(ctx, p->ix_adv, p->ncos));
     // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
     for (uint32_t di = dlo; di < dhi; di++) {
-        const PkDev::Dom& d = pk.dom[di];
-        const Fe* cos = p->dbuf[di].cos;
-        EvalHArgs a;
-        memset(&a, 0, sizeof(a));
-        a.c = pk.dc;
-        a.cols.fixed = d.fixed_cos; a.cols.advice = cos; a.cols.instance = cos + (size_t)A * d.en;
-        a.cols.log_size = d.ek; a.cols.rot_scale = (int32_t)(d.en / n);
-        a.cols.adv_bs = a.cols.inst_bs = (size_t)p->ncos * d.en;
-        a.sigma_cos = d.sigma_cos;
-        a.pz_cos = cos + (size_t)(A + I) * d.en;
-        a.lz_cos = a.pz_cos + (size_t)S * d.en;
-        // the a'/s' cosets are interleaved, [2l] = a'_l and [2l+1] = s'_l: two views with a stride of two slabs
-        a.pin_cos = a.lz_cos + (size_t)NL * d.en; a.ptab_cos = a.pin_cos + d.en; a.perm_stride = (size_t)2 * d.en;
-        a.l0 = d.l0; a.llast = d.llast; a.lactive = d.lactive;
-        a.ext_tw = hat ? d.ext_tw + d.en : d.ext_tw;  // (the twiddle table's second half is the 2^261 form)
-        a.t_eval = d.t_eval; a.t_mask = (1u << (d.ek - k)) - 1;
-        a.last_rot = -(int32_t)(bf + 1);
-        a.pc = p->d_pc; a.zpow = (uint32_t)d.zpow;
-        a.cos_bs = (size_t)p->ncos * d.en; a.h_bs = d.en;
-        a.delta = hat ? Fr::mul(fr_delta(), Fr9Params::c261_fe()) : fr_delta();
-        a.hat = hat;
-        a.monos_hat = pk.monos_hat;
-        a.gates_hat = pk.gates_hat;
-        a.gate_common = pk.gate_common;
-        a.gate_uni = pk.gate_uni;
-        a.uni_coef = pk.uni_coef;
-        a.gate_slab = pk.gate_slab;
-        a.gate_slabs = d.gate_slabs;
-        a.h = p->dbuf[di].h;
-        ZG_TRY(poly_evaluate_h(ctx, a, d.en, nb));
+        const EvalHArgs a = evalh_args(p, di);
+        ZG_TRY(poly_evaluate_h(ctx, a, pk.dom[di].en, nb));
     }
     p->have_last = true;
     p->last_split = split;
@@ -1463,6 +1473,51 @@ int zg_prover_fetch(zg_prover* p, uint32_t what, uint32_t index, zg_fr* out, siz
 }
 
 // ---- stand-alone building blocks ----
+// Evaluator::evaluate_h (+ vanishing::Argument::construct's division by X^n - 1) for ONE circuit instance over this
+// prover's resident proving key: from the coefficient forms of the witness-side polynomials and the four challenges
+// to h on EvaluationDomain's extended coset (2^ext_k values, library form).  Host pointers: this is the
+// arithmetic-level entry; inside create_proof the same kernel runs on slabs that never leave HBM.
+int zg_prover_evaluate_h(zg_prover* p, const zg_fr* advice_polys, const zg_fr* instance_polys, const zg_fr* perm_z_polys,
+                         const zg_fr* lookup_z_polys, const zg_fr* permuted_polys, const zg_fr* theta, const zg_fr* beta,
+                         const zg_fr* gamma, const zg_fr* y, zg_fr* h_out) {
+    ZG_REQUIRE(p && theta && beta && gamma && y && h_out, ZG_ERR_INVALID_ARG, "zg_prover_evaluate_h: null argument");
+    const PkDev& pk = *p->pk;
+    ZG_REQUIRE((advice_polys || !pk.A) && (instance_polys || !pk.I) && (perm_z_polys || !pk.sets) &&
+                   (lookup_z_polys || !pk.NL) && (permuted_polys || !pk.NL),
+               ZG_ERR_INVALID_ARG, "zg_prover_evaluate_h: a polynomial family is missing");
+    ZG_REQUIRE(p->cap >= 1, ZG_ERR_INVALID_ARG, "zg_prover_evaluate_h: the prover has no slot");
+    zg_ctx* ctx = p->ctx;
+    ZG_ENTER(ctx);
+    hipStream_t st = ctx->stream;
+    const uint32_t n = pk.n;
+    p->have_last = false;
+    // slot 0's coefficient slab, in its order: advice, instance, permutation z, lookup z, a'/s'
+    struct Fam { const zg_fr* src; uint32_t ix, count; };
+    const Fam fams[] = {{advice_polys, p->ix_adv, pk.A}, {instance_polys, p->ix_inst, pk.I}, {perm_z_polys, p->ix_pz, pk.sets},
+                        {lookup_z_polys, p->ix_lz, pk.NL}, {permuted_polys, p->ix_perm, 2 * pk.NL}};
+    for (const Fam& f : fams)
+        if (f.count)
+            ZG_HIP(hipMemcpyAsync(p->pp + (size_t)(f.ix - p->nsh) * n, f.src, (size_t)f.count * n * 32, hipMemcpyHostToDevice, st));
+    ProofConst& c = p->hpc[0];
+    memset(&c, 0, sizeof(c));
+    c.theta = to_fe(theta); c.beta = to_fe(beta); c.gamma = to_fe(gamma);
+    evalh_consts(c, to_fe(y), pk.hat);
+    p->stage_off = p->pin_stage;
+    ZG_TRY(upload_consts(p, 1));
+    const PkDev::Dom& d = pk.dom[0];
+    ZG_TRY(coeff_to_coset_dev(ctx, p->pp + (size_t)(p->ix_adv - p->nsh) * n, n, n, p->dbuf[0].cos, d.en, p->ncos, d.ek, pk.hat, d.zpow));
+    const EvalHArgs a = evalh_args(p, 0);
+    ZG_TRY(poly_evaluate_h(ctx, a, d.en, 1));
+    WsScope ws(ctx);
+    Fe* tmp = ws.get<Fe>(d.en);
+    if (!tmp) return ZG_ERR_OOM;
+    // (the nine-limb kernel leaves h as x * 2^261: hand back the library form)
+    ZG_TRY(poly_scale(ctx, p->dbuf[0].h, tmp, d.en, pk.hat ? Fr::inv(Fr::from_u64(32)) : Fr::one()));
+    ZG_HIP(hipMemcpyAsync(h_out, tmp, (size_t)d.en * 32, hipMemcpyDeviceToHost, st));
+    ZG_HIP(hipStreamSynchronize(st));
+    return ZG_OK;
+}
+
 int zg_grand_product_dev(zg_ctx* ctx, const void* d_num, const void* d_den, const zg_fr* z0, size_t n, void* d_z) {
     ZG_REQUIRE(ctx && d_num && d_den && d_z && z0, ZG_ERR_INVALID_ARG, "zg_grand_product_dev: null argument");
     ZG_REQUIRE(n < (1u << 28), ZG_ERR_UNSUPPORTED, "zg_grand_product_dev: n too large");

@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_set_overlap", "zg_ctx_set_msm_latency",
     "zg_prover_create_shared", "zg_prover_fork", "zg_prover_set_batch", "zg_prover_batch", "zg_prover_advice_slot",
     "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
-    "zg_grand_product", "zg_xyzz_sum_ranks",
+    "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
 ]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
@@ -497,6 +497,17 @@ class Prover:
         if st != 0 and raise_on_error:
             _check(st)
         return [bytes(bufs[b][: lens[b]]) for b in range(count)], list(sts)
+
+    def evaluate_h(self, advice_polys, instance_polys, perm_z_polys, lookup_z_polys, permuted_polys, theta, beta, gamma, y,
+                   extended_n: int) -> np.ndarray:
+        """Evaluator::evaluate_h / (X^n - 1) from coefficient forms (uint64[count, n, 4] each) -> uint64[extended_n, 4]."""
+        arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (advice_polys, instance_polys, perm_z_polys, lookup_z_polys,
+                                                                    permuted_polys)]
+        ptrs = [_ptr(a) if a.size else None for a in arrs]
+        out = np.zeros((extended_n, 4), np.uint64)
+        _check(self.ctx.lib.zg_prover_evaluate_h(self.h, *ptrs, _ptr(_fr(theta)), _ptr(_fr(beta)), _ptr(_fr(gamma)),
+                                                 _ptr(_fr(y)), _ptr(out)))
+        return out
 
     def set_overlap(self, enable: bool):
         """True (default): transforms on a side stream (latency); False: one stream per proof (throughput)."""

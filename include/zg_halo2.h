@@ -325,6 +325,16 @@ int zg_prover_phase_ms(const zg_prover *p, double *out, size_t cap);
 int zg_prover_set_overlap(zg_prover *p, int enable);
 
 /* Stand-alone building blocks of the above. */
+/* Evaluator::evaluate_h (halo2_proofs src/plonk/evaluation.rs) followed by the division by X^n - 1 of
+ * vanishing::Argument::construct, for ONE circuit instance over this prover's resident proving key.  Inputs are the
+ * coefficient forms upstream hands its evaluator -- advice_polys [n_advice][2^k], instance_polys [n_instance][2^k],
+ * perm_z_polys [sets][2^k] (permutation::Committed product polys), lookup_z_polys [lookups][2^k] and permuted_polys
+ * [2 * lookups][2^k] (a'_0, s'_0, a'_1, ...) -- and the challenges theta, beta, gamma, y; h_out receives h on
+ * EvaluationDomain's extended coset, 2^ext_k values.  Host pointers (the arithmetic-level entry: ~60 MiB cross PCIe
+ * at k = 14); slot 0 of the prover is used as scratch. */
+int zg_prover_evaluate_h(zg_prover *p, const zg_fr *advice_polys, const zg_fr *instance_polys, const zg_fr *perm_z_polys,
+                         const zg_fr *lookup_z_polys, const zg_fr *permuted_polys, const zg_fr *theta, const zg_fr *beta,
+                         const zg_fr *gamma, const zg_fr *y, zg_fr *h_out);
 /* z[0] = z0, z[i+1] = z[i] * num[i] / den[i], i + 1 < n  (the running product of lookup::prover::commit_product and
  * permutation::prover::commit; a zero denominator gives ratio 0, as halo2's BatchInvert leaves zeros alone).
  * Host pointers / device pointers. */

@@ -66,6 +66,9 @@ extern "C" {
     pub fn zg_prover_prove_batch(p: *mut zg_prover, count: usize, advice: *const *const Fr, instance: *const *const Fr,
                                  instance_len: usize, rng_keys: *const u8, proofs: *const *mut u8, cap: usize,
                                  lens: *mut usize, statuses: *mut c_int) -> c_int;
+    pub fn zg_prover_evaluate_h(p: *mut zg_prover, advice_polys: *const Fr, instance_polys: *const Fr, perm_z_polys: *const Fr,
+                                lookup_z_polys: *const Fr, permuted_polys: *const Fr, theta: *const Fr, beta: *const Fr,
+                                gamma: *const Fr, y: *const Fr, h_out: *mut Fr) -> c_int;
     pub fn zg_prover_set_shard(p: *mut zg_prover, rank: u32, world: u32, first_point: usize, exchange: zg_exchange_fn,
                                user: *mut c_void) -> c_int;
 }

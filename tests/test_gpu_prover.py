@@ -339,3 +339,41 @@ def test_large_shape_k17_verifies(ctx, zg, orc):
     assert got[0] == want and got[1] == orc.create_proof(pk, adv, inst, 4)[1]
     prover.close()
     assert orc.verify_proof_pairing(pk, inst, want) == 1
+
+
+@pytest.mark.parametrize("k,force_degree", [(6, None), (7, 6)])
+def test_stand_alone_evaluate_h_matches_oracle(ctx, zg, orc, k, force_degree):
+    """zg_prover_evaluate_h (the arithmetic-level entry for Evaluator::evaluate_h + the division by X^n - 1): fed the
+    coefficient forms of the oracle's own witness-side polynomials and its challenges, it must return the oracle's h on
+    the extended coset."""
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, k, force_degree=force_degree)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    seed = 21
+    st, _, tr = orc.create_proof(pk, adv, inst, seed, want_trace=True)
+    assert st == 0
+    n, en = 1 << k, 1 << cs.extended_k()
+    bf = cs.blinding_factors()
+    usable = n - (bf + 1)
+    blinded = adv.copy()
+    for c in range(cs.n_advice):  # create_proof's advice blinding: tag 1, index = column * (bf + 1) + j
+        for j in range(bf + 1):
+            blinded[c, usable + j] = orc.rand_fr(seed, 1, c * (bf + 1) + j)
+    inst_cols = np.zeros((cs.n_instance, n, 4), np.uint64)
+    inst_cols[:, :ilen] = inst
+    d = orc.domain(cs.degree(), k)
+    nl, sets = len(cs.lookups), tr.n_sets
+    pin = tr.array("permuted_input", nl * n).reshape(nl, n, 4)
+    ptab = tr.array("permuted_table", nl * n).reshape(nl, n, 4)
+    permuted = np.stack([x for l in range(nl) for x in (pin[l], ptab[l])]) if nl else np.zeros((0, n, 4), np.uint64)
+
+    def coeffs(cols):
+        return np.stack([orc.lagrange_to_coeff(d, c) for c in cols]) if len(cols) else np.zeros((0, n, 4), np.uint64)
+
+    got = prover.evaluate_h(coeffs(blinded), coeffs(inst_cols), coeffs(tr.array("perm_z", sets * n).reshape(sets, n, 4)),
+                            coeffs(tr.array("lookup_z", nl * n).reshape(nl, n, 4)), coeffs(permuted), tr.fe("theta"),
+                            tr.fe("beta"), tr.fe("gamma"), tr.fe("y"), en)
+    assert np.array_equal(got, tr.array("h_ext", en))
+    orc.trace_free(tr)
+    # the prover still proves afterwards (slot 0 was used as scratch)
+    assert prover.prove(adv, inst, 5) == orc.create_proof(pk, adv, inst, 5)[1]
+    prover.close()
