@@ -1,13 +1,12 @@
 #!/bin/bash
-# usage: tools/ab_model.sh MODEL "LABEL ENV=VAL ..." ...   (short runs of one model, 4 provers)
+# usage: tools/ab_model.sh MODEL "LABEL PROVERS BATCH [ENV=VAL ...]" ...   (short runs of one model)
 model=$1; shift
 out=gpurun_out/ab_model_$model.txt
 : > $out
 for cfg in "$@"; do
-  label=${cfg%% *}
-  envs=${cfg#* }
-  [ "$envs" = "$cfg" ] && envs=""
-  env $envs python bench.py --model $model --provers 4 --batch ${ZG_AB_BATCH:-16} --steps 4 --warmup 1 --no-other-configs --no-cpu-baseline --no-verify --no-latency-probe 2>/dev/null \
-    | python -c "import json,sys; d=json.load(sys.stdin); print('$model $label ms/proof %.4f' % d['ms_per_proof'])" >> $out
+  set -- $cfg
+  label=$1; p=$2; b=$3; shift 3
+  env "$@" python bench.py --model $model --provers $p --batch $b --steps 4 --warmup 1 --no-other-configs --no-cpu-baseline --no-verify --no-latency-probe 2>/dev/null \
+    | python -c "import json,sys; d=json.load(sys.stdin); print('$model $label provers $p batch $b ms/proof %.4f' % d['ms_per_proof'])" >> $out
 done
 cat $out
