@@ -177,6 +177,7 @@ struct zg_prover {
     size_t pinned_cap = 0, pin_results = 0, pin_evals = 0, pin_stage = 0;
     size_t stage_off = 0;
     bool have_last = false;
+    bool in_flight = false;   // a batch was started and did not reach its end (an error return): work may still be queued
     bool last_split = false;  // which extended domain the last proof used (zg_prover_fetch)
     uint32_t last_nb = 0;
     double phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -942,6 +943,11 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     std::vector<int> status(nb, ZG_OK);
     std::vector<Jac> pts;
     p->have_last = false;
+    if (p->in_flight) {  // the previous batch left through an error return: drain what it queued before its staging
+        (void)hipStreamSynchronize(st);  // arena and slots are reused
+        if (ctx->side) (void)hipStreamSynchronize(ctx->side->stream);
+    }
+    p->in_flight = true;
     p->stage_off = p->pin_stage;
     using clk = std::chrono::steady_clock;
     auto t_start = clk::now(), t_prev = t_start;
@@ -1097,6 +1103,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
             (void)hipStreamSynchronize(st);
             if (statuses) statuses[0] = status[0];
             proof_lens[0] = 0;
+            p->in_flight = false;
             return status[0];
         }
     }
@@ -1367,6 +1374,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     }
     lap(5);
     p->phase_ms[6] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
+    p->in_flight = false;
     return first_bad;
 }
 
