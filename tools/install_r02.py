@@ -23,7 +23,8 @@ BATCH = 16
 
 
 def one(pattern):
-    return glob.glob(os.path.join(src, pattern))[0]
+    """the newest match (gpurun merges into gpurun_out/ without clearing it: an older run's files may sit beside)"""
+    return max(glob.glob(os.path.join(src, pattern)), key=os.path.getmtime)
 
 
 def launch_name(kernel: str) -> str:
