@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- create_proof of zero_g's WNN circuit on MI355X (BASELINE.json metric).
 
-A "step" is `--provers` (default 8) lock-step batches of `--batch` (default 16) full create_proofs each: every
+A "step" is `--provers` (default 12) lock-step batches of `--batch` (default 16) full create_proofs each: every
 prover works on its own HIP stream from its own host thread (while one batch waits for its transcript hashes on
 the host, the other keeps the GPU busy) and makes its B proofs with ONE launch sequence (zg_prover_prove_batch: the
 commitments of a phase are one MSM over B x columns vectors, evaluate_h one grid with a row of workgroups per
@@ -302,7 +302,7 @@ def main():
     ap.add_argument("--model", choices=sorted(MODELS), default="tiny",
                     help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
     ap.add_argument("--batch", type=int, default=16, help="proofs per lock-step batch (zg_prover_prove_batch)")
-    ap.add_argument("--provers", type=int, default=8, help="proof streams per GPU (provers sharing one proving key)")
+    ap.add_argument("--provers", type=int, default=12, help="proof streams per GPU (provers sharing one proving key)")
     ap.add_argument("--mode", choices=["replicas", "shard-msm"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
@@ -489,7 +489,7 @@ def main():
         for m in ("small", "medium", "large"):
             c2 = Circuit(ctx0, m)
             b2 = batch if m != "large" else max(1, batch // 2)
-            np2 = nprov  # (a k = 17 slot is 1.4 GiB: 8 provers x 8 slots + workspaces = 130 GB of the 288)
+            np2 = min(nprov, 8)  # (a k = 17 slot is 1.4 GiB: 8 provers x 8 slots + workspaces = 130 GB of the 288)
             cx, st2, (lat, _) = make_streams(dev_index, c2, ctx0, np2, b2, rank, probe=latency_probe)
             dt2, _ = measure(st2, cx, 3, 1, barrier)
             others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * np2 * b2) * 1e3,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 profile on the GPU box:  ./tools/profile_r02.sh TAG     (outputs under gpurun_out/prof_TAG/)
-#   1. rocprofv3 --kernel-trace --stats of the default bench command (8 provers x lock-step batches of 16)
+#   1. rocprofv3 --kernel-trace --stats of the default bench command (12 provers x lock-step batches of 16)
 #   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU, three separate passes with no tracing flags, of ONE prover
 #      making batches of 16 (kernels are serialised under counter collection; a launch = 16 proofs as in the timed run)
 #   3. the bench line itself, without the profiler
