@@ -125,6 +125,9 @@ struct zg_bases {
     // the same table for the running sums Q_i = P_0 + ... + P_i (built on demand by bases_enable_runs): a scalar
     // vector with long constant runs is multiplied as sum_i (s_i - s_{i+1}) Q_i, whose coefficients vanish inside runs
     zg::Affine* run_table = nullptr;
+    // the same points under a larger window (built on demand by bases_enable_dense): for vectors of random scalars,
+    // which fill every window, fewer windows save more additions than the larger bucket set costs
+    zg_bases* dense = nullptr;
     std::mutex mu;
 };
 

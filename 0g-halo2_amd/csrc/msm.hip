@@ -767,6 +767,29 @@ int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t wi
 
 void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
 
+// window 0 of a table (x * 2^261) back to the library form the table kernel starts from
+__global__ void msm_untable_kernel(const Affine* __restrict__ table, Affine* __restrict__ bases, uint32_t n, Fe un) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st_fe_g(&bases[i].x, Fq::mul(ld_fe_g(&table[i].x), un));
+    st_fe_g(&bases[i].y, Fq::mul(ld_fe_g(&table[i].y), un));
+}
+
+// A second window table of the same points with `window_bits` bits per window (idempotent; the first call decides
+// the window).  msm_batch*_dev never picks it by itself: the prover names `b->dense` for its all-random phases.
+int bases_enable_dense(zg_ctx* ctx, zg_bases* b, uint32_t window_bits) {
+    std::lock_guard<std::mutex> lock(b->mu);
+    if (b->dense || window_bits == b->c) return ZG_OK;
+    WsScope ws(ctx);
+    Affine* d = ws.get<Affine>(b->n);
+    if (!d) return ZG_ERR_OOM;
+    const Fe un = Fq::inv(Fq9Params::c261_fe());
+    hipLaunchKernelGGL(msm_untable_kernel, dim3((uint32_t)((b->n + 255) / 256)), dim3(256), 0, ctx->stream, b->table, d,
+                       (uint32_t)b->n, un);
+    ZG_HIP(hipGetLastError());
+    return bases_register_dev(ctx, d, b->n, window_bits, &b->dense);
+}
+
 // Running sums Q_i = P_0 + ... + P_i of the registered points and their window table (once per base set; the
 // sums are a sequential chain, so the host adds them up -- one mixed addition per point -- and normalises them
 // with a single inversion).
@@ -1087,6 +1110,10 @@ void zg_bases_free(zg_bases* b) {
     (void)hipDeviceSynchronize();  // any context of the device may have been reading the tables
     (void)hipFree(b->table);
     if (b->run_table) (void)hipFree(b->run_table);
+    if (b->dense) {
+        (void)hipFree(b->dense->table);
+        delete b->dense;
+    }
     delete b;
 }
 

@@ -261,6 +261,11 @@ extern "C" int zg_xyzz_sum_ranks(const void* parts, size_t world, size_t count, 
 
 namespace {
 
+static const zg_bases* dense_g(const zg_prover* p) {
+    static const bool lat = getenv("ZG_MSM_DENSE_LATENCY") && atoi(getenv("ZG_MSM_DENSE_LATENCY"));
+    return p->g->dense && (lat || !p->ctx->msm_pair) ? p->g->dense : p->g;
+}
+
 // Commitments of a phase: one MSM launch sequence over `count` = groups x per scalar vectors (msm_batch4_dev), against
 // this prover's point range of the base sets; the XYZZ results go to the host behind it.
 int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, const Fe* scalars, size_t stride, size_t per,
@@ -739,6 +744,16 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     p->shard_n = (uint32_t)p->g->n;
     static const bool run_form = !(getenv("ZG_MSM_RUNS") && atoi(getenv("ZG_MSM_RUNS")) == 0);  // A/B knob
     if (run_form && pk->sets + pk->NL > 0) ZG_TRY(bases_enable_runs(ctx, p->gl));
+    {   // The quotient pieces and the opening quotients are vectors of random scalars, which fill every window: two more
+        // bits per window save more additions (22 -> 19 per scalar at k = 14) than the four-fold bucket set costs, which
+        // the sparse and run-form columns of g_lagrange would pay for nothing.  Measured in the throughput form:
+        // -1.3 % ms/proof at k = 14 (c 12 -> 13 or 14) and at k = 15 (13 -> 15), nothing at k = 17 (15 -> 16); a lone
+        // proof does not gain (dense_g).  +W'/W of the table memory of g.
+        static const int dense_env = getenv("ZG_MSM_C_DENSE") ? atoi(getenv("ZG_MSM_C_DENSE")) : -1;  // A/B knob; 0 = none
+        uint32_t cd = p->g->c + 2 <= 15 ? p->g->c + 2 : 15;
+        if (dense_env >= 0) cd = (uint32_t)dense_env;
+        if (cd > p->g->c && cd <= 16) ZG_TRY(bases_enable_dense(ctx, p->g, cd));
+    }
 
     // ---- proving-key slabs
     const uint32_t F = pk->F, P = pk->P, Q = pk->qpd;
@@ -1193,7 +1208,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
         ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
     }
-    ZG_TRY(commit(p, p->g, nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0));
+    ZG_TRY(commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0));
     ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
     for (uint32_t b = 0; b < nb; b++)
         for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
@@ -1348,7 +1363,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
                                   wp_bs, p->ktmp, n));
         // the witness polynomials sit at odd slots: stride 2n
-        ZG_TRY(commit(p, p->g, nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0));
+        ZG_TRY(commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0));
         ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
         for (uint32_t b = 0; b < nb; b++)
             for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
