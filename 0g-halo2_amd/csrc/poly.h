@@ -8,7 +8,7 @@ namespace zg {
 struct alignas(16) DMono {
     Fe coeff;
     uint32_t n_factors;
-    uint32_t coeff_is_one;
+    uint32_t coeff_is_one;  // 1: coefficient +1, 2: coefficient -1 (the nine-limb evaluation subtracts instead of multiplying)
     uint32_t factors[ZG_MAX_FACTORS];
     uint32_t pad[2];
 };
@@ -44,11 +44,13 @@ struct Cols {
 // Per-proof scalars of a lock-step batch: one entry per proof in HBM, rewritten by the host at every transcript step
 // (kernels read their proof's entry through the scalar cache: the proof index is workgroup-uniform).
 constexpr uint32_t PC_MAX_POINTS = 16;
+constexpr uint32_t EH_MAX_YPOW = 48;  // evaluate_h's grouped form: powers of y, one per term after the gates (+ 1)
 struct alignas(16) ProofConst {
     uint32_t key[8];            // blinding key (ChaCha20), rand_fr
     Fe theta, beta, gamma;      // library (2^256 Montgomery) form: lookup compression, product terms
     Fe eh_y, eh_beta, eh_gamma, eh_theta;  // the form evaluate_h computes in (x 2^5 for the nine-limb kernel)
     Fe eh_delta_start[2];       // beta * zeta^zpow for zpow = 1, 2, same form
+    Fe eh_ypow[EH_MAX_YPOW];    // y^j, same form (the weights of the permutation / lookup terms, EvalHArgs::n_terms)
     Fe xn;                      // x^n (vanishing::evaluate's Horner variable)
     Fe v;                       // GWC's v
     Fe points[PC_MAX_POINTS];   // opening points x * omega^rotation, by slot
@@ -96,6 +98,9 @@ struct EvalHArgs {
     // gate_slab[g] = index of the gate's slab (en entries) in gate_slabs, 0xffffffff: evaluate U in the kernel
     const uint32_t* gate_slab;
     const Fe* gate_slabs;
+    // grouped form of the nine-limb evaluation: the n_terms permutation / lookup terms that follow the gates are
+    // weighted by pc->eh_ypow and summed per l-polynomial (0: the plain Horner fold in y)
+    uint32_t n_terms;
 };
 
 // blinding scalar = f(seed, tag, index); identical to the oracle's definition

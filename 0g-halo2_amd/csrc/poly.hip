@@ -139,7 +139,7 @@ __device__ __forceinline__ Fe eval_poly(const DevCircuit& c, const Cols& cols, z
         const uint32_t nf = mo->n_factors;
         Fe prod;
         uint32_t f = 0;
-        if (mo->coeff_is_one && nf > 0) {
+        if (mo->coeff_is_one == 1 && nf > 0) {
             const zg_query q = c.queries[mo->factors[0]];
             const Fe* base = q.kind == ZG_FIXED ? cols.fixed : q.kind == ZG_ADVICE ? cols.advice : cols.instance;
             uint32_t idx = (row + (uint32_t)(q.rotation * cols.rot_scale)) & mask;
@@ -820,40 +820,43 @@ __device__ __forceinline__ F9 eval_poly9(const DevCircuit& c, const DMono* monos
 #pragma unroll
     for (int i = 0; i < 9; i++) acc.l[i] = 0;
     uint32_t pending = 0;  // terms added since the last carry normalisation
-    auto add = [&](const F9& t) {
-        acc = f9_add(acc, t);
+    auto add = [&](const F9& t, bool neg) {  // acc +/- t  (a coefficient -1 is a subtraction, not a product)
+        acc = neg ? f9_sub(acc, t) : f9_add(acc, t);
         if (++pending == 2) {  // (wave-uniform: the monomial list is)
             acc = f9_norm(acc);
             pending = 0;
         }
     };
-    // A monomial is L * R with R its last factor; the final products of two consecutive monomials share one
+    // A monomial is +/- L * R with R its last factor; the final products of two consecutive monomials share one
     // Montgomery reduction (Fr9::mul2).
     F9 hl, hr;          // a monomial waiting for its partner
-    bool held = false;
+    bool held = false, hneg = false;
     for (uint32_t m = p.first; m < p.first + p.count; m++) {
         const DMono* mo = monos + m;
         const uint32_t nf = mo->n_factors;
-        const bool with_coeff = !(mo->coeff_is_one && nf > 0);
-        const uint32_t terms = nf + (with_coeff ? 1u : 0u);  // operands of the product
+        const bool unit = mo->coeff_is_one != 0 && nf > 0;
+        const bool neg = unit && mo->coeff_is_one == 2;
+        const uint32_t terms = nf + (unit ? 0u : 1u);  // operands of the product
         if (terms == 1) {  // a bare cell or a bare constant
-            add(with_coeff ? f9_unpack(mo->coeff) : cell(mo->factors[0]));
+            add(unit ? cell(mo->factors[0]) : f9_unpack(mo->coeff), neg);
             continue;
         }
         uint32_t f = 0;
-        F9 l = with_coeff ? f9_unpack(mo->coeff) : cell(mo->factors[f++]);
+        F9 l = unit ? cell(mo->factors[f++]) : f9_unpack(mo->coeff);
         for (; f + 1 < nf; f++) l = Fr9::mul(l, cell(mo->factors[f]));
         const F9 r = cell(mo->factors[nf - 1]);
         if (held) {
-            add(Fr9::mul2<false>(hl, hr, l, r));
+            if (hneg == neg) add(Fr9::mul2<false>(hl, hr, l, r), neg);
+            else add(Fr9::mul2<true>(hl, hr, l, r), hneg);  // +(hl hr - l r) or -(hl hr - l r)
             held = false;
         } else {
             hl = l;
             hr = r;
+            hneg = neg;
             held = true;
         }
     }
-    if (held) add(Fr9::mul(hl, hr));
+    if (held) add(Fr9::mul(hl, hr), hneg);
     return f9_norm(acc);
 }
 
@@ -879,6 +882,12 @@ int poly_gate_factor(zg_ctx* ctx, const Fe* col, uint32_t rot_off, uint32_t en, 
     return ZG_OK;
 }
 
+// GROUPED: the terms after the gates are not folded one by one (value * y + term * l, two products each) but
+// weighted and summed per l-polynomial,
+//     h_num = G y^T + l0 * sum_i y^e_i a_i + llast * sum_i y^e_i b_i + lactive * sum_i y^e_i c_i,
+// with the powers of y from pc->eh_ypow: one product per term (two terms per Montgomery reduction) + four at the
+// end -- the same field element, since the arithmetic is exact.
+template <bool GROUPED>
 __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t en) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= en) return;
@@ -929,6 +938,81 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     auto llast = [&]() { return ld9(a.llast + idx); };
     auto lactive = [&]() { return ld9(a.lactive + idx); };
     auto one = [&]() { return Fr9Params::one(); };
+    // theta-compression of a lookup's input and table expressions (the first expression enters as it is)
+    auto compress = [&](const DLookup* lk, F9& ai, F9& ti) {
+        ai = eval_poly9(c, a.monos_hat, pr.cols, lk->inputs[0], idx);
+        ti = eval_poly9(c, a.monos_hat, pr.cols, lk->tables[0], idx);
+        for (uint32_t e = 1; e < lk->width; e++) {
+            ai = f9_add(Fr9::mul(ai, f9_unpack(pc->eh_theta)), eval_poly9(c, a.monos_hat, pr.cols, lk->inputs[e], idx));
+            ti = f9_add(Fr9::mul(ti, f9_unpack(pc->eh_theta)), eval_poly9(c, a.monos_hat, pr.cols, lk->tables[e], idx));
+        }
+    };
+    if (GROUPED) {
+        // term i of the sequence (upstream's order) carries y^(T - 1 - i); `w` walks down from T - 1
+        uint32_t w = a.n_terms;
+        auto yw = [&](uint32_t e) { return f9_unpack(pc->eh_ypow[e]); };
+        F9 s0, sl, sa;  // the sums that l0, llast and lactive multiply (normalised after every addition)
+#pragma unroll
+        for (int i = 0; i < 9; i++) s0.l[i] = sl.l[i] = sa.l[i] = 0;
+        auto acc1 = [&](F9& s, uint32_t e, const F9& t) { s = f9_norm(f9_add(s, Fr9::mul(yw(e), t))); };
+        auto acc2 = [&](F9& s, uint32_t e, const F9& t, uint32_t e2, const F9& t2) {
+            s = f9_norm(f9_add(s, Fr9::mul2<false>(yw(e), t, yw(e2), t2)));
+        };
+        if (c.n_sets > 0) {
+            const F9 zf = ld9(pr.pz_cos + idx);
+            const F9 zl = ld9(pr.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
+            acc1(s0, w - 1, f9_sub(one(), zf));
+            acc1(sl, w - 2, f9_sub(Fr9::sqr(zl), zl));
+            w -= 2;
+            for (uint32_t s = 1; s < c.n_sets; s++) {
+                const F9 t = f9_sub(ld9(pr.pz_cos + (size_t)s * en + idx), ld9(pr.pz_cos + (size_t)(s - 1) * en + r_last));
+                acc1(s0, --w, t);
+            }
+            F9 current_delta = Fr9::mul(f9_unpack(pc->eh_delta_start[a.zpow - 1]), ld9(a.ext_tw + idx));
+            const F9 delta = f9_unpack(a.delta);
+            for (uint32_t s = 0; s < c.n_sets; s++) {
+                uint32_t c0 = s * c.chunk, c1 = c0 + c.chunk;
+                if (c1 > c.n_perm) c1 = c.n_perm;
+                F9 left = ld9(pr.pz_cos + (size_t)s * en + r_next);
+                F9 right = ld9(pr.pz_cos + (size_t)s * en + idx);
+                for (uint32_t col = c0; col < c1; col++) {
+                    const zg_query q = c.perm_cols[col];
+                    const Fe* base = q.kind == ZG_FIXED ? pr.cols.fixed : q.kind == ZG_ADVICE ? pr.cols.advice : pr.cols.instance;
+                    const F9 v = ld9(base + ((size_t)q.column << a.cols.log_size) + idx);
+                    const F9 sg = ld9(a.sigma_cos + (size_t)col * en + idx);
+                    const F9 fl = f9_norm(f9_add(f9_add(Fr9::mul(f9_unpack(pc->eh_beta), sg), v), f9_unpack(pc->eh_gamma)));
+                    const F9 fr = f9_norm(f9_add(f9_add(v, current_delta), f9_unpack(pc->eh_gamma)));
+                    current_delta = Fr9::mul(current_delta, delta);
+                    if (col + 1 < c1) {
+                        left = Fr9::mul(left, fl);
+                        right = Fr9::mul(right, fr);
+                    } else {
+                        left = Fr9::mul2<true>(left, fl, right, fr);
+                    }
+                }
+                acc1(sa, --w, left);
+            }
+        }
+        for (uint32_t l = 0; l < c.n_lookups; l++) {
+            const DLookup* lk = c.lookups + l;
+            F9 ai, ti;
+            compress(lk, ai, ti);
+            const Fe* zc = pr.lz_cos + (size_t)l * en;
+            const Fe* ap = pr.pin_cos + (size_t)l * a.perm_stride;
+            const Fe* sp = pr.ptab_cos + (size_t)l * a.perm_stride;
+            const F9 z = ld9(zc + idx), apv = ld9(ap + idx), spv = ld9(sp + idx);
+            const F9 lft = Fr9::mul(f9_add(apv, f9_unpack(pc->eh_beta)), f9_norm(f9_add(spv, f9_unpack(pc->eh_gamma))));
+            const F9 rgt = Fr9::mul(f9_norm(f9_add(ai, f9_unpack(pc->eh_beta))), f9_norm(f9_add(ti, f9_unpack(pc->eh_gamma))));
+            const F9 ams = f9_sub(apv, spv);
+            // five terms: (1 - z) l0, (z^2 - z) llast, (lft z(wX) - rgt z) lactive, (a' - s') l0, (a' - s')(a' - a'(w^-1 X)) lactive
+            acc2(s0, w - 1, f9_sub(one(), z), w - 4, ams);
+            acc1(sl, w - 2, f9_sub(Fr9::sqr(z), z));
+            acc2(sa, w - 3, Fr9::mul2<true>(lft, ld9(zc + r_next), rgt, z), w - 5, Fr9::mul(ams, f9_sub(apv, ld9(ap + r_prev))));
+            w -= 5;
+        }
+        // h_num = value y^T + l0 s0 + llast sl + lactive sa
+        value = f9_norm(f9_add(Fr9::mul2<false>(value, yw(a.n_terms), s0, l0()), Fr9::mul2<false>(sl, llast(), sa, lactive())));
+    } else {
     if (c.n_sets > 0) {
         const F9 zf = ld9(pr.pz_cos + idx);
         const F9 zl = ld9(pr.pz_cos + (size_t)(c.n_sets - 1) * en + idx);
@@ -967,12 +1051,7 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     for (uint32_t l = 0; l < c.n_lookups; l++) {
         const DLookup* lk = c.lookups + l;
         F9 ai, ti;
-#pragma unroll
-        for (int i = 0; i < 9; i++) ai.l[i] = ti.l[i] = 0;
-        for (uint32_t e = 0; e < lk->width; e++) {
-            ai = f9_add(Fr9::mul(ai, f9_unpack(pc->eh_theta)), eval_poly9(c, a.monos_hat, pr.cols, lk->inputs[e], idx));
-            ti = f9_add(Fr9::mul(ti, f9_unpack(pc->eh_theta)), eval_poly9(c, a.monos_hat, pr.cols, lk->tables[e], idx));
-        }
+        compress(lk, ai, ti);
         const Fe* zc = pr.lz_cos + (size_t)l * en;
         const Fe* ap = pr.pin_cos + (size_t)l * a.perm_stride;
         const Fe* sp = pr.ptab_cos + (size_t)l * a.perm_stride;
@@ -986,6 +1065,7 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
         const F9 ams = f9_sub(apv, spv);
         value = fold2(value, ams, l0());
         value = fold2(value, Fr9::mul(ams, f9_sub(apv, ld9(ap + r_prev))), lactive());
+    }
     }
     // divide_by_vanishing_poly, then back to the canonical packed form (still x * 2^261)
     value = Fr9::mul(value, ld9(a.t_eval + (idx & a.t_mask)));
@@ -1002,8 +1082,10 @@ int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en, uint32_t nb) {
                "evaluate_h: the 2^261-form monomial table is missing");
     ZG_REQUIRE(!a.hat || c.n_gates == 0 || (a.gates_hat != nullptr && a.gate_common != nullptr && a.gate_uni != nullptr && a.uni_coef != nullptr && a.gate_slab != nullptr && a.gate_slabs != nullptr), ZG_ERR_INVALID_ARG,
                "evaluate_h: the factored gate table is missing");
-    if (a.hat)
-        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h9_kernel, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
+    if (a.hat && a.n_terms)
+        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h9_kernel<true>, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
+    else if (a.hat)
+        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h9_kernel<false>, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
     else
         ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h_kernel, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
     ZG_HIP(hipGetLastError());

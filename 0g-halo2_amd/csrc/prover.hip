@@ -294,7 +294,16 @@ int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
 }
 
 // the scalars evaluate_h reads, in the form it computes in (theta, beta, gamma already in c)
-void evalh_consts(ProofConst& c, const Fe& y, bool hat) {
+// terms of evaluate_h after the gates: permutation (l0, llast, one l0 per further set, one lactive per set) and five per
+// lookup; 0 when they are too many for ProofConst::eh_ypow (or switched off): the kernel then folds in y term by term
+uint32_t evalh_terms(const PkDev& pk) {
+    static const bool grouped = !(getenv("ZG_EVALH_GROUPED") && atoi(getenv("ZG_EVALH_GROUPED")) == 0);  // A/B knob
+    const uint32_t t = (pk.sets ? 2 + (pk.sets - 1) + pk.sets : 0) + 5 * pk.NL;
+    // (at most 40: the sums that multiply l0 / lactive then stay below the operand bound of Fr9::mul2)
+    return grouped && pk.hat && t >= 1 && t <= 40 && t + 1 <= EH_MAX_YPOW ? t : 0;
+}
+
+void evalh_consts(ProofConst& c, const Fe& y, bool hat, uint32_t n_terms) {
     const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
     c.eh_y = y; c.eh_beta = c.beta; c.eh_gamma = c.gamma; c.eh_theta = c.theta;
     c.eh_delta_start[0] = Fr::mul(c.beta, zeta);   // beta * coset shift
@@ -303,6 +312,11 @@ void evalh_consts(ProofConst& c, const Fe& y, bool hat) {
         const Fe c261 = Fr9Params::c261_fe();
         for (Fe* cst : {&c.eh_y, &c.eh_beta, &c.eh_gamma, &c.eh_theta, &c.eh_delta_start[0], &c.eh_delta_start[1]})
             *cst = Fr::mul(*cst, c261);
+        Fe pw = Fr::one();
+        for (uint32_t j = 0; j <= n_terms && j < EH_MAX_YPOW; j++) {
+            c.eh_ypow[j] = Fr::mul(pw, c261);
+            pw = Fr::mul(pw, y);
+        }
     }
 }
 
@@ -334,6 +348,7 @@ EvalHArgs evalh_args(const zg_prover* p, uint32_t di) {
     a.delta = hat ? Fr::mul(fr_delta(), Fr9Params::c261_fe()) : fr_delta();
     a.hat = hat;
     a.monos_hat = pk.monos_hat;
+    a.n_terms = evalh_terms(pk);
     a.gates_hat = pk.gates_hat;
     a.gate_common = pk.gate_common;
     a.gate_uni = pk.gate_uni;
@@ -479,17 +494,19 @@ GateFactor factor_gate(const std::vector<DMono>& monos, zg_poly g, uint32_t f, c
         if (univariate) {
             // U * B = (d U) * (B / d) with d the most frequent coefficient of B: those monomials become
             // coefficient-free products again, as they were before the selector was substituted
+            // (up to sign: a coefficient -1 costs the kernel a subtraction, like +1 an addition)
             size_t best = 0, best_n = 0;
             for (size_t i = 0; i < base.size(); i++) {
                 size_t cnt = 0;
-                for (const DMono& o : base) cnt += fe_eq(o.coeff, base[i].coeff);
+                const Fe neg_i = Fr::neg(base[i].coeff);
+                for (const DMono& o : base) cnt += fe_eq(o.coeff, base[i].coeff) || fe_eq(o.coeff, neg_i);
                 if (cnt > best_n) best = i, best_n = cnt;
             }
             const Fe d = base[best].coeff, d_inv = Fr::inv(d);
             const Fe one_hat = Fr::mul(Fr::one(), c261);
             for (DMono& o : base) {
                 o.coeff = Fr::mul(Fr::mul(o.coeff, d_inv), c261);  // (o / d) back in the 2^261 form
-                o.coeff_is_one = fe_eq(o.coeff, one_hat) ? 1 : 0;
+                o.coeff_is_one = fe_eq(o.coeff, one_hat) ? 1 : fe_eq(o.coeff, Fr::neg(one_hat)) ? 2 : 0;
             }
             for (Fe& u : out.uc) u = Fr::mul(u, Fr::mul(d, Fr::inv(c261)));  // (d carries the 2^261 factor already)
             out.inner = std::move(base);
@@ -621,7 +638,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         memset(&d, 0, sizeof(d));
         memcpy(&d.coeff, &s.coeff, 32);
         d.n_factors = s.n_factors;
-        d.coeff_is_one = fe_eq(d.coeff, one) ? 1 : 0;
+        d.coeff_is_one = fe_eq(d.coeff, one) ? 1 : fe_eq(d.coeff, Fr::neg(one)) ? 2 : 0;
         for (uint32_t f = 0; f < s.n_factors; f++) {
             ZG_REQUIRE(s.factors[f] < cs->n_queries, ZG_ERR_INVALID_ARG, "zg_prover_create: monomial %u factor out of range", m);
             d.factors[f] = s.factors[f];
@@ -1172,7 +1189,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     }
     for (uint32_t b = 0; b < nb; b++) tr[b].write_point(random_commit[b]);
     ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
-    for (uint32_t b = 0; b < nb; b++) evalh_consts(p->hpc[b], tr[b].squeeze(), hat);
+    for (uint32_t b = 0; b < nb; b++) evalh_consts(p->hpc[b], tr[b].squeeze(), hat, evalh_terms(pk));
     ZG_TRY(upload_consts(p, nb));
     lap(2);
 
@@ -1524,7 +1541,7 @@ int zg_prover_evaluate_h(zg_prover* p, const zg_fr* advice_polys, const zg_fr* i
     ProofConst& c = p->hpc[0];
     memset(&c, 0, sizeof(c));
     c.theta = to_fe(theta); c.beta = to_fe(beta); c.gamma = to_fe(gamma);
-    evalh_consts(c, to_fe(y), pk.hat);
+    evalh_consts(c, to_fe(y), pk.hat, evalh_terms(pk));
     p->stage_off = p->pin_stage;
     ZG_TRY(upload_consts(p, 1));
     const PkDev::Dom& d = pk.dom[0];
