@@ -71,6 +71,8 @@ ABI_SYMBOLS = [
     "zg_prover_create_shared", "zg_prover_fork", "zg_prover_set_batch", "zg_prover_batch", "zg_prover_advice_slot",
     "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
+    "zg_witness_plan_create", "zg_witness_plan_destroy", "zg_witness_plan_image_bytes", "zg_witness_plan_instance_len",
+    "zg_witness_run_dev",
 ]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
@@ -368,6 +370,51 @@ def keccak256(data: bytes) -> bytes:
     out = (ctypes.c_uint8 * 32)()
     load().zg_keccak256(data, c_size_t(len(data)), out)
     return bytes(out)
+
+
+class WitnessPlan:
+    """zg_witness_plan: the recorded witness program of a circuit (harness/witness_tape.py WitnessProgram.arrays())
+    on one context; run() writes the advice columns of a batch of inputs into device buffers."""
+
+    def __init__(self, ctx: Ctx, arrays: dict):
+        self.ctx = ctx
+        lib = ctx.lib
+        lib.zg_witness_plan_destroy.argtypes = [c_void_p]
+        lib.zg_witness_plan_destroy.restype = None
+        ops = np.ascontiguousarray(arrays["ops"], dtype=np.uint64)
+        level_start = np.ascontiguousarray(arrays["level_start"], dtype=np.uint32)
+        consts = np.ascontiguousarray(arrays["consts"], dtype=np.uint64)
+        table = np.ascontiguousarray(arrays["table"], dtype=np.uint64)
+        cell_slot = np.ascontiguousarray(arrays["cell_slot"], dtype=np.uint32)
+        inst = np.ascontiguousarray(arrays["instance_slots"], dtype=np.uint32)
+        self.n_advice, n = cell_slot.shape
+        self.k = n.bit_length() - 1
+        self.n_instance = int(inst.shape[0])
+        self.image_bytes = int(arrays["image_bytes"])
+        h = c_void_p()
+        _check(lib.zg_witness_plan_create(ctx.h, _ptr(ops), c_size_t(ops.shape[0]), _ptr(level_start),
+                                          c_size_t(level_start.shape[0] - 1), _ptr(consts), c_size_t(consts.shape[0]),
+                                          _ptr(table), c_size_t(table.shape[0]), _ptr(cell_slot), c_uint32(self.n_advice),
+                                          c_uint32(self.k), _ptr(inst), c_size_t(self.n_instance),
+                                          c_size_t(self.image_bytes), ctypes.byref(h)))
+        self.h = h
+        ctx._adopt(self)
+
+    def run(self, images: np.ndarray, d_advice) -> np.ndarray:
+        """images: uint8[count, image_bytes...]; d_advice: `count` device addresses ([n_advice][2^k] field elements
+        each).  Returns the instance values, uint64[count, n_instance, 4] (Montgomery form)."""
+        images = np.ascontiguousarray(images, dtype=np.uint8).reshape(len(d_advice), -1)
+        assert images.shape[1] == self.image_bytes, "image size does not match the recorded program"
+        count = images.shape[0]
+        ptrs = (c_void_p * count)(*[c_void_p(a) for a in d_advice])
+        out = np.zeros((count, self.n_instance, 4), np.uint64)
+        _check(self.ctx.lib.zg_witness_run_dev(self.h, _ptr(images), c_size_t(count), ptrs, _ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.zg_witness_plan_destroy(self.h)
+            self.h = None
 
 
 class Prover:

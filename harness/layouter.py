@@ -83,6 +83,12 @@ class Layouter:
         for u in used:
             self.columns[u] = region.start + rows
         assert region.start + rows <= self.cs.usable_rows(), "not enough rows available (k too small)"
+        self.commit_region(region)
+        self.n_regions += 1
+        return result
+
+    def commit_region(self, region: Region):
+        """the placed region into the assignment (witness_tape.TapeLayouter records cells instead)"""
         asg = self.asg
         for c in region.cells:
             asg.set(ADVICE, c.column, c.row, c.value)
@@ -97,8 +103,6 @@ class Layouter:
             asg.set(FIXED, self.constants_column, row, value)
             asg.copy((FIXED, self.constants_column, row), cell.cell())
             self.columns[key] = row + 1
-        self.n_regions += 1
-        return result
 
     def assign_table(self, columns, rows):
         """columns: fixed column ids; rows: list of tuples, one value per column."""

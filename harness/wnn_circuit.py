@@ -18,6 +18,7 @@ import numpy as np
 
 from circuit import ADVICE, FIXED, INSTANCE, R, ConstraintSystem
 from layouter import AssignedCell, Layouter, Region
+from symint import as_int_check, bit_of_byte, byte_be, eq, exact_shr, ge, gt, is_sym
 from wnn_model import Wnn, WnnCircuitParams
 
 K = 8  # bits per range-check word (range_check.rs:10)
@@ -45,6 +46,17 @@ class ArrayLookupChip:
         weights = 1 << np.arange(word_length - 1, -1, -1, dtype=object)  # from_be_bits
         words = bloom_filter_arrays.reshape(bloom_filter_arrays.shape[0], -1, word_length).astype(object)
         self.bloom_filter_words = (words * weights).sum(axis=2)  # [bloom_index][word_index] -> int
+
+    def word(self, bloom_index: int, word_index):
+        """bloom_filter_words[bloom_index][word_index]; a recorded index becomes a table read of the tape"""
+        if is_sym(word_index):
+            tape = word_index.tape
+            key = ("bloom_words", id(self))
+            if key not in tape.__dict__.setdefault("table_bases", {}):
+                tape.table_bases[key] = tape.add_table(self.bloom_filter_words.reshape(-1))
+            base = tape.table_bases[key] + bloom_index * self.bloom_filter_words.shape[1]
+            return tape.emit("TABLE", word_index.slot, imm=base, deps=(word_index.slot,))
+        return int(self.bloom_filter_words[bloom_index][word_index])
 
     def bytes_per_word(self) -> int:
         return 1 << (self.config["bits_per_hash"] - self.config["word_index_bits"] - 3)
@@ -86,11 +98,11 @@ class ArrayLookupChip:
             hashes_le = [(h >> (i * bph)) & ((1 << bph) - 1) for i in range(n_hashes)]
             low = bph - wib
             idx = [(v >> low, (v & ((1 << low) - 1)) >> 3, v & 7) for v in hashes_le]
-            words = [int(self.bloom_filter_words[bloom_index][w]) for w, _, _ in idx]
+            words = [self.word(bloom_index, w) for w, _, _ in idx]
             decomposition = [h]
             for v in hashes_le:
-                decomposition.append((decomposition[-1] - v) * inv(1 << bph) % R)
-            assert decomposition[-1] == 0, "hash does not fit n_hashes * bits_per_hash bits"
+                decomposition.append(exact_shr(decomposition[-1] - v, bph))  # (.. - v) * inv(2^bph)
+            as_int_check(decomposition[-1], lambda x: x == 0, "hash does not fit n_hashes * bits_per_hash bits")
             for i, v in enumerate(decomposition):
                 if i == 0:
                     hash_value.copy_advice(region, c["hash_decomposition"], 0)
@@ -138,7 +150,7 @@ class BitSelectorChip:
         c = self.config
 
         def region_fn(region: Region):
-            bit = (byte.value >> (7 - index.value)) & 1
+            bit = bit_of_byte(byte.value, index.value)  # (byte >> (7 - index)) & 1
             region.enable_selector(c["selector"], 0)
             byte.copy_advice(region, c["byte"], 0)
             index.copy_advice(region, c["index"], 0)
@@ -183,11 +195,11 @@ class ByteSelectorChip:
         def region_fn(region: Region):
             w, idx = word.value, index.value
             bytes_be = [(w >> (8 * (num_bytes - 1 - i))) & 0xFF for i in range(num_bytes)]
-            ith_byte = bytes_be[idx]
+            ith_byte = byte_be(w, idx, num_bytes)  # bytes_be[idx]
             decomposition = [w]
             for b in reversed(bytes_be):
-                decomposition.append((decomposition[-1] - b) * inv(256) % R)
-            assert decomposition[-1] == 0
+                decomposition.append(exact_shr(decomposition[-1] - b, 8))  # (.. - b) * inv(256)
+            as_int_check(decomposition[-1], lambda x: x == 0, "word does not fit num_bytes bytes")
             for i, v in enumerate(decomposition):
                 if i == 0:
                     word.copy_advice(region, c["byte_decomposition"], 0)
@@ -200,17 +212,17 @@ class ByteSelectorChip:
             for i in range(num_bytes):  # little-endian rows, big-endian index
                 region.assign_advice_from_constant(c["byte_index"], num_bytes - 1 - i, i)
             for i in range(num_bytes):
-                region.assign_advice(c["byte_selector"], i, 1 if num_bytes - 1 - i == idx else 0)
+                region.assign_advice(c["byte_selector"], i, eq(idx, num_bytes - 1 - i))
             for i in range(num_bytes + 1):
                 if i == 0:
                     region.assign_advice_from_constant(c["selector_acc"], 0, 0)
                 elif i < num_bytes:
-                    region.assign_advice(c["selector_acc"], i, 1 if num_bytes - i <= idx else 0)
+                    region.assign_advice(c["selector_acc"], i, ge(idx, num_bytes - i))
                 else:
                     region.assign_advice_from_constant(c["selector_acc"], i, 1)
             result = region.assign_advice_from_constant(c["byte_acc"], 0, 0)
             for i in range(1, num_bytes + 1):
-                result = region.assign_advice(c["byte_acc"], i, ith_byte if num_bytes - i <= idx else 0)
+                result = region.assign_advice(c["byte_acc"], i, ge(idx, num_bytes - i) * ith_byte)
             for s in c["selectors"]:
                 for i in range(num_bytes):
                     region.enable_selector(s, i)
@@ -318,7 +330,7 @@ class RangeCheckConfig:
                 word = z.value & ((1 << K) - 1)
                 region.enable_selector(c["q_lookup"], idx)
                 region.enable_selector(c["q_running"], idx)
-                z = region.assign_advice(c["advice_column"], idx + 1, (z.value - word) * inv(1 << K) % R)
+                z = region.assign_advice(c["advice_column"], idx + 1, exact_shr(z.value - word, K))  # (z - word) * inv(2^K)
                 zs.append(z)
             if strict:
                 region.constrain_constant(zs[-1], 0)
@@ -379,15 +391,15 @@ class GreaterThanChip:
     def _greater_than(self, region: Region, x_cell: AssignedCell, y: int):
         assert y <= 255, "y must be less than 256!"
         c = self.config
-        gt = 1 if x_cell.value > y else 0
-        diff = (256 * gt + y - x_cell.value) % R
+        is_gt = gt(x_cell.value, y)  # 1 if x > y else 0
+        diff = (256 * is_gt + y - x_cell.value) % R
         region.enable_selector(c["selector"], 0)
         region.assign_advice_from_constant(c["y"], 0, y)
         diff_cell = region.assign_advice(c["diff"], 0, diff)
-        gt_cell = region.assign_advice(c["is_gt"], 0, gt)
+        gt_cell = region.assign_advice(c["is_gt"], 0, is_gt)
         return diff_cell, gt_cell
 
-    def greater_than_witness(self, layouter: Layouter, x: int, y: int):
+    def greater_than_witness(self, layouter: Layouter, x, y: int):
         def region_fn(region: Region):
             x_cell = region.assign_advice(self.config["x"], 0, x)
             diff_cell, gt_cell = self._greater_than(region, x_cell, y)
@@ -439,7 +451,9 @@ class EncodeImageChip:
                         t = threshold - 1  # >= via >
                         first = intensity_cells.get((i, j))
                         if first is None:
-                            x_cell, bit_cell = self.greater_than_chip.greater_than_witness(layouter, int(image[i, j]), t)
+                            px = image[i, j]  # (a recorded pixel when the image is symbolic: witness_tape.SymImage)
+                            x_cell, bit_cell = self.greater_than_chip.greater_than_witness(
+                                layouter, px if is_sym(px) else int(px), t)
                             intensity_cells[(i, j)] = x_cell
                         else:
                             bit_cell = self.greater_than_chip.greater_than_copy(layouter, first, t)

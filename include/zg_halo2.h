@@ -350,6 +350,35 @@ int zg_kate_division_dev(zg_ctx *ctx, const void *d_a, size_t n, const zg_fr *z,
 /* Keccak-256 (EvmTranscript's hash), host. */
 void zg_keccak256(const uint8_t *data, size_t len, uint8_t out[32]);
 
+/* ---- witness of a batch of inputs on the device ------------------------------------------
+ * Replaces, for a circuit whose layout does not depend on its input: the host pass upstream's create_proof makes
+ * through Circuit::synthesize under its WitnessCollection (halo2_proofs v2023_04_20 src/plonk/prover.rs) -- for zero_g
+ * WnnChip::predict, /root/reference/src/gadgets/wnn.rs:180-237, reached once per image from Wnn::proof,
+ * /root/reference/src/wnn.rs:232-262.  The caller records that pass ONCE as a straight-line program over unsigned
+ * 256-bit integers (one slot per operation; operands are earlier slots) and the library replays it per input:
+ *
+ *   op  0 CONST  consts[imm]        1 PIXEL  input byte imm     2 ADD a+b    3 SUB a-b     4 MUL a*b (low 256 bits)
+ *       5 ADDI a+imm   6 RSUBI imm-a   7 MULI a*imm   8 SHRI a>>imm   9 SHLI a<<imm   10 ANDI a&imm   11 SHRV a>>b
+ *       12 GTI a>imm   13 GEI a>=imm   14 EQI a==imm  (0 / 1)    15 DIVI a/imm    16 TABLE table[imm+a] (0 outside)
+ *
+ * Operations are given sorted by dependency level (level_start[l] .. level_start[l+1]); an operand must lie in an
+ * earlier level (checked here, with every immediate: the program runs on the GPU unchecked).  cell_slot[c * 2^k + row]
+ * names the slot advice column c shows in that row, or 0xFFFFFFFF for a cell left unassigned (zero); values are
+ * reduced modulo r and written in the Montgomery form create_proof takes.  instance_slots: the public inputs. */
+typedef struct zg_witness_plan zg_witness_plan;
+typedef struct { uint64_t op, a, b, imm; } zg_witness_op;
+int zg_witness_plan_create(zg_ctx* ctx, const zg_witness_op* ops, size_t n_ops, const uint32_t* level_start, size_t n_levels,
+                           const uint64_t* consts /* [n_consts][4] little-endian words */, size_t n_consts,
+                           const uint64_t* table, size_t n_table, const uint32_t* cell_slot /* [n_advice][2^k] */,
+                           uint32_t n_advice, uint32_t k, const uint32_t* instance_slots, size_t n_instance,
+                           size_t image_bytes, zg_witness_plan** out);
+void zg_witness_plan_destroy(zg_witness_plan* plan);
+size_t zg_witness_plan_image_bytes(const zg_witness_plan* plan);
+size_t zg_witness_plan_instance_len(const zg_witness_plan* plan);
+/* images: host, count * image_bytes; d_advice[i]: device, [n_advice][2^k] zg_fr (e.g. zg_prover_advice_slot);
+ * instance_out: host, [count][n_instance].  At most 64 inputs per call.  Returns when the columns are written. */
+int zg_witness_run_dev(zg_witness_plan* plan, const uint8_t* images, size_t count, void* const* d_advice, zg_fr* instance_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+"""The witness of a batch of images on the device (zg_witness_plan_create / zg_witness_run_dev): the recorded program
+of zero_g's WnnCircuit replayed by the GPU must write, for every image, exactly the advice columns and public inputs
+the host synthesis produces -- and create_proof from those device-resident columns must give the oracle's bytes."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch  # (before the first HIP call of the process)
+
+pytestmark = pytest.mark.gpu
+
+
+def _d2h(ptr: int, nbytes: int) -> np.ndarray:
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = np.zeros(nbytes // 8, np.uint64)
+    assert hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2) == 0
+    return out
+
+
+@pytest.mark.parametrize("model", ["tiny", "medium"])
+def test_device_witness_equals_host_synthesis(ctx, zg, orc, model):
+    import witness_tape
+    import wnn_circuit
+    import wnn_model
+
+    k, name = {"tiny": wnn_model.MNIST_TINY, "medium": wnn_model.MNIST_MEDIUM}[model]
+    wnn = wnn_model.load_checked_in(name)
+    prog = witness_tape.trace(wnn, k)
+    plan = zg.WitnessPlan(ctx, prog.arrays())
+    real = wnn_model.load_test_image()
+    rng = np.random.default_rng(11)
+    images = [real, np.zeros_like(real), np.full_like(real, 255)] + [rng.integers(0, 256, size=real.shape, dtype=real.dtype)
+                                                                      for _ in range(2 if model == "tiny" else 0)]
+    n = 1 << k
+    bufs = [torch.full((6 * n * 4,), -1, dtype=torch.int64, device="cuda") for _ in images]  # (stale contents must go)
+    inst = plan.run(np.stack(images), [b.data_ptr() for b in bufs])
+    for im, buf, got_inst in zip(images, bufs, inst):
+        cs, asg, ilen, scores = wnn_circuit.build(wnn, im, k)
+        want = asg.advice_values()
+        got = _d2h(buf.data_ptr(), want.nbytes).reshape(want.shape)
+        assert np.array_equal(got, want)
+        assert np.array_equal(got_inst, asg.instance_values(ilen)[0])
+    plan.close()
+
+
+def test_proofs_from_device_witness(ctx, zg, orc):
+    """image bytes -> advice columns in the prover's slots -> lock-step batch of proofs, nothing but the image and the
+    class scores crossing PCIe: bytes == the oracle's create_proof of the host-synthesised witness."""
+    import witness_tape
+    import wnn_circuit
+    import wnn_model
+
+    orc.load().orc_set_threads(16)
+    k, name = wnn_model.MNIST_TINY
+    wnn = wnn_model.load_checked_in(name)
+    real = wnn_model.load_test_image()
+    rng = np.random.default_rng(3)
+    images = [real] + [rng.integers(0, 256, size=real.shape, dtype=real.dtype) for _ in range(2)]
+    built = [wnn_circuit.build(wnn, im, k) for im in images]
+    cs, asg0, ilen, _ = built[0]
+    img = cs.to_c()
+    params = orc.params_new(k, 0x5EED)
+    vk_repr = orc.fr_from_int(0xC0FFEE)
+    pk = orc.ProvingKey(img, asg0.fixed_values(), asg0.sigma_values(), params, vk_repr)
+    prover = zg.Prover(ctx, img, asg0.fixed_values(), asg0.sigma_values(), params.g_np(), params.g_lagrange_np(), vk_repr)
+    prover.set_batch(3)
+    prover.set_overlap(False)
+    plan = zg.WitnessPlan(ctx, witness_tape.trace(wnn, k).arrays())
+    for seeds in ([31, 32, 33], [41, 42, 43]):  # twice: the second run overwrites the blinding rows of the first
+        inst = plan.run(np.stack(images), [prover.advice_slot(b) for b in range(3)])
+        got, sts = prover.prove_batch(None, [i[None, :, :] for i in inst], seeds, device=True)
+        assert sts == [0, 0, 0]
+        for b, (_, asg, _, scores) in enumerate(built):
+            st, want, _ = orc.create_proof(pk, asg.advice_values(), asg.instance_values(ilen), seeds[b])
+            assert st == 0 and got[b] == want, f"proof {b}"
+    plan.close()
+    prover.close()
+
+
+def test_plan_rejects_malformed_programs(ctx, zg):
+    """The program runs on the GPU unchecked, so zg_witness_plan_create refuses everything it can see statically."""
+    def arrays(**over):
+        a = dict(ops=np.array([[1, 0, 0, 0], [5, 0, 0, 7]], dtype=np.uint64),  # PIXEL 0; ADDI slot0 + 7
+                 level_start=np.array([0, 1, 2], dtype=np.uint32), consts=np.zeros((1, 4), np.uint64),
+                 table=np.zeros(1, np.uint64), cell_slot=np.full((1, 4), 0xFFFFFFFF, np.uint32),
+                 instance_slots=np.array([1], dtype=np.uint32), image_bytes=2)
+        a.update(over)
+        return a
+
+    ok = zg.WitnessPlan(ctx, arrays())
+    buf = torch.zeros(4 * 4, dtype=torch.int64, device="cuda")
+    inst = ok.run(np.array([[5, 9]], dtype=np.uint8), [buf.data_ptr()])
+    assert zg.fr_to_int(inst[0, 0]) == 12
+    ok.close()
+    bad = [
+        dict(ops=np.array([[1, 0, 0, 0], [5, 1, 0, 7]], dtype=np.uint64)),              # reads its own slot
+        dict(ops=np.array([[1, 0, 0, 2], [5, 0, 0, 7]], dtype=np.uint64)),              # pixel outside the image
+        dict(ops=np.array([[0, 0, 0, 3], [5, 0, 0, 7]], dtype=np.uint64)),              # constant outside the pool
+        dict(ops=np.array([[1, 0, 0, 0], [16, 0, 0, 1]], dtype=np.uint64)),             # table base outside the table
+        dict(ops=np.array([[1, 0, 0, 0], [15, 0, 0, 0]], dtype=np.uint64)),             # division by zero
+        dict(ops=np.array([[1, 0, 0, 0], [99, 0, 0, 0]], dtype=np.uint64)),             # unknown opcode
+        dict(level_start=np.array([0, 2, 2], dtype=np.uint32)),                         # operand in the same level
+        dict(cell_slot=np.full((1, 4), 2, np.uint32)),                                  # cell shows a missing slot
+        dict(instance_slots=np.array([2], dtype=np.uint32)),
+    ]
+    for over in bad:
+        with pytest.raises(zg.ZgError):
+            zg.WitnessPlan(ctx, arrays(**over))

@@ -1,0 +1,61 @@
+"""The recorded witness program (harness/witness_tape.py): WnnChip::predict traced once on a symbolic image must give,
+replayed on concrete images, exactly the advice columns and class scores the concrete synthesis gives -- the same chip
+code produces both.  The flat form handed to zg_witness_plan_create is checked for the properties the device relies
+on.  (The device's replay against this interpreter: tests/test_gpu_witness.py.)"""
+import numpy as np
+import pytest
+
+import symint
+import witness_tape
+import wnn_circuit
+import wnn_model
+
+
+def _images(n, seed=5):
+    real = wnn_model.load_test_image()
+    rng = np.random.default_rng(seed)
+    extremes = [np.zeros_like(real), np.full_like(real, 255)]
+    return [real] + extremes + [rng.integers(0, 256, size=real.shape, dtype=real.dtype) for _ in range(n)]
+
+
+@pytest.mark.parametrize("which", [wnn_model.MNIST_TINY, wnn_model.MNIST_SMALL])
+def test_replay_equals_concrete_synthesis(which):
+    k, name = which
+    wnn = wnn_model.load_checked_in(name)
+    prog = witness_tape.trace(wnn, k)
+    assert prog.image_bytes == 28 * 28 and prog.n_advice == 6
+    for im in _images(2 if k == 14 else 1):
+        cs, asg, ilen, scores = wnn_circuit.build(wnn, im, k)
+        adv, got_scores = prog.run(im)
+        assert got_scores == scores == wnn.predict(im)
+        assert adv == [[int(v) for v in col] for col in asg.advice]
+
+
+def test_flat_form_is_straight_line():
+    k, name = wnn_model.MNIST_TINY
+    prog = witness_tape.trace(wnn_model.load_checked_in(name), k)
+    a = prog.arrays()
+    ops, ls = a["ops"], a["level_start"]
+    assert ls[0] == 0 and ls[-1] == ops.shape[0] and np.all(np.diff(ls.astype(np.int64)) >= 0)
+    level_of = np.repeat(np.arange(len(ls) - 1), np.diff(ls.astype(np.int64)))
+    first = ls[level_of]  # first op of the op's own level: operands must lie before it
+    code = ops[:, 0]
+    uses_a = code >= symint.OPCODE["ADD"]
+    uses_b = np.isin(code, [symint.OPCODE[x] for x in ("ADD", "SUB", "MUL", "SHRV")])
+    assert np.all(ops[uses_a, 1] < first[uses_a]) and np.all(ops[uses_b, 2] < first[uses_b])
+    assert np.all(ops[code == symint.OPCODE["PIXEL"], 3] < a["image_bytes"])
+    assert np.all(ops[code == symint.OPCODE["CONST"], 3] < a["consts"].shape[0])
+    assert np.all(ops[code == symint.OPCODE["TABLE"], 3] < a["table"].shape[0])
+    cs = a["cell_slot"]
+    assert cs.shape == (6, 1 << k)
+    assigned = cs != witness_tape.NO_SLOT
+    assert np.all(cs[assigned] < ops.shape[0]) and assigned.sum() == len(prog.cells)
+    assert a["instance_slots"].shape == (10,)
+    # renumbering is consistent: replaying the flat form gives the recorded program's values
+    t = symint.Tape()
+    t.ops = [(int(o), int(x), int(y), int(i)) for o, x, y, i in ops]
+    t.consts = [sum(int(w) << (64 * j) for j, w in enumerate(c)) for c in a["consts"]]
+    t.table = [int(w) for w in a["table"]]
+    im = wnn_model.load_test_image()
+    v = t.run(im.reshape(-1))
+    assert [v[s] for s in a["instance_slots"]] == [9, 6, 13, 10, 17, 10, 9, 26, 11, 16]  # integration_test.rs:19
