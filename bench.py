@@ -80,6 +80,7 @@ class Circuit:
         self.k, self.model_name = MODELS[model]
         self.model = model
         wnn = wnn_model.synthetic_wnn() if model == "large" else wnn_model.load_checked_in(self.model_name)
+        self.wnn = wnn
         # zero_g's WnnCircuit for this model, synthesised on benches/example_image_7.png: the real
         # constraint system, fixed / sigma columns and witness (harness/wnn_circuit.py restates WnnChip)
         self.cs, self.asg, self.ilen, self.scores = wnn_circuit.build(
@@ -116,8 +117,17 @@ class Stream:
         # the witness into every slot, once: a proof rewrites only the last blinding_factors+1 rows of its advice
         # columns and reads the rest, so the slots can be proved from again (inputs resident in HBM, as the contract asks)
         self.seed0 = 1_000_000 * stream_id
+        self.stream_id = stream_id
         self.steps = 0
+        self.plan = None
         self.last = self.prover.prove_batch([c.advice] * batch, [c.instance] * batch, self.seeds())[0]
+
+    def enable_images(self, arrays: dict, pool: np.ndarray):
+        """From here on every proof of a step is for ANOTHER image of `pool`: the recorded witness program runs on the
+        device (zg_witness_run_dev) into the prover's slots -- image bytes in, class scores out, inside step()."""
+        self.plan = zg.WitnessPlan(self.ctx, arrays)
+        self.pool = pool
+        self.slots = [self.prover.advice_slot(b) for b in range(self.batch)]
 
     def seeds(self):
         return [self.seed0 + 1000 * self.steps + b for b in range(self.batch)]
@@ -125,7 +135,12 @@ class Stream:
     def step(self):
         self.steps += 1
         self.last_seeds = self.seeds()
-        if HOST_ADVICE:  # the host-pointer entry: every proof's columns cross PCIe (3 MiB per proof at k = 14)
+        if self.plan is not None:
+            first = (self.stream_id * 7 + self.steps * self.batch) % len(self.pool)
+            self.last_images = [(first + b) % len(self.pool) for b in range(self.batch)]
+            self.last_inst = self.plan.run(self.pool[self.last_images], self.slots)
+            self.last = self.prover.prove_batch(None, [i[None, :, :] for i in self.last_inst], self.last_seeds, device=True)[0]
+        elif HOST_ADVICE:  # the host-pointer entry: every proof's columns cross PCIe (3 MiB per proof at k = 14)
             self.last = self.prover.prove_batch([self.c.advice] * self.batch, [self.c.instance] * self.batch, self.last_seeds)[0]
         else:
             self.last = self.prover.prove_batch(None, [self.c.instance] * self.batch, self.last_seeds, device=True)[0]
@@ -260,6 +275,64 @@ def verify_last_step(c: Circuit, streams, threads: int) -> dict:
     return {"verified": True, "detail": f"{checked} proofs of the last timed step byte-identical to the oracle's, 1 pairing-verified"}
 
 
+def image_pool(c: Circuit, count: int = 64) -> np.ndarray:
+    """benches/example_image_7.png and seeded noise images of its shape (synthetic: the MNIST test set is not in the
+    reference checkout)"""
+    real = wnn_model.load_test_image()
+    rng = np.random.default_rng(2024)
+    return np.stack([real] + [rng.integers(0, 256, size=real.shape, dtype=real.dtype) for _ in range(count - 1)]).reshape(count, -1)
+
+
+def image_to_proof(c: Circuit, streams, ctxs, barrier, threads: int, verify: bool) -> dict:
+    """The same provers, but every proof for a different image and the witness made on the device inside the timed
+    step (SURVEY.md 8f item 2: Wnn::proof's whole body, /root/reference/src/wnn.rs:232-262, image bytes to proof bytes).
+    Checked like the headline: proofs of the last step against the oracle's create_proof of the HOST-synthesised witness
+    of the same image."""
+    import witness_tape
+
+    t0 = time.perf_counter()
+    prog = witness_tape.trace(c.wnn, c.k)
+    arrays = prog.arrays()
+    trace_s = time.perf_counter() - t0
+    pool = image_pool(c)
+    for s in streams:
+        s.enable_images(arrays, pool)
+    steps = 5
+    dt, stats = measure(streams, ctxs, steps, 1, barrier, profile=True)
+    n = steps * sum(s.batch for s in streams)
+    wit_ms = sum(stats.get(k_, (0, 0.0, 0.0))[1] for k_ in ("witness_run", "witness_finish"))
+    wit_launches = stats.get("witness_run", (0, 0.0, 0.0))[0]
+    out = {"ms_per_proof": dt / n * 1e3, "proofs_per_hour": n / dt * 3600.0, "images": len(pool),
+           "witness_program": {"operations": int(arrays["ops"].shape[0]), "levels": int(arrays["level_start"].shape[0] - 1),
+                               "assigned_cells": len(prog.cells), "recorded_in_s": round(trace_s, 2)},
+           "witness_device_ms_per_batch": wit_ms / max(1, wit_launches),
+           "note": "every proof of a step for another image; witness program + create_proof inside the timed region; "
+                   "per image 784 B in and the class scores out cross PCIe"}
+    if verify:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import orc
+
+        orc.load().orc_set_threads(threads)
+        params = orc.params_from_scalar(c.k, c.s)
+        pk = orc.ProvingKey(c.img, c.fixed, c.sigma, params, c.vk_repr)
+        ok, checked = True, 0
+        shape = wnn_model.load_test_image().shape
+        for i, b in dict.fromkeys([(0, 0), (0, streams[0].batch - 1), (len(streams) - 1, 0)]):
+            s = streams[i]
+            im = pool[s.last_images[b]].reshape(shape)
+            _, asg, ilen, scores = wnn_circuit.build(c.wnn, im, c.k)
+            inst = asg.instance_values(ilen)
+            st, want, _ = orc.create_proof(pk, asg.advice_values(), inst, s.last_seeds[b])
+            ok = ok and st == 0 and want == s.last[b] and np.array_equal(inst[0], s.last_inst[b]) and scores == c.wnn.predict(im)
+            checked += 1
+        out["verified"] = bool(ok)
+        out["detail"] = f"{checked} proofs of the last step byte-identical to the oracle's proof of the host-synthesised witness of the same image"
+    for s in streams:
+        s.plan.close()
+        s.plan = None
+    return out
+
+
 def measure(streams, ctxs, steps, warmup, barrier, profile=False):
     run_steps(streams, max(warmup, 1))
     for x in ctxs:
@@ -311,6 +384,7 @@ def main():
     ap.add_argument("--host-advice", action="store_true",
                     help="every proof uploads its advice columns from host memory (PCIe-inclusive rate, for DESIGN.md)")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the lone-proof latency measurement (counter passes)")
+    ap.add_argument("--no-image-to-proof", action="store_true", help="skip the run with a different image per proof (device witness)")
     args = ap.parse_args()
 
     global HOST_ADVICE
@@ -478,6 +552,8 @@ def main():
         if not args.no_verify:
             out.update(verify_last_step(circuit, streams, host_cores()) if not sharded else
                        verify_last_step_sharded(circuit, streams, host_cores()))
+    if rank == 0 and not args.no_image_to_proof and not sharded and args.model == "tiny" and world == 1 and not HOST_ADVICE:
+        out["image_to_proof"] = image_to_proof(circuit, streams, ctxs, barrier, host_cores(), not args.no_verify)
     # the other three models of BASELINE.json: a few steps each, same driver (after the headline's timed region)
     if not args.no_other_configs and not sharded and args.model == "tiny" and world == 1:
         others = {}

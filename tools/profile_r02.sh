@@ -10,7 +10,7 @@ TAG=${1:-cur}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-PMC_ARGS="--steps 2 --warmup 1 --provers 1 --batch 16 --no-kernel-events --no-cpu-baseline --no-other-configs --no-verify --no-latency-probe"
+PMC_ARGS="--steps 2 --warmup 1 --provers 1 --batch 16 --no-kernel-events --no-cpu-baseline --no-other-configs --no-verify --no-latency-probe --no-image-to-proof"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-other-configs > $OUT/bench_under_trace.json 2> $OUT/trace.log
 for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
