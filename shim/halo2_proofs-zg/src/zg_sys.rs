@@ -8,6 +8,10 @@ use std::os::raw::{c_char, c_int, c_void};
 #[repr(C)] pub struct zg_ctx { _p: [u8; 0] }
 #[repr(C)] pub struct zg_bases { _p: [u8; 0] }
 #[repr(C)] pub struct zg_prover { _p: [u8; 0] }
+#[repr(C)] pub struct zg_witness_plan { _p: [u8; 0] }
+/// one operation of a recorded witness program (include/zg_halo2.h: opcode table there)
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct zg_witness_op { pub op: u64, pub a: u64, pub b: u64, pub imm: u64 }
 
 pub const ZG_FIXED: u32 = 0;
 pub const ZG_ADVICE: u32 = 1;
@@ -71,4 +75,13 @@ extern "C" {
                                 gamma: *const Fr, y: *const Fr, h_out: *mut Fr) -> c_int;
     pub fn zg_prover_set_shard(p: *mut zg_prover, rank: u32, world: u32, first_point: usize, exchange: zg_exchange_fn,
                                user: *mut c_void) -> c_int;
+    // witness of a batch of inputs on the device (optional; the recorder is the caller's: see README.md)
+    pub fn zg_prover_advice_slot(p: *mut zg_prover, slot: usize) -> *mut c_void;
+    pub fn zg_witness_plan_create(ctx: *mut zg_ctx, ops: *const zg_witness_op, n_ops: usize, level_start: *const u32, n_levels: usize,
+                                  consts: *const u64, n_consts: usize, table: *const u64, n_table: usize, cell_slot: *const u32,
+                                  n_advice: u32, k: u32, instance_slots: *const u32, n_instance: usize, image_bytes: usize,
+                                  out: *mut *mut zg_witness_plan) -> c_int;
+    pub fn zg_witness_plan_destroy(plan: *mut zg_witness_plan);
+    pub fn zg_witness_run_dev(plan: *mut zg_witness_plan, images: *const u8, count: usize, d_advice: *const *mut c_void,
+                              instance_out: *mut Fr) -> c_int;
 }
