@@ -377,3 +377,21 @@ def test_stand_alone_evaluate_h_matches_oracle(ctx, zg, orc, k, force_degree):
     # the prover still proves afterwards (slot 0 was used as scratch)
     assert prover.prove(adv, inst, 5) == orc.create_proof(pk, adv, inst, 5)[1]
     prover.close()
+
+
+def test_ab_knob_variants_give_the_same_bytes():
+    """The forms the default replaced stay selectable for A/B (read once per process): evaluate_h folding in y term by
+    term (ZG_EVALH_GROUPED=0) and the quotient / opening commitments against the one table of g (ZG_MSM_C_DENSE=0).
+    Rerun the proof-parity tests of this file in a child process with both switched."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("ZG_EVALH_GROUPED") == "0":
+        pytest.skip("already inside the variant run")
+    env = dict(os.environ, ZG_EVALH_GROUPED="0", ZG_MSM_C_DENSE="0")
+    here = os.path.abspath(__file__)
+    pick = "test_proof_bytes_match_oracle_and_verify or test_circuit_variants_match_oracle or test_split_extended_domain"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", here, "-k", pick], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
