@@ -629,7 +629,7 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
 }
 
 // ---- the throughput form of the reduction: least work.  sum_k k B_k over the buckets k = 1 .. nb of one vector.
-// Stage 1, one LANE per strip of MSM_STRIP consecutive buckets [jS + 1, (j + 1) S], highest bucket first:
+// Stage 1, one LANE per strip of S (MSM_STRIP) consecutive buckets [jS + 1, (j + 1) S], highest bucket first:
 //     B = the bucket's task partials merged (hot buckets arrive merged from msm_heavy);  run += B;  loc += run
 // leaves run = U_j (the strip's sum) and loc = sum_s (s + 1) B_(jS + s + 1), so that
 //     sum_k k B_k = sum_j loc_j + S * sum_j j U_j.
@@ -639,21 +639,21 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
 // same way (C_l = their sum, w_l = sum_t t U_(l per + t)), a suffix scan + tree over the 256 lanes gives
 // W = sum_l l C_l, and  result = sum_j loc_j + S * (sum_l w_l + per * W)  with the factors S and per (powers of two)
 // applied by doublings.
-constexpr uint32_t MSM_STRIP = 4;
+constexpr uint32_t MSM_STRIP = 8;  // (default; a power of two; ZG_MSM_STRIP for A/B: 2 / 4 / 8 / 16 -> 0.750 / 0.734 / 0.728 / 0.736 ms/proof)
 constexpr uint32_t MSM_STRIP_LANES = 256;  // stage-2 workgroup
 
 __global__ __launch_bounds__(256) void msm_strip_kernel(const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff,
                                                         const uint32_t* __restrict__ hmap, const XYZZ9* __restrict__ hsum,
                                                         uint32_t max_tasks, uint32_t max_heavy, uint32_t c, uint32_t nstrips,
-                                                        XYZZ9* __restrict__ strip_u, XYZZ9* __restrict__ strip_loc) {
+                                                        XYZZ9* __restrict__ strip_u, XYZZ9* __restrict__ strip_loc, uint32_t S) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (j >= nstrips) return;
     const uint32_t nb = 1u << (c - 1);
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
     XYZZ9 run = xyzz9_identity(), loc = xyzz9_identity();
-    for (uint32_t s = MSM_STRIP; s-- > 0;) {
-        const uint32_t k = j * MSM_STRIP + s + 1;
+    for (uint32_t s = S; s-- > 0;) {
+        const uint32_t k = j * S + s + 1;
         if (k <= nb) {
             const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
             if (hs < max_heavy) {
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void msm_strip_kernel(const XYZZ9* __restrict_
 
 __global__ __launch_bounds__(MSM_STRIP_LANES) void msm_strip_sum_kernel(const XYZZ9* __restrict__ strip_u,
                                                                        const XYZZ9* __restrict__ strip_loc, uint32_t nstrips,
-                                                                       uint32_t per, XYZZ* __restrict__ out) {
+                                                                       uint32_t per, XYZZ* __restrict__ out, uint32_t S) {
     __shared__ XYZZ9 sh[MSM_STRIP_LANES];
     const uint32_t l = threadIdx.x, b = blockIdx.x;
     const XYZZ9* U = strip_u + (size_t)b * nstrips;
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(MSM_STRIP_LANES) void msm_strip_sum_kernel(const XY
     if (l != 0) return;
     for (uint32_t d = per; d > 1; d >>= 1) W = xyzz9_add(W, W);            // per * W   (equal operands: the doubling case)
     XYZZ9 V = xyzz9_add(W, wsum);                                           // sum_j j U_j
-    for (uint32_t d = MSM_STRIP; d > 1; d >>= 1) V = xyzz9_add(V, V);      // S * V
+    for (uint32_t d = S; d > 1; d >>= 1) V = xyzz9_add(V, V);              // S * V
     st_xyzz(out + b, xyzz9_to_xyzz(xyzz9_add(V, asum), false));
 }
 
@@ -1037,14 +1037,16 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         static const bool strips = !(getenv("ZG_MSM_STRIPS") && atoi(getenv("ZG_MSM_STRIPS")) == 0);  // A/B knob
         if (strips) {
             // (sfx has room for nb points per vector: the strip sums and strip-local weighted sums share it)
-            const uint32_t nstrips = (nb + MSM_STRIP - 1) / MSM_STRIP;
+            static const uint32_t s_env = getenv("ZG_MSM_STRIP") ? (uint32_t)atoi(getenv("ZG_MSM_STRIP")) : 0;  // A/B knob
+            const uint32_t S = s_env == 2 || s_env == 4 || s_env == 8 || s_env == 16 ? s_env : MSM_STRIP;
+            const uint32_t nstrips = (nb + S - 1) / S;
             uint32_t per = 1;
             while (per * MSM_STRIP_LANES < nstrips) per <<= 1;
             XYZZ9 *strip_u = sfx, *strip_loc = sfx + (size_t)B * nstrips;
             ZG_LAUNCH(ctx, "msm_strip", msm_bytes, msm_strip_kernel, dim3((nstrips + 255) / 256, B), dim3(256), 0, partial,
-                      toff, hmap, hsum, max_tasks, max_heavy, c, nstrips, strip_u, strip_loc);
+                      toff, hmap, hsum, max_tasks, max_heavy, c, nstrips, strip_u, strip_loc, S);
             ZG_LAUNCH(ctx, "msm_strip_sum", msm_bytes, msm_strip_sum_kernel, dim3(B), dim3(MSM_STRIP_LANES), 0, strip_u, strip_loc,
-                      nstrips, per, d_out);
+                      nstrips, per, d_out, S);
         } else {
             ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
                       toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
