@@ -43,6 +43,38 @@ def test_device_witness_equals_host_synthesis(ctx, zg, orc, model):
     plan.close()
 
 
+def test_device_witness_of_the_k17_stand_in(ctx, zg):
+    """model_49input_8192entry_4hash_6bpi's shape (seeded stand-in): 49-bit filter inputs, so the hash gadget cubes to
+    147 bits and divides by a 53-bit modulus -- the wide multiplications and the division of the program's integer
+    arithmetic.  360 000 operations, 215 levels; checked against the reference interpreter of the recorded program
+    (itself checked against the host synthesis in tests/test_witness_tape.py) and against Wnn::predict."""
+    import witness_tape
+    import wnn_model
+    from circuit import R
+
+    k = 17
+    wnn = wnn_model.synthetic_wnn()
+    prog = witness_tape.trace(wnn, k)
+    plan = zg.WitnessPlan(ctx, prog.arrays())
+    real = wnn_model.load_test_image()
+    images = [real, np.random.default_rng(2).integers(0, 256, size=real.shape, dtype=real.dtype)]
+    n = 1 << k
+    bufs = [torch.full((6 * n * 4,), -1, dtype=torch.int64, device="cuda") for _ in images]
+    inst = plan.run(np.stack(images), [b.data_ptr() for b in bufs])
+    mont = pow(2, 256, R)
+    for im, buf, got_inst in zip(images, bufs, inst):
+        adv, scores = prog.run(im)
+        assert scores == wnn.predict(im)
+        assert [zg.fr_to_int(x) for x in got_inst] == scores
+        got = _d2h(buf.data_ptr(), 6 * n * 32).reshape(6, n, 4)
+        want = np.zeros((6, n, 4), np.uint64)
+        for c in range(6):
+            for r in np.nonzero(np.array([v != 0 for v in adv[c]]))[0]:
+                want[c, r] = zg.int_to_limbs(adv[c][r] * mont % R)
+        assert np.array_equal(got, want)
+    plan.close()
+
+
 def test_proofs_from_device_witness(ctx, zg, orc):
     """image bytes -> advice columns in the prover's slots -> lock-step batch of proofs, nothing but the image and the
     class scores crossing PCIe: bytes == the oracle's create_proof of the host-synthesised witness."""

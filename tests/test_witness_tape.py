@@ -31,6 +31,17 @@ def test_replay_equals_concrete_synthesis(which):
         assert adv == [[int(v) for v in col] for col in asg.advice]
 
 
+def test_replay_of_the_k17_stand_in():
+    """49-bit filter inputs: cubes of 147 bits, a 53-bit hash modulus"""
+    wnn = wnn_model.synthetic_wnn()
+    prog = witness_tape.trace(wnn, 17)
+    im = wnn_model.load_test_image()
+    cs, asg, ilen, scores = wnn_circuit.build(wnn, im, 17)
+    adv, got_scores = prog.run(im)
+    assert got_scores == scores == wnn.predict(im)
+    assert adv == [[int(v) for v in col] for col in asg.advice]
+
+
 def test_flat_form_is_straight_line():
     k, name = wnn_model.MNIST_TINY
     prog = witness_tape.trace(wnn_model.load_checked_in(name), k)
