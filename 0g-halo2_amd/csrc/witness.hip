@@ -378,4 +378,22 @@ int zg_witness_run_dev(zg_witness_plan* p, const uint8_t* images, size_t count, 
     return ZG_OK;
 }
 
+int zg_prover_prove_images(zg_prover* p, zg_witness_plan* plan, const uint8_t* images, size_t count, const uint8_t* rng_keys,
+                           uint8_t* const* proofs, size_t proof_cap, size_t* proof_lens, zg_fr* outputs, int* statuses) {
+    ZG_REQUIRE(p && plan && images && rng_keys && proofs && proof_lens && (outputs || !plan->n_instance), ZG_ERR_INVALID_ARG,
+               "zg_prover_prove_images: null argument");
+    ZG_REQUIRE(count >= 1 && count <= zg_prover_batch(p) && count <= 64, ZG_ERR_INVALID_ARG,
+               "zg_prover_prove_images: %zu images for a prover of %zu slots (64 at most per call)", count, zg_prover_batch(p));
+    void* slots[64];
+    const zg_fr* inst[64];
+    for (size_t b = 0; b < count; b++) {
+        slots[b] = zg_prover_advice_slot(p, b);
+        ZG_REQUIRE(slots[b] != nullptr, ZG_ERR_INVALID_ARG, "zg_prover_prove_images: the prover has no slot %zu", b);
+        inst[b] = outputs + b * plan->n_instance;
+    }
+    // (the program writes [n_advice][2^k] columns: the prover checks the instance length, a slot's size is the circuit's)
+    ZG_TRY(zg_witness_run_dev(plan, images, count, slots, outputs));
+    return zg_prover_prove_batch_dev(p, count, nullptr, inst, plan->n_instance, rng_keys, proofs, proof_cap, proof_lens, statuses);
+}
+
 }  // extern "C"

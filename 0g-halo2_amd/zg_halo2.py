@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
     "zg_witness_plan_create", "zg_witness_plan_destroy", "zg_witness_plan_image_bytes", "zg_witness_plan_instance_len",
-    "zg_witness_run_dev",
+    "zg_witness_run_dev", "zg_prover_prove_images",
 ]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
@@ -544,6 +544,22 @@ class Prover:
         if st != 0 and raise_on_error:
             _check(st)
         return [bytes(bufs[b][: lens[b]]) for b in range(count)], list(sts)
+
+    def prove_images(self, plan: "WitnessPlan", images: np.ndarray, seeds, raise_on_error=True):
+        """Wnn::proof for a batch: image bytes -> (proofs, outputs uint64[count, n_instance, 4], statuses)."""
+        count = len(seeds)
+        images = np.ascontiguousarray(images, dtype=np.uint8).reshape(count, -1)
+        keys = b"".join(rng_key(s) for s in seeds)
+        bufs = [(ctypes.c_uint8 * self.proof_cap)() for _ in range(count)]
+        out_ptrs = (c_void_p * count)(*[ctypes.addressof(b) for b in bufs])
+        lens = (c_size_t * count)()
+        sts = (c_int * count)()
+        outputs = np.zeros((count, plan.n_instance, 4), np.uint64)
+        st = self.ctx.lib.zg_prover_prove_images(self.h, plan.h, _ptr(images), c_size_t(count), keys, out_ptrs,
+                                                 c_size_t(self.proof_cap), lens, _ptr(outputs), sts)
+        if st != 0 and raise_on_error:
+            _check(st)
+        return [bytes(bufs[b][: lens[b]]) for b in range(count)], outputs, list(sts)
 
     def evaluate_h(self, advice_polys, instance_polys, perm_z_polys, lookup_z_polys, permuted_polys, theta, beta, gamma, y,
                    extended_n: int) -> np.ndarray:

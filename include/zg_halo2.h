@@ -378,6 +378,12 @@ size_t zg_witness_plan_instance_len(const zg_witness_plan* plan);
 /* images: host, count * image_bytes; d_advice[i]: device, [n_advice][2^k] zg_fr (e.g. zg_prover_advice_slot);
  * instance_out: host, [count][n_instance].  At most 64 inputs per call.  Returns when the columns are written. */
 int zg_witness_run_dev(zg_witness_plan* plan, const uint8_t* images, size_t count, void* const* d_advice, zg_fr* instance_out);
+/* Wnn::proof for a batch (/root/reference/src/wnn.rs:232-262: image -> witness -> create_proof -> (proof bytes,
+ * outputs)): the witness program into the prover's slots 0..count-1, then one lock-step batch of create_proofs with the
+ * program's instance values as the single instance column.  outputs: host, [count][n_instance] (the class scores, as
+ * field elements); everything else as zg_prover_prove_batch.  plan and prover must live on the same device. */
+int zg_prover_prove_images(zg_prover* p, zg_witness_plan* plan, const uint8_t* images, size_t count, const uint8_t* rng_keys,
+                           uint8_t* const* proofs, size_t proof_cap, size_t* proof_lens, zg_fr* outputs, int* statuses);
 
 #ifdef __cplusplus
 }

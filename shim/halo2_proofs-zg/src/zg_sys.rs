@@ -84,4 +84,7 @@ extern "C" {
     pub fn zg_witness_plan_destroy(plan: *mut zg_witness_plan);
     pub fn zg_witness_run_dev(plan: *mut zg_witness_plan, images: *const u8, count: usize, d_advice: *const *mut c_void,
                               instance_out: *mut Fr) -> c_int;
+    pub fn zg_prover_prove_images(p: *mut zg_prover, plan: *mut zg_witness_plan, images: *const u8, count: usize, rng_keys: *const u8,
+                                  proofs: *const *mut u8, proof_cap: usize, proof_lens: *mut usize, outputs: *mut Fr,
+                                  statuses: *mut c_int) -> c_int;
 }

@@ -105,6 +105,14 @@ def test_proofs_from_device_witness(ctx, zg, orc):
         for b, (_, asg, _, scores) in enumerate(built):
             st, want, _ = orc.create_proof(pk, asg.advice_values(), asg.instance_values(ilen), seeds[b])
             assert st == 0 and got[b] == want, f"proof {b}"
+    # the same through the one-call form of Wnn::proof (image bytes -> proof bytes + outputs)
+    got, outputs, sts = prover.prove_images(plan, np.stack(images), [51, 52, 53])
+    assert sts == [0, 0, 0]
+    for b, (_, asg, _, scores) in enumerate(built):
+        st, want, _ = orc.create_proof(pk, asg.advice_values(), asg.instance_values(ilen), 51 + b)
+        assert st == 0 and got[b] == want
+        assert [zg.fr_to_int(x) for x in outputs[b]] == scores
+        assert orc.verify_proof_pairing(pk, outputs[b][None, :, :], got[b]) == 1
     plan.close()
     prover.close()
 
