@@ -99,7 +99,7 @@ class Tape:
             elif name == "DIVI":
                 r = v[a] // imm
             elif name == "TABLE":
-                r = self.table[imm + v[a]]
+                r = self.table[imm + v[a]] if imm + v[a] < len(self.table) else 0  # (zero outside the table)
             else:
                 raise AssertionError(name)
             v[i] = r & M256

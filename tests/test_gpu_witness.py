@@ -117,6 +117,77 @@ def test_proofs_from_device_witness(ctx, zg, orc):
     prover.close()
 
 
+def test_every_operation_on_wide_operands(ctx, zg):
+    """The circuit's own programs mostly move small integers; this one drives every opcode with random 256-bit
+    operands, carries across all four words, shifts by 0..255 (and beyond, for the variable shift), divisors from 1
+    to 2^64 - 1 and table reads on both sides of the bound -- against the reference interpreter."""
+    import random
+
+    import symint
+    from circuit import R
+
+    rnd = random.Random(20261004)
+    t = symint.Tape()
+
+    def raw_const(v):  # (Tape.const reduces modulo r: wide values go into the pool directly)
+        t.consts.append(v)
+        return t.emit("CONST", imm=len(t.consts) - 1)
+
+    wide = [raw_const(rnd.getrandbits(256)) for _ in range(24)] + [raw_const(v) for v in (0, 1, (1 << 256) - 1, (1 << 64) - 1, 1 << 64, 1 << 255)]
+    small = [raw_const(rnd.getrandbits(rnd.choice((1, 8, 31, 32, 33, 63)))) for _ in range(12)]
+    px = [t.pixel(i) for i in range(4)]
+    base = t.add_table([rnd.getrandbits(64) for _ in range(16)])
+    out = []
+    vals = lambda sym: t.consts[t.ops[sym.slot][3]]  # value of a CONST slot
+    for _ in range(40):
+        a, b = rnd.choice(wide), rnd.choice(wide)
+        hi, lo = (a, b) if vals(a) >= vals(b) else (b, a)
+        out += [a + b, hi - lo, a * b, a * rnd.choice(small), a + rnd.getrandbits(64), a * rnd.getrandbits(64)]
+        out += [a >> rnd.randrange(256), a << rnd.randrange(256), a & rnd.getrandbits(64), a // rnd.choice((1, 2, 3, (1 << 64) - 1, rnd.getrandbits(64) | 1, rnd.getrandbits(33) | 1))]
+        s_ = rnd.choice(small)
+        out += [(rnd.getrandbits(64) | (1 << 63)) - s_]  # RSUBI: imm >= a
+        out += [a >> rnd.choice(small + px), symint.gt(s_, vals(s_)), symint.gt(s_, max(0, vals(s_) - 1)), symint.ge(s_, vals(s_)),
+                symint.ge(s_, vals(s_) + 1), symint.eq(s_, vals(s_)), symint.eq(a, vals(a) & symint.M64), symint.gt(a, symint.M64)]
+    for idx in (0, 5, 15, 16, 1 << 40):  # in range, last, first outside, far outside
+        c = raw_const(idx)
+        out.append(t.emit("TABLE", c.slot, imm=base, deps=(c.slot,)))
+    out += [p * 3 + 1 for p in px]
+    # one advice column of 2^k rows showing the results; instance = the first four
+    k = (len(out) - 1).bit_length()
+    prog_cells = {(0, i): o.slot for i, o in enumerate(out)}
+    import witness_tape
+
+    prog = witness_tape.WitnessProgram(t, prog_cells, {i: out[i].slot for i in range(4)}, 1, k, 4)
+    plan = zg.WitnessPlan(ctx, prog.arrays())
+    image = np.array([[0, 7, 200, 255]], dtype=np.uint8)
+    buf = torch.full(((1 << k) * 4,), -1, dtype=torch.int64, device="cuda")
+    inst = plan.run(image, [buf.data_ptr()])
+    v = t.run(image.reshape(-1))
+    got = _d2h(buf.data_ptr(), (1 << k) * 32).reshape(1 << k, 4)
+    for i, o in enumerate(out):
+        assert zg.fr_to_int(got[i]) == v[o.slot] % R, f"result {i}: op {symint.OPS[t.ops[o.slot][0]]}"
+    assert not got[len(out):].any()
+    assert [zg.fr_to_int(x) for x in inst[0]] == [v[out[i].slot] % R for i in range(4)]
+    plan.close()
+
+
+def test_prove_images_refuses_more_images_than_slots(ctx, zg, orc):
+    from circuits import toy_circuit
+
+    cs, asg, ilen = toy_circuit(6)
+    params = orc.params_new(6, 0xABCDEF)
+    prover = zg.Prover(ctx, cs.to_c(), asg.fixed_values(), asg.sigma_values(), params.g_np(), params.g_lagrange_np(), orc.fr_from_int(1))
+    prover.set_batch(2)
+    plan = zg.WitnessPlan(ctx, dict(ops=np.array([[1, 0, 0, 0]], dtype=np.uint64), level_start=np.array([0, 1], dtype=np.uint32),
+                                    consts=np.zeros((1, 4), np.uint64), table=np.zeros(1, np.uint64),
+                                    cell_slot=np.full((cs.n_advice, 64), 0xFFFFFFFF, np.uint32),
+                                    instance_slots=np.zeros(0, np.uint32), image_bytes=1))
+    with pytest.raises(zg.ZgError):
+        prover.prove_images(plan, np.zeros((3, 1), np.uint8), [1, 2, 3])
+    plan.close()
+    prover.close()
+
+
 def test_plan_rejects_malformed_programs(ctx, zg):
     """The program runs on the GPU unchecked, so zg_witness_plan_create refuses everything it can see statically."""
     def arrays(**over):
