@@ -75,7 +75,8 @@ class WitnessProgram:
     def arrays(self) -> dict:
         """flat arrays for zg_witness_plan_create: ops in level order (slots renumbered accordingly)"""
         t = self.tape
-        order = sorted(range(len(t.ops)), key=lambda i: (t.level[i], i))
+        # (within a level by opcode: the lanes of a wave then mostly run the same case of the interpreter's switch)
+        order = sorted(range(len(t.ops)), key=lambda i: (t.level[i], t.ops[i][0], i))
         new = {old: i for i, old in enumerate(order)}
         ops = np.zeros((len(order), 4), dtype=np.uint64)  # opcode, a, b, imm
         uses_a = {OPCODE[x] for x in ("ADD", "SUB", "MUL", "ADDI", "RSUBI", "MULI", "SHRI", "SHLI", "ANDI", "SHRV", "GTI",
