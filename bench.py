@@ -283,7 +283,7 @@ def image_pool(c: Circuit, count: int = 64) -> np.ndarray:
     return np.stack([real] + [rng.integers(0, 256, size=real.shape, dtype=real.dtype) for _ in range(count - 1)]).reshape(count, -1)
 
 
-def image_to_proof(c: Circuit, streams, ctxs, barrier, threads: int, verify: bool) -> dict:
+def image_to_proof(c: Circuit, streams, ctxs, barrier, threads: int, verify: bool, steps: int = 5, checks: int = 3) -> dict:
     """The same provers, but every proof for a different image and the witness made on the device inside the timed
     step (SURVEY.md 8f item 2: Wnn::proof's whole body, /root/reference/src/wnn.rs:232-262, image bytes to proof bytes).
     Checked like the headline: proofs of the last step against the oracle's create_proof of the HOST-synthesised witness
@@ -297,7 +297,6 @@ def image_to_proof(c: Circuit, streams, ctxs, barrier, threads: int, verify: boo
     pool = image_pool(c)
     for s in streams:
         s.enable_images(arrays, pool)
-    steps = 5
     dt, stats = measure(streams, ctxs, steps, 1, barrier, profile=True)
     n = steps * sum(s.batch for s in streams)
     wit_ms = sum(stats.get(k_, (0, 0.0, 0.0))[1] for k_ in ("witness_run", "witness_finish"))
@@ -317,7 +316,7 @@ def image_to_proof(c: Circuit, streams, ctxs, barrier, threads: int, verify: boo
         pk = orc.ProvingKey(c.img, c.fixed, c.sigma, params, c.vk_repr)
         ok, checked = True, 0
         shape = wnn_model.load_test_image().shape
-        for i, b in dict.fromkeys([(0, 0), (0, streams[0].batch - 1), (len(streams) - 1, 0)]):
+        for i, b in list(dict.fromkeys([(0, 0), (0, streams[0].batch - 1), (len(streams) - 1, 0)]))[:checks]:
             s = streams[i]
             im = pool[s.last_images[b]].reshape(shape)
             _, asg, ilen, scores = wnn_circuit.build(c.wnn, im, c.k)
@@ -571,6 +570,9 @@ def main():
             others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * np2 * b2) * 1e3,
                          "create_proof_wall_s": lat, "batch": b2, "provers": np2,
                          "proofs_per_hour": 3 * np2 * b2 / dt2 * 3600.0}
+            if m != "large" and not args.no_image_to_proof:  # (the stand-in's program: 360 000 operations, 5 s to record)
+                i2p = image_to_proof(c2, st2, cx, barrier, host_cores(), not args.no_verify, steps=2, checks=1)
+                others[m]["image_to_proof"] = {k_: i2p[k_] for k_ in ("ms_per_proof", "witness_program", "verified") if k_ in i2p}
             for s in st2:
                 s.prover.close()
             c2.g_bases.free()
