@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <memory>
 
 #include "poly.h"
@@ -145,6 +146,11 @@ struct zg_prover {
     uint32_t shard_lo = 0, shard_n = 0, world = 1, rank = 0;
     zg_exchange_fn exchange = nullptr;
     void* exchange_user = nullptr;
+    // ... or, with a communicator of the collective library (zg_prover_set_shard_rccl), all-gathered and summed on the
+    // device: the phase's partial sums never visit the host before they are whole
+    void* rccl_comm = nullptr;
+    XYZZ* gathered = nullptr;  // [world][maxv * cap]
+    size_t gathered_cap = 0;   // the slot count it is sized for (zg_prover_set_batch regrows it)
     // per-proof buffers, [cap] slots each (alloc_slots)
     uint32_t cap = 0;
     std::vector<void*> slot_owned;
@@ -268,10 +274,40 @@ static const zg_bases* dense_g(const zg_prover* p) {
 
 // Commitments of a phase: one MSM launch sequence over `count` = groups x per scalar vectors (msm_batch4_dev), against
 // this prover's point range of the base sets; the XYZZ results go to the host behind it.
+// RCCL is bound at run time (dlopen): the library has no link-time dependency on it, and only a prover that was given a
+// communicator ever asks for it.
+typedef int (*rccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+static rccl_all_gather_fn rccl_all_gather() {
+    static rccl_all_gather_fn fn = []() -> rccl_all_gather_fn {
+        void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        return h ? (rccl_all_gather_fn)dlsym(h, "ncclAllGather") : nullptr;
+    }();
+    return fn;
+}
+
+// out[i] = sum over ranks r of parts[r * count + i] (extended Jacobian), one lane per commitment: world - 1 additions
+__global__ void xyzz_sum_ranks_kernel(const XYZZ* __restrict__ parts, uint32_t world, uint32_t count, XYZZ* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    XYZZ acc = parts[i];
+    for (uint32_t r = 1; r < world; r++) acc = xyzz_add(acc, parts[(size_t)r * count + i]);
+    out[i] = acc;
+}
+
 int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, const Fe* scalars, size_t stride, size_t per,
            size_t outer, size_t count, uint64_t run_mask) {
     ZG_REQUIRE(count <= p->maxv * (size_t)p->cap, ZG_ERR_INVALID_ARG, "zg_prover: %zu commitments in one phase", count);
     ZG_TRY(msm_batch4_dev(p->ctx, a, b2, split, scalars + p->shard_lo, stride, per, outer, count, p->shard_n, p->xyzz, run_mask));
+    if (p->rccl_comm) {  // ONE all-gather of the phase's partial sums over xGMI, then the additions, all on this stream
+        rccl_all_gather_fn gather = rccl_all_gather();
+        ZG_REQUIRE(gather != nullptr, ZG_ERR_UNSUPPORTED, "zg_prover: librccl.so could not be loaded");
+        const int st = gather(p->xyzz, p->gathered, count * sizeof(XYZZ), /* ncclUint8 */ 1, p->rccl_comm, p->ctx->stream);
+        ZG_REQUIRE(st == 0, ZG_ERR_HIP, "zg_prover: ncclAllGather failed with %d", st);
+        ZG_LAUNCH(p->ctx, "xyzz_sum_ranks", (double)p->world * count * sizeof(XYZZ), xyzz_sum_ranks_kernel,
+                  dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, p->gathered, p->world, (uint32_t)count, p->xyzz);
+        ZG_HIP(hipGetLastError());
+    }
     ZG_HIP(hipMemcpyAsync((char*)p->pinned + p->pin_results, p->xyzz, count * sizeof(XYZZ), hipMemcpyDeviceToHost, p->ctx->stream));
     ZG_HIP(hipEventRecord(p->ev, p->ctx->stream));
     return ZG_OK;
@@ -282,7 +318,7 @@ int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
     ZG_HIP(hipEventSynchronize(p->ev));
     const XYZZ* local = (const XYZZ*)((char*)p->pinned + p->pin_results);
     out.resize(count);
-    if (p->world <= 1) {
+    if (p->world <= 1 || p->rccl_comm) {  // (whole sums already: a lone prover, or gathered and added on the device)
         xyzz_batch_normalise(local, count, reinterpret_cast<zg_g1*>(out.data()));
         return ZG_OK;
     }
@@ -548,6 +584,7 @@ void zg_prover_destroy(zg_prover* p) {
         (void)hipStreamSynchronize(p->ctx->stream);
         if (p->ctx->side) (void)hipStreamSynchronize(p->ctx->side->stream);
         free_slots(p);
+        if (p->gathered) (void)hipFree(p->gathered);
         p->owned_bases.reset();  // (the tables go with the last prover that uses them)
         if (p->ev) (void)hipEventDestroy(p->ev);
         if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
@@ -891,7 +928,14 @@ int zg_prover_set_batch(zg_prover* p, size_t max_batch) {
     if (max_batch == p->cap) return ZG_OK;
     ZG_REQUIRE(max_batch >= 1 && max_batch <= 1024, ZG_ERR_INVALID_ARG, "zg_prover_set_batch: %zu proofs", max_batch);
     p->have_last = false;
-    return alloc_slots(p, (uint32_t)max_batch);
+    ZG_TRY(alloc_slots(p, (uint32_t)max_batch));
+    if (p->rccl_comm && p->gathered_cap < p->cap) {  // the gather buffer follows the slot count
+        if (p->gathered) (void)hipFree(p->gathered);
+        p->gathered = nullptr;
+        ZG_HIP(hipMalloc((void**)&p->gathered, (size_t)p->world * p->maxv * p->cap * sizeof(XYZZ)));
+        p->gathered_cap = p->cap;
+    }
+    return ZG_OK;
 }
 
 size_t zg_prover_batch(const zg_prover* p) { return p ? p->cap : 0; }
@@ -915,6 +959,7 @@ int zg_prover_fork(const zg_prover* parent, zg_ctx* ctx, zg_prover** out) {
     p->use_side = parent->use_side;
     p->shard_lo = parent->shard_lo; p->shard_n = parent->shard_n; p->world = parent->world; p->rank = parent->rank;
     p->exchange = parent->exchange; p->exchange_user = parent->exchange_user;
+    // (a communicator serialises its collectives on ONE stream: a fork does not inherit it)
     ZG_TRY(prover_events(p));
     if (p->use_side && !ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
     ZG_TRY(alloc_slots(p, parent->cap ? parent->cap : 1));
@@ -936,6 +981,40 @@ int zg_prover_set_shard(zg_prover* p, uint32_t rank, uint32_t world, size_t firs
     p->shard_n = (uint32_t)p->g->n;
     p->exchange = fn;
     p->exchange_user = user;
+    p->rccl_comm = nullptr;
+    return ZG_OK;
+}
+
+int zg_xyzz_sum_ranks_dev(zg_ctx* ctx, const void* d_parts, size_t world, size_t count, void* d_out) {
+    ZG_REQUIRE(ctx && d_out && (d_parts || count == 0) && world >= 1 && count < (1ull << 31), ZG_ERR_INVALID_ARG,
+               "zg_xyzz_sum_ranks_dev: bad argument");
+    if (count == 0) return ZG_OK;
+    ZG_ENTER(ctx);
+    ZG_LAUNCH(ctx, "xyzz_sum_ranks", (double)world * count * sizeof(XYZZ), xyzz_sum_ranks_kernel, dim3((uint32_t)((count + 63) / 64)),
+              dim3(64), 0, (const XYZZ*)d_parts, (uint32_t)world, (uint32_t)count, (XYZZ*)d_out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
+int zg_prover_set_shard_rccl(zg_prover* p, uint32_t rank, uint32_t world, size_t first_point, void* nccl_comm) {
+    ZG_REQUIRE(p && nccl_comm, ZG_ERR_INVALID_ARG, "zg_prover_set_shard_rccl: null argument");
+    ZG_ENTER(p->ctx);
+    ZG_REQUIRE(world >= 1 && rank < world, ZG_ERR_INVALID_ARG, "zg_prover_set_shard_rccl: rank %u of %u", rank, world);
+    ZG_REQUIRE(first_point + p->g->n <= p->pk->n, ZG_ERR_INVALID_ARG, "zg_prover_set_shard_rccl: points [%zu, %zu) of %u", first_point,
+               first_point + p->g->n, p->pk->n);
+    ZG_REQUIRE(world > 1 || p->g->n == p->pk->n, ZG_ERR_INVALID_ARG, "zg_prover_set_shard_rccl: a lone prover needs all 2^k points");
+    ZG_REQUIRE(rccl_all_gather() != nullptr, ZG_ERR_UNSUPPORTED, "zg_prover_set_shard_rccl: librccl.so could not be loaded");
+    if (p->gathered) (void)hipFree(p->gathered);
+    p->gathered = nullptr;
+    ZG_HIP(hipMalloc((void**)&p->gathered, (size_t)world * p->maxv * p->cap * sizeof(XYZZ)));
+    p->gathered_cap = (size_t)p->cap;
+    p->rank = rank;
+    p->world = world;
+    p->shard_lo = (uint32_t)first_point;
+    p->shard_n = (uint32_t)p->g->n;
+    p->exchange = nullptr;
+    p->exchange_user = nullptr;
+    p->rccl_comm = nccl_comm;
     return ZG_OK;
 }
 

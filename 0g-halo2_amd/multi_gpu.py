@@ -85,3 +85,40 @@ def make_exchange(dist_mod=dist, device=None, group=None):
         torch.frombuffer(recv, dtype=torch.uint8).copy_(out)
 
     return exchange
+
+
+class RcclComm:
+    """A raw RCCL communicator for zg_prover_set_shard_rccl (torch.distributed keeps its own to itself): rank 0 draws
+    the unique id, `dist_mod` (any backend) carries its 128 bytes to the others, every rank joins with ncclCommInitRank
+    on its own device.  world = 1 needs no dist_mod.  `handle` is the ncclComm_t."""
+
+    def __init__(self, rank: int, world: int, device_index: int, dist_mod=None, group=None):
+        import ctypes
+
+        class UniqueId(ctypes.Structure):
+            _fields_ = [("internal", ctypes.c_char * 128)]
+
+        self._rccl = ctypes.CDLL("librccl.so.1")
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipSetDevice(ctypes.c_int(device_index)) == 0
+        uid = UniqueId()
+        if rank == 0:
+            assert self._rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0, "ncclGetUniqueId failed"
+        if world > 1:
+            box = [bytes(uid.internal) if rank == 0 else None]
+            dist_mod.broadcast_object_list(box, src=0, group=group)
+            ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        comm = ctypes.c_void_p()
+        self._rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+        st = self._rccl.ncclCommInitRank(ctypes.byref(comm), ctypes.c_int(world), uid, ctypes.c_int(rank))
+        assert st == 0, f"ncclCommInitRank failed with {st}"
+        self.handle = comm.value
+        self.rank, self.world = rank, world
+
+    def close(self):
+        if getattr(self, "handle", None):
+            import ctypes
+
+            self._rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            self._rccl.ncclCommDestroy(ctypes.c_void_p(self.handle))
+            self.handle = None

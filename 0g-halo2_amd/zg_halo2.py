@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
     "zg_witness_plan_create", "zg_witness_plan_destroy", "zg_witness_plan_image_bytes", "zg_witness_plan_instance_len",
-    "zg_witness_run_dev", "zg_prover_prove_images",
+    "zg_witness_run_dev", "zg_prover_prove_images", "zg_prover_set_shard_rccl", "zg_xyzz_sum_ranks_dev",
 ]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
@@ -491,6 +491,11 @@ class Prover:
         self._exchange = EXCHANGE_FN(_cb) if world > 1 else None
         fn = self._exchange if self._exchange is not None else ctypes.cast(None, EXCHANGE_FN)
         _check(self.ctx.lib.zg_prover_set_shard(self.h, c_uint32(rank), c_uint32(world), c_size_t(first_point), fn, None))
+
+    def set_shard_rccl(self, rank: int, world: int, first_point: int, comm: int):
+        """comm: an initialised ncclComm_t (multi_gpu.RcclComm(...).handle); the exchange then runs inside the library."""
+        _check(self.ctx.lib.zg_prover_set_shard_rccl(self.h, c_uint32(rank), c_uint32(world), c_size_t(first_point),
+                                                     c_void_p(comm)))
 
     @staticmethod
     def _inst(instance):

@@ -112,7 +112,9 @@ class Stream:
         self.ctx, self.prover, self.c, self.batch = ctx, prover, c, batch
         prover.set_batch(batch)
         prover.set_overlap(False)  # throughput configuration: one HIP stream per prover, split extended domain
-        if shard[1] > 1:
+        if shard[1] > 1 and isinstance(exchange, int):  # an ncclComm_t: the all-gather runs inside the library
+            prover.set_shard_rccl(shard[0], shard[1], c.lo, exchange)
+        elif shard[1] > 1:
             prover.set_shard(shard[0], shard[1], c.lo, exchange)
         # the witness into every slot, once: a proof rewrites only the last blinding_factors+1 rows of its advice
         # columns and reads the rest, so the slots can be proved from again (inputs resident in HBM, as the contract asks)
@@ -376,6 +378,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="proofs per lock-step batch (zg_prover_prove_batch)")
     ap.add_argument("--provers", type=int, default=12, help="proof streams per GPU (provers sharing one proving key)")
     ap.add_argument("--mode", choices=["replicas", "shard-msm"], default="replicas")
+    ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
+                    help="shard-msm: all-gather through the host callback (torch.distributed) or inside the library on a raw "
+                         "RCCL communicator (zg_prover_set_shard_rccl; needs one GPU per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other three models")
@@ -431,7 +436,11 @@ def main():
     if sharded:
         import multi_gpu
 
-        exchange = multi_gpu.make_exchange(dist, dev if backend == "nccl" else None)
+        if args.exchange == "rccl":
+            rccl = multi_gpu.RcclComm(rank, world, dev_index, dist)
+            exchange = rccl.handle
+        else:
+            exchange = multi_gpu.make_exchange(dist, dev if backend == "nccl" else None)
 
     ctx0 = zg.Ctx(dev_index)
     circuit = Circuit(ctx0, args.model, shard)
@@ -531,7 +540,8 @@ def main():
                                       if args.model == "large" else ""),
                        "class_scores": circuit.scores,
                        "proofs_per_step": proofs_per_step,
-                       "parallelism": (f"{world} GPU(s), commitments sharded by point range (one all-gather per phase), "
+                       "parallelism": (f"{world} GPU(s), commitments sharded by point range (one all-gather per phase, "
+                                       f"{'inside the library on RCCL' if args.exchange == 'rccl' else 'host callback'}), "
                                        f"1 lock-step batch of {batch} proofs in flight" if sharded else
                                        f"{world} GPU(s) x {nprov} prover stream(s) x lock-step batches of {batch} proofs")},
             "mode": args.mode if world > 1 else "single-gpu",

@@ -299,6 +299,16 @@ typedef int (*zg_exchange_fn)(void *user, const void *send, size_t bytes, void *
 int zg_xyzz_sum_ranks(const void *parts, size_t world, size_t count, zg_g1 *out);
 int zg_prover_set_shard(zg_prover *p, uint32_t rank, uint32_t world, size_t first_point, zg_exchange_fn exchange,
                         void *user);
+/* The same shard with the exchange INSIDE the library: nccl_comm is an initialised RCCL communicator (ncclComm_t) of
+ * `world` ranks whose rank order is the point-range order, one per prover (a communicator serialises its collectives
+ * on one stream; forks do not inherit it).  Per commitment phase: ONE ncclAllGather of the phase's partial sums
+ * (128 B each) over xGMI on the prover's stream, the world - 1 additions per commitment in a kernel behind it, and
+ * only whole sums reach the host -- north_star's "single RCCL reduce of partial sums", spelt as gather + additions
+ * because EC addition is no ncclRedOp.  librccl.so is bound with dlopen when this entry is first used. */
+int zg_prover_set_shard_rccl(zg_prover *p, uint32_t rank, uint32_t world, size_t first_point, void *nccl_comm);
+/* The additions of that path as an entry of their own (device pointers, on the context's stream, not normalised:
+ * d_out[i] = sum over r of d_parts[r * count + i], both in the 128-byte extended Jacobian form). */
+int zg_xyzz_sum_ranks_dev(zg_ctx *ctx, const void *d_parts, size_t world, size_t count, void *d_out);
 /* Upper bound of the proof size in bytes for this circuit. */
 size_t zg_prover_proof_size(const zg_prover *p);
 /* Test hook: copies an intermediate of the LAST proof to the host.  what: 0 = h(X) on the extended

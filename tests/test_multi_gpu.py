@@ -202,3 +202,74 @@ def test_sharded_commitments_inside_create_proof_two_ranks_on_gpu():
         ret = m.dict()
         mp.spawn(_sharded_prover_worker, args=(world, 29541, ret), nprocs=world, join=True)
         assert all(ret[r] for r in range(world))
+
+
+@pytest.mark.gpu
+def test_rank_sums_on_the_device_match_the_host():
+    """zg_xyzz_sum_ranks_dev (the additions behind the in-library all-gather) against zg_xyzz_sum_ranks, on partial sums
+    of real shards: three 'ranks', five commitments, one of them the identity on every rank."""
+    import ctypes
+
+    sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import multi_gpu
+    import orc
+    import zg_halo2 as zg
+
+    ctx = zg.Ctx(0)
+    prm = orc.params_new(7)
+    g = prm.g_np()
+    n, world, count = g.shape[0], 3, 5
+    scal = [orc.fill_fr(60 + i, n) for i in range(count - 1)] + [np.zeros((n, 4), np.uint64)]
+    parts = np.zeros((world, count, 16), np.uint64)
+    for r in range(world):
+        lo, hi = multi_gpu.shard_range(n, r, world)
+        for i, s in enumerate(scal):
+            parts[r, i] = _xyzz_of(orc, orc.msm(s[lo:hi], g[lo:hi]))
+    want = zg.xyzz_sum_ranks(parts)
+    d_parts = torch.from_numpy(parts.view(np.int64).reshape(-1)).cuda()
+    d_out = torch.zeros(count * 16, dtype=torch.int64, device="cuda")
+    st = ctx.lib.zg_xyzz_sum_ranks_dev(ctx.h, ctypes.c_void_p(d_parts.data_ptr()), ctypes.c_size_t(world), ctypes.c_size_t(count),
+                                       ctypes.c_void_p(d_out.data_ptr()))
+    assert st == 0
+    ctx.sync()
+    summed = d_out.cpu().numpy().view(np.uint64).reshape(1, count, 16)
+    assert np.array_equal(zg.xyzz_sum_ranks(summed), want)
+    for i in range(count - 1):
+        assert np.array_equal(want[i], orc.msm(scal[i], g))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_in_library_rccl_exchange_single_rank():
+    """zg_prover_set_shard_rccl with a real RCCL communicator of ONE rank (two ranks on one GPU are refused by RCCL, and
+    this pool has one GPU per box): librccl is bound at run time, every commitment phase goes through ncclAllGather on
+    the prover's stream and the summing kernel, and the proofs are the oracle's -- in both scheduling forms, in a batch."""
+    sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import multi_gpu
+    import orc
+    import zg_halo2 as zg
+    from circuits import toy_circuit
+
+    ctx = zg.Ctx(0)
+    comm = multi_gpu.RcclComm(0, 1, 0)
+    cs, asg, ilen = toy_circuit(8, force_degree=6)
+    img = cs.to_c()
+    params = orc.params_new(8, 0xABCDEF)
+    vk_repr = orc.fr_from_int(0x1234567)
+    fixed, sigma = asg.fixed_values(), asg.sigma_values()
+    pk = orc.ProvingKey(img, fixed, sigma, params, vk_repr)
+    prover = zg.Prover(ctx, img, fixed, sigma, params.g_np(), params.g_lagrange_np(), vk_repr)
+    prover.set_shard_rccl(0, 1, 0, comm.handle)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    prover.set_batch(3)  # (after the shard call: the gather buffer follows the slot count)
+    for overlap in (True, False):
+        prover.set_overlap(overlap)
+        seeds = [71, 72, 73]
+        got, _ = prover.prove_batch([adv] * 3, [inst] * 3, seeds)
+        assert got == [orc.create_proof(pk, adv, inst, s)[1] for s in seeds]
+    prover.close()
+    comm.close()
+    ctx.close()
