@@ -574,7 +574,7 @@ def main():
         for m in ("small", "medium", "large"):
             c2 = Circuit(ctx0, m)
             b2 = batch if m != "large" else max(1, batch // 2)
-            np2 = min(nprov, 8)  # (a k = 17 slot is 1.4 GiB: 8 provers x 8 slots + workspaces = 130 GB of the 288)
+            np2 = min(nprov, 12)  # (a k = 17 slot is 1.4 GiB: 12 provers x 8 slots + workspaces = 175 GB of the 288)
             cx, st2, (lat, _) = make_streams(dev_index, c2, ctx0, np2, b2, rank, probe=latency_probe)
             dt2, _ = measure(st2, cx, 3, 1, barrier)
             others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * np2 * b2) * 1e3,
