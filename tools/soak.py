@@ -2,7 +2,9 @@
 """Concurrency soak of the bench configuration: P forked provers x batches of B on P host threads, S steps.  Every
 (prover, step, slot) proves under a key that a DIFFERENT prover uses in a different slot and step, so every proof has a
 twin made elsewhere, at another time, next to other neighbours: all twins must agree byte for byte, and a sample is
-checked against the oracle.    python tools/soak.py [P] [B] [S]"""
+checked against the oracle.    python tools/soak.py [P] [B] [S] [images]
+With a fourth argument every proof is for an image of bench.image_pool chosen by its key, the witness made on the device
+(zg_prover_prove_images): twins then share image AND key, and the oracle sample proves the host-synthesised witness."""
 import os
 import sys
 import threading
@@ -12,12 +14,20 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 zg = bench.zg
-P, B, S = (int(a) for a in (sys.argv[1:4] + ["8", "16", "12"][len(sys.argv) - 1:]))
+P, B, S = (int(a) for a in (sys.argv[1:4] + ["8", "16", "12"][len(sys.argv) - 1:])[:3])
+IMAGES = len(sys.argv) > 4
 ctx0 = zg.Ctx(0)
 c = bench.Circuit(ctx0, "tiny")
 ctxs, streams, _ = bench.make_streams(0, c, ctx0, P, B, 0)
 out = [[None] * S for _ in range(P)]
 errors = []
+pool = plans = None
+if IMAGES:
+    import witness_tape
+
+    pool = bench.image_pool(c)
+    arrays = witness_tape.trace(c.wnn, c.k).arrays()
+    plans = [zg.WitnessPlan(x, arrays) for x in ctxs]
 
 
 def key(p, s, b):  # the twin of (p, s, b) is (p ^ 1, S - 1 - s, B - 1 - b): same key, other prover, slot and time
@@ -29,7 +39,10 @@ def work(p):
     try:
         for s in range(S):
             seeds = [key(p, s, b) for b in range(B)]
-            out[p][s] = streams[p].prover.prove_batch(None, [c.instance] * B, seeds, device=True)[0]
+            if IMAGES:
+                out[p][s] = streams[p].prover.prove_images(plans[p], pool[[k % len(pool) for k in seeds]], seeds)[0]
+            else:
+                out[p][s] = streams[p].prover.prove_batch(None, [c.instance] * B, seeds, device=True)[0]
     except Exception as e:  # noqa: BLE001
         errors.append(e)
 
@@ -55,6 +68,16 @@ import orc  # noqa: E402
 params = orc.params_from_scalar(c.k, c.s)
 pk = orc.ProvingKey(c.img, c.fixed, c.sigma, params, c.vk_repr)
 sample = sorted(by_key)[:: max(1, len(by_key) // 6)][:6]
-bad = sum(orc.create_proof(pk, c.advice, c.instance, k)[1] != by_key[k] for k in sample)
+
+
+def want(k):
+    if not IMAGES:
+        return orc.create_proof(pk, c.advice, c.instance, k)[1]
+    im = pool[k % len(pool)].reshape(bench.wnn_model.load_test_image().shape)
+    _, asg, ilen, _ = bench.wnn_circuit.build(c.wnn, im, c.k)
+    return orc.create_proof(pk, asg.advice_values(), asg.instance_values(ilen), k)[1]
+
+
+bad = sum(want(k) != by_key[k] for k in sample)
 print(f"oracle check of {len(sample)} sampled keys: {bad} differ")
 sys.exit(1 if (mismatches or bad) else 0)
