@@ -899,7 +899,10 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         return ZG_OK;
     }
     static const uint32_t k_env = getenv("ZG_MSM_K") ? (uint32_t)atoi(getenv("ZG_MSM_K")) : 0;  // A/B knob
-    const uint32_t MSM_K = ctx->msm_pair ? MSM_K_LATENCY : (k_env >= 4 && k_env <= 120 ? k_env : MSM_K_THROUGHPUT);
+    // (A/B knob; a lone k = 14 proof with 12 / 16 / 24 / 32 / 48 points per task: 3.38 / 3.01 / 3.15 / 3.21 / 3.42 ms)
+    static const uint32_t kl_env = getenv("ZG_MSM_K_LAT") ? (uint32_t)atoi(getenv("ZG_MSM_K_LAT")) : 0;
+    const uint32_t MSM_K = ctx->msm_pair ? (kl_env >= 4 && kl_env <= 120 ? kl_env : MSM_K_LATENCY)
+                                         : (k_env >= 4 && k_env <= 120 ? k_env : MSM_K_THROUGHPUT);
     const uint64_t entries = (uint64_t)N * W;
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
     uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
