@@ -70,3 +70,32 @@ def test_flat_form_is_straight_line():
     im = wnn_model.load_test_image()
     v = t.run(im.reshape(-1))
     assert [v[s] for s in a["instance_slots"]] == [9, 6, 13, 10, 17, 10, 9, 26, 11, 16]  # integration_test.rs:19
+
+
+def test_helpers_on_integers_are_the_reference_formulas():
+    """On Python integers the chip helpers must compute what the reference's closures compute -- the running-sum step as a
+    product with the field inverse, selections as comparisons -- and on recorded values the same numbers."""
+    import random
+
+    rnd = random.Random(9)
+    inv = lambda x: pow(x, -1, symint.R)
+    t = symint.Tape()
+    for _ in range(50):
+        k = rnd.choice((1, 3, 8, 13))
+        x = rnd.getrandbits(60) << k
+        assert symint.exact_shr(x, k) == x * inv(1 << k) % symint.R == x >> k
+        w, nb = rnd.getrandbits(64), 8
+        idx = rnd.randrange(nb)
+        assert symint.byte_be(w, idx, nb) == [(w >> (8 * (nb - 1 - i))) & 0xFF for i in range(nb)][idx]
+        byte, bit = rnd.getrandbits(8), rnd.randrange(8)
+        assert symint.bit_of_byte(byte, bit) == (byte >> (7 - bit)) & 1
+        y = rnd.getrandbits(8)
+        assert (symint.gt(byte, y), symint.ge(byte, y), symint.eq(byte, y)) == (int(byte > y), int(byte >= y), int(byte == y))
+        # ... and recorded: the same values out of the interpreter
+        sw, si, sb, sbit = t.const(w), t.const(idx), t.const(byte), t.const(bit)
+        rec = [symint.exact_shr(t.const(x), k), symint.byte_be(sw, si, nb), symint.byte_be(sw, idx, nb), symint.bit_of_byte(sb, sbit),
+               symint.bit_of_byte(sb, bit), symint.gt(sb, y), symint.ge(sb, y), symint.eq(sb, y), 256 * symint.gt(sb, y) + y - sb + 255]
+        v = t.run([])
+        assert [v[r.slot] for r in rec] == [x >> k, symint.byte_be(w, idx, nb), symint.byte_be(w, idx, nb), (byte >> (7 - bit)) & 1,
+                                             (byte >> (7 - bit)) & 1, int(byte > y), int(byte >= y), int(byte == y),
+                                             256 * int(byte > y) + y - byte + 255]
