@@ -128,6 +128,9 @@ struct zg_bases {
     // the same points under a larger window (built on demand by bases_enable_dense): for vectors of random scalars,
     // which fill every window, fewer windows save more additions than the larger bucket set costs
     zg_bases* dense = nullptr;
+    // > 0: this table holds 2^j * P_i for EVERY bit position j (c = 1, 255 rows) and is multiplied with odd signed
+    // digits of naf_w bits at free positions (msm.hip msm_digits_naf_kernel); only a `dense` table is built that way
+    uint32_t naf_w = 0;
     std::mutex mu;
 };
 

@@ -192,6 +192,55 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ 
     }
 }
 
+// Odd signed digits at free bit positions (width-w non-adjacent form) for vectors of random scalars, against a table
+// with one row per BIT position (2^j P_i, j < 255): a non-zero digit d (odd, |d| < 2^(w-1)) is followed by at least
+// w - 1 zero bits, so a 254-bit scalar leaves ~254 / (w + 1) entries where c-bit windows leave 255 / c -- 15.9 instead
+// of 19 at the same 8192 buckets (only odd values occur: bucket k holds digit 2k - 1, and the reduction's
+// sum_k k B_k becomes 2 sum_k k B_k - sum_k B_k).  Entry = bucket | row << 16 | sign << 31 in slot order; the later
+// kernels treat slots as they treat windows.
+__global__ __launch_bounds__(256) void msm_digits_naf_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t per,
+                                                             size_t outer, uint32_t n, uint32_t w, uint32_t slots,
+                                                             uint32_t* __restrict__ dig) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    if (i >= n) return;
+    const Fe* sv = scalars + (size_t)(b / per) * outer + (size_t)(b % per) * stride;
+    const Fe s = Fr::to_raw(ld_fe_g(sv + i));
+    // 64-bit sliding register over the value; a digit's carry is folded straight into it (at most 48 valid bits
+    // are held, so the +1 cannot leave the register; a refill ADDS its limb above them)
+    uint64_t bits = (uint64_t)s.l[0];
+    uint32_t have = 32, next = 1, pos = 0, slot = 0;
+    uint32_t* db = dig + (size_t)b * slots * n + i;
+    const uint32_t mask = (1u << w) - 1u, half = 1u << (w - 1);
+    for (;;) {
+        if (have <= 16 && next < 8) {
+            const uint32_t limb = next == 1 ? s.l[1] : next == 2 ? s.l[2] : next == 3 ? s.l[3] : next == 4 ? s.l[4]
+                                : next == 5 ? s.l[5] : next == 6 ? s.l[6] : s.l[7];
+            bits += (uint64_t)limb << have;
+            have += 32;
+            next++;
+        }
+        if (bits == 0 && next >= 8) break;  // (all limbs in, nothing left)
+        if ((bits & 1ull) == 0) {           // skip the zero run (inside what is loaded)
+            uint32_t z = bits ? (uint32_t)__ffsll((long long)bits) - 1u : have;
+            if (z > have) z = have;
+            if (z == 0) z = 1;
+            bits >>= z;
+            have -= z;
+            pos += z;
+            continue;
+        }
+        const uint32_t v = (uint32_t)bits & mask;  // odd
+        const bool neg = v > half;
+        const uint32_t d = neg ? (mask + 1u) - v : v;
+        if (slot < slots) db[(size_t)slot * n] = ((d + 1u) >> 1) | (pos << 16) | (neg ? 0x80000000u : 0u);
+        slot++;
+        bits = (bits >> w) + (neg ? 1ull : 0ull);
+        have = have >= w ? have - w : 0;
+        pos += w;
+    }
+    for (; slot < slots; slot++) db[(size_t)slot * n] = 0u;
+}
+
 // One workgroup per (window, vector): bucket histogram of that window in LDS (LDS atomics return the
 // entry's slot inside its (window, bucket) cell), then one coalesced write of the counts.  No global
 // atomics: on this chip scattered device-scope atomics top out near 2*10^10/s, which made the old
@@ -207,7 +256,7 @@ __global__ __launch_bounds__(1024) void msm_hist_kernel(const uint32_t* __restri
     const uint32_t* db = dig + ((size_t)b * windows + w) * n;
     uint32_t* sb = slot + ((size_t)b * windows + w) * n;
     for (uint32_t i = tid; i < n; i += 1024) {
-        uint32_t k = db[i] & 0x7fffffffu;
+        uint32_t k = db[i] & 0xffffu;  // (bits 16..23: the table row of a free-position digit, else zero)
         if (k != 0) sb[i] = atomicAdd(&hist[k], 1u);
     }
     __syncthreads();
@@ -361,17 +410,19 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
 __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __restrict__ dig, uint32_t n, uint32_t c,
                                                           uint32_t windows, const uint32_t* __restrict__ off,
                                                           const uint32_t* __restrict__ slot,
-                                                          uint32_t* __restrict__ sorted) {
+                                                          uint32_t* __restrict__ sorted, uint32_t naf) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t w = blockIdx.y, b = blockIdx.z;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
     const size_t cell = ((size_t)b * windows + w);
     const uint32_t d = dig[cell * n + i];
-    const uint32_t k = d & 0x7fffffffu;
+    const uint32_t k = d & 0xffffu;
     if (k == 0) return;
     uint32_t pos = off[cell * (nb + 1) + k] + slot[cell * n + i];
-    sorted[(size_t)b * windows * n + pos] = i | (w << 24) | (d & 0x80000000u);
+    // entry = point (23 bits) | table row (8 bits: the window, or the bit position of a free-position digit) | sign
+    const uint32_t row = naf ? (d >> 16) & 0xffu : w;
+    sorted[(size_t)b * windows * n + pos] = i | (row << 23) | (d & 0x80000000u);
 }
 
 // One lane per task: at most K points of one bucket, mixed adds in XYZZ on nine 29-bit limbs (field9.h:
@@ -427,7 +478,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
         PairAcc acc;
         for (uint32_t e = 0; e < len; e++) {  // (both lanes of a pair see the same entries)
             uint32_t ent = so[e];
-            uint32_t i = ent & 0xffffffu, w = (ent >> 24) & 0x7fu;
+            uint32_t i = ent & 0x7fffffu, w = (ent >> 23) & 0xffu;
             const Affine* src = table + (size_t)w * n_table + i;
             const F9 qx = f9_unpack(ld_fe_g(&src->x));
             F9 qy = f9_unpack(ld_fe_g(&src->y));
@@ -448,7 +499,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
         XYZZ9 acc;
         for (uint32_t e = 0; e < len; e++) {
             uint32_t ent = so[e];
-            uint32_t i = ent & 0xffffffu, w = (ent >> 24) & 0x7fu;
+            uint32_t i = ent & 0x7fffffu, w = (ent >> 23) & 0xffu;
             const Affine* src = table + (size_t)w * n_table + i;
             const F9 qx = f9_unpack(ld_fe_g(&src->x));
             F9 qy = f9_unpack(ld_fe_g(&src->y));
@@ -671,7 +722,7 @@ __global__ __launch_bounds__(256) void msm_strip_kernel(const XYZZ9* __restrict_
 
 __global__ __launch_bounds__(MSM_STRIP_LANES) void msm_strip_sum_kernel(const XYZZ9* __restrict__ strip_u,
                                                                        const XYZZ9* __restrict__ strip_loc, uint32_t nstrips,
-                                                                       uint32_t per, XYZZ* __restrict__ out, uint32_t S) {
+                                                                       uint32_t per, XYZZ* __restrict__ out, uint32_t S, uint32_t odd) {
     __shared__ XYZZ9 sh[MSM_STRIP_LANES];
     const uint32_t l = threadIdx.x, b = blockIdx.x;
     const XYZZ9* U = strip_u + (size_t)b * nstrips;
@@ -712,11 +763,19 @@ __global__ __launch_bounds__(MSM_STRIP_LANES) void msm_strip_sum_kernel(const XY
     XYZZ9 W = tree(sfx);
     const XYZZ9 wsum = tree(w);
     const XYZZ9 asum = tree(a);
+    XYZZ9 T = xyzz9_identity();
+    if (odd) T = tree(C);  // sum_k B_k (workgroup-uniform branch)
     if (l != 0) return;
     for (uint32_t d = per; d > 1; d >>= 1) W = xyzz9_add(W, W);            // per * W   (equal operands: the doubling case)
     XYZZ9 V = xyzz9_add(W, wsum);                                           // sum_j j U_j
     for (uint32_t d = S; d > 1; d >>= 1) V = xyzz9_add(V, V);              // S * V
-    st_xyzz(out + b, xyzz9_to_xyzz(xyzz9_add(V, asum), false));
+    XYZZ9 R = xyzz9_add(V, asum);  // sum_k k B_k
+    if (odd) {   // bucket k holds the digit 2k - 1:  2 sum_k k B_k - sum_k B_k
+        R = xyzz9_add(R, R);
+        T.y = f9_neg(T.y);
+        R = xyzz9_add(R, T);
+    }
+    st_xyzz(out + b, xyzz9_to_xyzz(R, false));
 }
 
 static uint32_t default_window_bits(size_t n) {
@@ -735,9 +794,10 @@ static uint32_t default_window_bits(size_t n) {
 }
 
 int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t window_bits, zg_bases** out) {
-    ZG_REQUIRE(n > 0 && n < (1u << 24), ZG_ERR_UNSUPPORTED, "zg_bases_register: n=%zu out of range", n);
+    ZG_REQUIRE(n > 0 && n < (1u << 23), ZG_ERR_UNSUPPORTED, "zg_bases_register: n=%zu out of range", n);
     uint32_t c = window_bits ? window_bits : default_window_bits(n);
-    ZG_REQUIRE(c >= 2 && c <= MSM_MAX_C, ZG_ERR_INVALID_ARG, "zg_bases_register: window_bits %u not in [2,16]", c);
+    // (c = 1, one row per bit position, is what bases_enable_naf builds; the public entries ask for 2..16)
+    ZG_REQUIRE(c >= 1 && c <= MSM_MAX_C, ZG_ERR_INVALID_ARG, "zg_bases_register: window_bits %u not in [2,16]", c);
     uint32_t windows = (255 + c - 1) / c;
     zg_bases* b = new zg_bases();
     b->ctx = ctx;
@@ -774,6 +834,24 @@ __global__ void msm_untable_kernel(const Affine* __restrict__ table, Affine* __r
     if (i >= n) return;
     st_fe_g(&bases[i].x, Fq::mul(ld_fe_g(&table[i].x), un));
     st_fe_g(&bases[i].y, Fq::mul(ld_fe_g(&table[i].y), un));
+}
+
+// The same points with one table row per bit position (c = 1: 255 rows, 255 * n * 64 B -- 0.27 GB at k = 14, 2.1 GB at
+// k = 17, what 288 GB of HBM are for) for free-position odd digits of `w` bits (idempotent; excludes bases_enable_dense).
+int bases_enable_naf(zg_ctx* ctx, zg_bases* b, uint32_t w) {
+    std::lock_guard<std::mutex> lock(b->mu);
+    if (b->dense) return ZG_OK;
+    ZG_REQUIRE(w >= 3 && w <= 16, ZG_ERR_INVALID_ARG, "bases_enable_naf: digit width %u not in [3,16]", w);
+    WsScope ws(ctx);
+    Affine* d = ws.get<Affine>(b->n);
+    if (!d) return ZG_ERR_OOM;
+    const Fe un = Fq::inv(Fq9Params::c261_fe());
+    hipLaunchKernelGGL(msm_untable_kernel, dim3((uint32_t)((b->n + 255) / 256)), dim3(256), 0, ctx->stream, b->table, d,
+                       (uint32_t)b->n, un);
+    ZG_HIP(hipGetLastError());
+    ZG_TRY(bases_register_dev(ctx, d, b->n, 1, &b->dense));
+    b->dense->naf_w = w;
+    return ZG_OK;
 }
 
 // A second window table of the same points with `window_bits` bits per window (idempotent; the first call decides
@@ -890,7 +968,12 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_REQUIRE(n <= bases->n, ZG_ERR_INVALID_ARG, "zg_msm: %zu scalars for %zu bases", n, bases->n);
     ZG_REQUIRE(batch <= 65535, ZG_ERR_UNSUPPORTED, "zg_msm: batch %zu > 65535", batch);
     if (batch == 0) return ZG_OK;
-    const uint32_t c = bases->c, W = bases->windows, nb = 1u << (c - 1);
+    // free-position odd digits (bases_enable_naf): "c" below is then the bucket-index width + 1 (nb = 2^(w-2) buckets),
+    // "W" the digit slots per scalar; the throughput form's kernels take both as they take windows
+    const uint32_t naf = bases->naf_w;
+    ZG_REQUIRE(!naf || (!bases_b && run_mask == 0 && !ctx->msm_pair), ZG_ERR_UNSUPPORTED,
+               "zg_msm: a bit-position table serves one base set, no run form, the throughput form only");
+    const uint32_t c = naf ? naf - 1 : bases->c, W = naf ? 254 / naf + 2 : bases->windows, nb = 1u << (c - 1);
     const uint32_t B = (uint32_t)batch, N = (uint32_t)n;
     if (n == 0) {
         std::vector<XYZZ> ids(batch, xyzz_identity());
@@ -978,8 +1061,12 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                                      // capped at 6 it spread over ~200, each just past the hot-bucket threshold)
     }
     if (const char* e = getenv("ZG_MSM_BALANCE")) tbits = atoi(e) ? tbits : 0;
-    ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
-              (uint32_t)per, outer, N, c, W, tbits, dig, run_mask);
+    if (naf)
+        ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_naf_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
+                  (uint32_t)per, outer, N, naf, W, dig);
+    else
+        ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
+                  (uint32_t)per, outer, N, c, W, tbits, dig, run_mask);
     ZG_LAUNCH(ctx, "msm_hist", msm_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
@@ -1002,7 +1089,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         }
     }
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
-              off, slot, sorted);
+              off, slot, sorted, naf);
     if (ctx->msm_pair) {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<true>, dim3((2 * max_tasks + 255) / 256, B), dim3(256),
                   0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
@@ -1038,7 +1125,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<1>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
         static const bool strips = !(getenv("ZG_MSM_STRIPS") && atoi(getenv("ZG_MSM_STRIPS")) == 0);  // A/B knob
-        if (strips) {
+        if (strips || naf) {
             // (sfx has room for nb points per vector: the strip sums and strip-local weighted sums share it)
             static const uint32_t s_env = getenv("ZG_MSM_STRIP") ? (uint32_t)atoi(getenv("ZG_MSM_STRIP")) : 0;  // A/B knob
             const uint32_t S = s_env == 2 || s_env == 4 || s_env == 8 || s_env == 16 ? s_env : MSM_STRIP;
@@ -1049,7 +1136,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
             ZG_LAUNCH(ctx, "msm_strip", msm_bytes, msm_strip_kernel, dim3((nstrips + 255) / 256, B), dim3(256), 0, partial,
                       toff, hmap, hsum, max_tasks, max_heavy, c, nstrips, strip_u, strip_loc, S);
             ZG_LAUNCH(ctx, "msm_strip_sum", msm_bytes, msm_strip_sum_kernel, dim3(B), dim3(MSM_STRIP_LANES), 0, strip_u, strip_loc,
-                      nstrips, per, d_out, S);
+                      nstrips, per, d_out, S, naf ? 1u : 0u);
         } else {
             ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
                       toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);

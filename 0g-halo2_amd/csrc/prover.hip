@@ -806,7 +806,9 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         static const int dense_env = getenv("ZG_MSM_C_DENSE") ? atoi(getenv("ZG_MSM_C_DENSE")) : -1;  // A/B knob; 0 = none
         uint32_t cd = p->g->c + 2 <= 15 ? p->g->c + 2 : 15;
         if (dense_env >= 0) cd = (uint32_t)dense_env;
-        if (cd > p->g->c && cd <= 16) ZG_TRY(bases_enable_dense(ctx, p->g, cd));
+        static const int naf_env = getenv("ZG_MSM_NAF") ? atoi(getenv("ZG_MSM_NAF")) : 0;  // A/B knob: digit width, 0 = none
+        if (naf_env >= 3 && naf_env <= 16) ZG_TRY(bases_enable_naf(ctx, p->g, (uint32_t)naf_env));
+        else if (cd > p->g->c && cd <= 16) ZG_TRY(bases_enable_dense(ctx, p->g, cd));
     }
 
     // ---- proving-key slabs
