@@ -381,17 +381,19 @@ def test_stand_alone_evaluate_h_matches_oracle(ctx, zg, orc, k, force_degree):
 
 def test_ab_knob_variants_give_the_same_bytes():
     """The forms the default replaced stay selectable for A/B (read once per process): evaluate_h folding in y term by
-    term (ZG_EVALH_GROUPED=0) and the quotient / opening commitments against the one table of g (ZG_MSM_C_DENSE=0).
-    Rerun the proof-parity tests of this file in a child process with both switched."""
+    term (ZG_EVALH_GROUPED=0) and the quotient / opening commitments against the one table of g (ZG_MSM_C_DENSE=0,
+    ZG_MSM_NAF=0) or against a second table with larger windows (ZG_MSM_NAF=0 alone) instead of the bit-position table.
+    Rerun the proof-parity tests of this file in child processes with those."""
     import os
     import subprocess
     import sys
 
     if os.environ.get("ZG_EVALH_GROUPED") == "0":
         pytest.skip("already inside the variant run")
-    env = dict(os.environ, ZG_EVALH_GROUPED="0", ZG_MSM_C_DENSE="0")
     here = os.path.abspath(__file__)
     pick = "test_proof_bytes_match_oracle_and_verify or test_circuit_variants_match_oracle or test_split_extended_domain"
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", here, "-k", pick], env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    # (1) one table of g, term-by-term fold; (2) the larger-window second table instead of the bit-position one
+    for knobs in (dict(ZG_EVALH_GROUPED="0", ZG_MSM_C_DENSE="0", ZG_MSM_NAF="0"), dict(ZG_MSM_NAF="0")):
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", here, "-k", pick], env=dict(os.environ, **knobs),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
