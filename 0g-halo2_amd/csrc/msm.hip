@@ -200,11 +200,34 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ 
 // kernels treat slots as they treat windows.
 __global__ __launch_bounds__(256) void msm_digits_naf_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t per,
                                                              size_t outer, uint32_t n, uint32_t w, uint32_t slots,
-                                                             uint32_t* __restrict__ dig) {
+                                                             uint32_t* __restrict__ dig, uint64_t run_mask) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= n) return;
-    const Fe* sv = scalars + (size_t)(b / per) * outer + (size_t)(b % per) * stride;
-    const Fe s = Fr::to_raw(ld_fe_g(sv + i));
+    const uint32_t vj = b % per;
+    const Fe* sv = scalars + (size_t)(b / per) * outer + (size_t)vj * stride;
+    Fe s = ld_fe_g(sv + i);
+    uint32_t flip = 0;  // the whole scalar negated: every digit's sign flips
+    if (vj < 64 && ((run_mask >> vj) & 1ull)) {  // run form, as in msm_digits_kernel: s_i - s_{i+1}, taken as the smaller of s and r - s
+        if (i + 1 < n) s = Fr::sub(s, ld_fe_g(sv + i + 1));
+        s = Fr::to_raw(s);
+        Fe neg, pr;
+#pragma unroll
+        for (int j = 0; j < 8; j++) pr.l[j] = FrParams::p(j);
+        sub8(neg.l, pr.l, s.l);  // r - s (s < r)
+        bool smaller = false;    // neg < s ?
+        for (int j = 7; j >= 0; j--) {
+            if (neg.l[j] != s.l[j]) {
+                smaller = neg.l[j] < s.l[j];
+                break;
+            }
+        }
+        if (smaller && !fe_is_zero(s)) {
+            s = neg;
+            flip = 0x80000000u;
+        }
+    } else {
+        s = Fr::to_raw(s);
+    }
     // 64-bit sliding register over the value; a digit's carry is folded straight into it (at most 48 valid bits
     // are held, so the +1 cannot leave the register; a refill ADDS its limb above them)
     uint64_t bits = (uint64_t)s.l[0];
@@ -232,7 +255,7 @@ __global__ __launch_bounds__(256) void msm_digits_naf_kernel(const Fe* __restric
         const uint32_t v = (uint32_t)bits & mask;  // odd
         const bool neg = v > half;
         const uint32_t d = neg ? (mask + 1u) - v : v;
-        if (slot < slots) db[(size_t)slot * n] = ((d + 1u) >> 1) | (pos << 16) | (neg ? 0x80000000u : 0u);
+        if (slot < slots) db[(size_t)slot * n] = ((d + 1u) >> 1) | (pos << 16) | ((neg ? 0x80000000u : 0u) ^ flip);
         slot++;
         bits = (bits >> w) + (neg ? 1ull : 0ull);
         have = have >= w ? have - w : 0;
@@ -971,8 +994,8 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     // free-position odd digits (bases_enable_naf): "c" below is then the bucket-index width + 1 (nb = 2^(w-2) buckets),
     // "W" the digit slots per scalar; the throughput form's kernels take both as they take windows
     const uint32_t naf = bases->naf_w;
-    ZG_REQUIRE(!naf || (!bases_b && run_mask == 0 && !ctx->msm_pair), ZG_ERR_UNSUPPORTED,
-               "zg_msm: a bit-position table serves one base set, no run form, the throughput form only");
+    ZG_REQUIRE(!naf || !ctx->msm_pair, ZG_ERR_UNSUPPORTED, "zg_msm: a bit-position table serves the throughput form only");
+    ZG_REQUIRE(!bases_b || bases_b->naf_w == naf, ZG_ERR_INVALID_ARG, "zg_msm: the two base sets differ in their digit form");
     const uint32_t c = naf ? naf - 1 : bases->c, W = naf ? 254 / naf + 2 : bases->windows, nb = 1u << (c - 1);
     const uint32_t B = (uint32_t)batch, N = (uint32_t)n;
     if (n == 0) {
@@ -1063,7 +1086,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     if (const char* e = getenv("ZG_MSM_BALANCE")) tbits = atoi(e) ? tbits : 0;
     if (naf)
         ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_naf_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
-                  (uint32_t)per, outer, N, naf, W, dig);
+                  (uint32_t)per, outer, N, naf, W, dig, run_mask);
     else
         ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
                   (uint32_t)per, outer, N, c, W, tbits, dig, run_mask);

@@ -267,6 +267,12 @@ extern "C" int zg_xyzz_sum_ranks(const void* parts, size_t world, size_t count, 
 
 namespace {
 
+// the bit-position table of a base set for the throughput form's commitments of full-size scalars (the sorted a' / s'
+// columns and the products in their run form, the random vectors), else the base set itself
+static const zg_bases* naf_of(const zg_prover* p, const zg_bases* b) {
+    return b && b->dense && b->dense->naf_w && !p->ctx->msm_pair ? b->dense : b;
+}
+
 static const zg_bases* dense_g(const zg_prover* p) {
     static const bool lat = getenv("ZG_MSM_DENSE_LATENCY") && atoi(getenv("ZG_MSM_DENSE_LATENCY"));
     return p->g->dense && (lat || !p->ctx->msm_pair) ? p->g->dense : p->g;
@@ -816,8 +822,18 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         while ((2u << lg) <= p->g->n) lg++;
         uint32_t nw = lg >= 16 ? 16u : lg >= 14 ? 15u : lg + 1 < 3 ? 3u : lg + 1;
         if (naf_env >= 0) nw = (uint32_t)naf_env;
-        if (nw >= 3 && nw <= 16) ZG_TRY(bases_enable_naf(ctx, p->g, nw));
-        else if (cd > p->g->c && cd <= 16) ZG_TRY(bases_enable_dense(ctx, p->g, cd));
+        // (for g_lagrange too -- the run-form columns -- only on request: their coefficient vectors are half empty, so
+        //  the four-fold bucket sets cost more than the shorter digit strings save: 0.718 -> 0.740 ms/proof at w = 15)
+        static const bool naf_gl = getenv("ZG_MSM_NAF_GL") && atoi(getenv("ZG_MSM_NAF_GL")) != 0;  // A/B knob
+        if (nw >= 3 && nw <= 16) {
+            ZG_TRY(bases_enable_naf(ctx, p->g, nw));
+            if (naf_gl && p->gl->run_table && p->g->dense && p->g->dense->naf_w) {
+                // the same for g_lagrange and its running sums: the sorted columns and the products are committed in the
+                // run form, whose coefficients s_i - s_{i+1} are full-size scalars wherever a row changes something
+                ZG_TRY(bases_enable_naf(ctx, p->gl, p->g->dense->naf_w));
+                if (p->gl->dense && p->gl->dense->naf_w == p->g->dense->naf_w) ZG_TRY(bases_enable_runs(ctx, p->gl->dense));
+            }
+        } else if (cd > p->g->c && cd <= 16) ZG_TRY(bases_enable_dense(ctx, p->g, cd));
     }
 
     // ---- proving-key slabs
@@ -1198,8 +1214,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
         ZG_TRY(fork());
         // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
-        const uint64_t sorted_runs = p->gl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
-        ZG_TRY(commit(p, p->gl, p->g, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs));
+        const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);  // (both or neither)
+        const uint64_t sorted_runs = cgl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
+        ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs));
         uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
         ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ZG_HIP(hipEventRecord(p->ev, st));  // (wait_points waits for the error words too)
@@ -1248,16 +1265,17 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(poly_blind_rows2(ctx, p->d_pc, nb, p->zs, zs_bs, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf));  // (lz follows pz)
         // The products stay constant wherever a row changes nothing (every padding row of the circuit): they are
         // committed in the run form, sum_i (z_i - z_{i+1}) Q_i over the running sums Q of g_lagrange.
-        const uint64_t z_runs = p->gl->run_table && mb < 64 ? (1ull << mb) - 1ull : 0ull;
+        const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);
+        const uint64_t z_runs = cgl->run_table && mb < 64 ? (1ull << mb) - 1ull : 0ull;
         ZG_TRY(fork());
         uint32_t per = mb;
         if (have_random) {
-            ZG_TRY(commit(p, p->gl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs));
+            ZG_TRY(commit(p, cgl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs));
         } else {  // no lookups: the random polynomial rides here instead (row mb of zs)
             for (uint32_t b = 0; b < nb; b++)
                 ZG_HIP(hipMemcpyAsync(p->zs + b * zs_bs + (size_t)mb * n, random_row + b * perm_bs, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
             per = mb + 1;
-            ZG_TRY(commit(p, p->gl, p->g, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs));
+            ZG_TRY(commit(p, cgl, cg, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs));
         }
         {
             const Grouping g = grouping(mb, zs_bs, pp_bs);
