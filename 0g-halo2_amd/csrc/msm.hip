@@ -996,7 +996,8 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     const uint32_t naf = bases->naf_w;
     ZG_REQUIRE(!naf || !ctx->msm_pair, ZG_ERR_UNSUPPORTED, "zg_msm: a bit-position table serves the throughput form only");
     ZG_REQUIRE(!bases_b || bases_b->naf_w == naf, ZG_ERR_INVALID_ARG, "zg_msm: the two base sets differ in their digit form");
-    const uint32_t c = naf ? naf - 1 : bases->c, W = naf ? 254 / naf + 2 : bases->windows, nb = 1u << (c - 1);
+    // (digits sit at least `naf` positions apart, the first at >= 0, the last at <= 254: at most 254 / naf + 1 of them)
+    const uint32_t c = naf ? naf - 1 : bases->c, W = naf ? 254 / naf + 1 : bases->windows, nb = 1u << (c - 1);
     const uint32_t B = (uint32_t)batch, N = (uint32_t)n;
     if (n == 0) {
         std::vector<XYZZ> ids(batch, xyzz_identity());
