@@ -31,7 +31,8 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
 int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
 int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
-                   size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask);
+                   size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask,
+                   uint32_t naf_width);
 
 // Max points per accumulate task.  Throughput form: 48 -- the fewer tasks, the fewer partial sums the reduction has
 // to merge, and since lanes take tasks in length-sorted order (msm_scan_kernel) longer tasks cost no lane
@@ -966,14 +967,15 @@ int msm_batch2_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
 // base set must have its running-sum table (bases_enable_runs).
 int msm_batch3_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
                    size_t stride, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask) {
-    return msm_batch4_dev(ctx, bases, bases_b, split, d_scalars, stride, 0, 0, batch, n, d_out, run_mask);
+    return msm_batch4_dev(ctx, bases, bases_b, split, d_scalars, stride, 0, 0, batch, n, d_out, run_mask, 0);
 }
 
 // ... and the batch may be `batch / per` groups of `per` vectors each (the same commitments of several proofs):
 // vector v = group * per + j lives at d_scalars + group * outer + j * stride; split and run_mask go by j.
 // per = 0: one group (v = j).
 int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars,
-                   size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask) {
+                   size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask,
+                   uint32_t naf_width) {
     if (per == 0) {
         per = batch ? batch : 1;
         outer = 0;
@@ -993,9 +995,11 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     if (batch == 0) return ZG_OK;
     // free-position odd digits (bases_enable_naf): "c" below is then the bucket-index width + 1 (nb = 2^(w-2) buckets),
     // "W" the digit slots per scalar; the throughput form's kernels take both as they take windows
-    const uint32_t naf = bases->naf_w;
+    // (a bit-position table serves any digit width: naf_width picks it per launch, 0 = the width the table was made for)
+    const uint32_t naf = bases->naf_w ? (naf_width ? naf_width : bases->naf_w) : 0;
     ZG_REQUIRE(!naf || !ctx->msm_pair, ZG_ERR_UNSUPPORTED, "zg_msm: a bit-position table serves the throughput form only");
-    ZG_REQUIRE(!bases_b || bases_b->naf_w == naf, ZG_ERR_INVALID_ARG, "zg_msm: the two base sets differ in their digit form");
+    ZG_REQUIRE(!naf || (naf >= 3 && naf <= 16), ZG_ERR_INVALID_ARG, "zg_msm: digit width %u", naf);
+    ZG_REQUIRE(!bases_b || (bases_b->naf_w != 0) == (naf != 0), ZG_ERR_INVALID_ARG, "zg_msm: the two base sets differ in their digit form");
     // (digits sit at least `naf` positions apart, the first at >= 0, the last at <= 254: at most 254 / naf + 1 of them)
     const uint32_t c = naf ? naf - 1 : bases->c, W = naf ? 254 / naf + 1 : bases->windows, nb = 1u << (c - 1);
     const uint32_t B = (uint32_t)batch, N = (uint32_t)n;

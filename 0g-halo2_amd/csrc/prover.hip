@@ -273,6 +273,18 @@ static const zg_bases* naf_of(const zg_prover* p, const zg_bases* b) {
     return b && b->dense && b->dense->naf_w && !p->ctx->msm_pair ? b->dense : b;
 }
 
+// Digit width of the free-position form for the run-form commitments against g_lagrange (the sorted a' / s' columns and
+// the products: full-size coefficients wherever a row changes something, but half-empty vectors -- so the width that
+// keeps the bucket count of the window form, c + 1: 254 / (c + 2) digits per coefficient instead of 255 / c windows.
+// Same-box A/B at k = 14: 0.7122 -> 0.7060 ms/proof at 13; 12: 0.718, 14: 0.722; 15, the random vectors' width: 0.740.)
+// ZG_MSM_NAF_GL = width, 0 = the window form.
+static uint32_t naf_gl_width(const zg_prover* p) {
+    static const int v = getenv("ZG_MSM_NAF_GL") ? atoi(getenv("ZG_MSM_NAF_GL")) : -1;
+    if (v >= 0) return v >= 3 && v <= 16 ? (uint32_t)v : 0u;
+    const uint32_t w = p->gl->c + 1;
+    return w >= 3 && w <= 16 ? w : 0u;
+}
+
 static const zg_bases* dense_g(const zg_prover* p) {
     static const bool lat = getenv("ZG_MSM_DENSE_LATENCY") && atoi(getenv("ZG_MSM_DENSE_LATENCY"));
     return p->g->dense && (lat || !p->ctx->msm_pair) ? p->g->dense : p->g;
@@ -302,9 +314,10 @@ __global__ void xyzz_sum_ranks_kernel(const XYZZ* __restrict__ parts, uint32_t w
 }
 
 int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, const Fe* scalars, size_t stride, size_t per,
-           size_t outer, size_t count, uint64_t run_mask) {
+           size_t outer, size_t count, uint64_t run_mask, uint32_t naf_width = 0) {
     ZG_REQUIRE(count <= p->maxv * (size_t)p->cap, ZG_ERR_INVALID_ARG, "zg_prover: %zu commitments in one phase", count);
-    ZG_TRY(msm_batch4_dev(p->ctx, a, b2, split, scalars + p->shard_lo, stride, per, outer, count, p->shard_n, p->xyzz, run_mask));
+    ZG_TRY(msm_batch4_dev(p->ctx, a, b2, split, scalars + p->shard_lo, stride, per, outer, count, p->shard_n, p->xyzz, run_mask,
+                          naf_width));
     if (p->rccl_comm) {  // ONE all-gather of the phase's partial sums over xGMI, then the additions, all on this stream
         rccl_all_gather_fn gather = rccl_all_gather();
         ZG_REQUIRE(gather != nullptr, ZG_ERR_UNSUPPORTED, "zg_prover: librccl.so could not be loaded");
@@ -822,9 +835,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         while ((2u << lg) <= p->g->n) lg++;
         uint32_t nw = lg >= 16 ? 16u : lg >= 14 ? 15u : lg + 1 < 3 ? 3u : lg + 1;
         if (naf_env >= 0) nw = (uint32_t)naf_env;
-        // (for g_lagrange too -- the run-form columns -- only on request: their coefficient vectors are half empty, so
-        //  the four-fold bucket sets cost more than the shorter digit strings save: 0.718 -> 0.740 ms/proof at w = 15)
-        static const bool naf_gl = getenv("ZG_MSM_NAF_GL") && atoi(getenv("ZG_MSM_NAF_GL")) != 0;  // A/B knob
+        const bool naf_gl = naf_gl_width(p) != 0;  // (the same tables serve any digit width: naf_gl_width)
         if (nw >= 3 && nw <= 16) {
             ZG_TRY(bases_enable_naf(ctx, p->g, nw));
             if (naf_gl && p->gl->run_table && p->g->dense && p->g->dense->naf_w) {
@@ -1216,7 +1227,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
         const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);  // (both or neither)
         const uint64_t sorted_runs = cgl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
-        ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs));
+        ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs, naf_gl_width(p)));
         uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
         ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         ZG_HIP(hipEventRecord(p->ev, st));  // (wait_points waits for the error words too)
@@ -1270,12 +1281,12 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(fork());
         uint32_t per = mb;
         if (have_random) {
-            ZG_TRY(commit(p, cgl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs));
+            ZG_TRY(commit(p, cgl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs, naf_gl_width(p)));
         } else {  // no lookups: the random polynomial rides here instead (row mb of zs)
             for (uint32_t b = 0; b < nb; b++)
                 ZG_HIP(hipMemcpyAsync(p->zs + b * zs_bs + (size_t)mb * n, random_row + b * perm_bs, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
             per = mb + 1;
-            ZG_TRY(commit(p, cgl, cg, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs));
+            ZG_TRY(commit(p, cgl, cg, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs, naf_gl_width(p)));
         }
         {
             const Grouping g = grouping(mb, zs_bs, pp_bs);

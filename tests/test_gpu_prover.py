@@ -393,7 +393,8 @@ def test_ab_knob_variants_give_the_same_bytes():
     here = os.path.abspath(__file__)
     pick = "test_proof_bytes_match_oracle_and_verify or test_circuit_variants_match_oracle or test_split_extended_domain"
     # (1) one table of g, term-by-term fold; (2) the larger-window second table instead of the bit-position one
-    for knobs in (dict(ZG_EVALH_GROUPED="0", ZG_MSM_C_DENSE="0", ZG_MSM_NAF="0"), dict(ZG_MSM_NAF="0")):
+    # (3) free-position digits for the random vectors only
+    for knobs in (dict(ZG_EVALH_GROUPED="0", ZG_MSM_C_DENSE="0", ZG_MSM_NAF="0"), dict(ZG_MSM_NAF="0"), dict(ZG_MSM_NAF_GL="0")):
         r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", here, "-k", pick], env=dict(os.environ, **knobs),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
