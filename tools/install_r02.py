@@ -42,7 +42,7 @@ def launch_name(kernel: str) -> str:
              "dot": "eval_dot", "kd_strip": "kate_division",
              "pp_flags": "permute_flags", "pp_scan": "permute_scan", "pp_leftover": "permute_leftover",
              "pp_build": "permute_build", "random_and_blind": "random_poly", "evaluate_h9": "evaluate_h",
-             "horner_combine_sets": "horner_combine", "sort_global_fused": "sort_global", "gate_factor9": "gate_factor"}
+             "horner_combine_sets": "horner_combine", "msm_digits_naf": "msm_digits", "sort_global_fused": "sort_global", "gate_factor9": "gate_factor"}
     return alias.get(k, k)
 
 
