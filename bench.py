@@ -39,9 +39,6 @@ sys.path.insert(0, os.path.join(ROOT, "harness"))
 # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); every prover stream
 # should have a queue of its own, next to torch's and RCCL's.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-# the oracle's OpenMP team (verification after the timed region, the CPU baseline) sleeps between its parallel regions
-# instead of spinning on the cores the prover threads of the later legs run on
-os.environ.setdefault("OMP_WAIT_POLICY", "passive")
 
 import numpy as np
 import torch
