@@ -659,7 +659,8 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
                                                                                    const XYZZ9* __restrict__ blk_p,
                                                                                    XYZZ9* __restrict__ blk_w,
                                                                                    uint32_t nblk, uint32_t* __restrict__ tickets,
-                                                                                   XYZZ* __restrict__ out) {
+                                                                                   XYZZ* __restrict__ out, uint32_t odd,
+                                                                                   XYZZ9* __restrict__ tsum) {
     __shared__ XYZZ9 sh[RB];
     __shared__ XYZZ9 bs;
     const uint32_t j = threadIdx.x / L, role = threadIdx.x % L;
@@ -682,6 +683,10 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
     if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(sfx + ((size_t)b * nblk + blk) * RB + j, &bs, role));
     else sh[j] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * RB + j), bs);
     __syncthreads();
+    // odd-digit buckets (free-position form): the vector's plain sum T = sum_k B_k is the global suffix sum at the first
+    // bucket, which block 0 holds here; the last workgroup turns sum_k k B_k into 2 sum_k k B_k - T
+    if (odd && blk == 0 && threadIdx.x == 0) st_xyzz9(tsum + b, sh[0]);
+    __syncthreads();
     for (uint32_t o = RB / 2; o > 0; o >>= 1) tree_step(o);
     // result = sum_blk W'_blk, by whichever workgroup of the vector finishes last (a ticket per vector; every
     // writer makes its W' visible device-wide before taking one, the last one re-reads them after its own)
@@ -698,8 +703,15 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
     __syncthreads();
     for (uint32_t o = span / 2; o > 0; o >>= 1) tree_step(o);
     if (threadIdx.x == 0) {
-        st_xyzz(out + b, xyzz9_to_xyzz(sh[0], false));  // back to the library's packed form
-        tickets[b] = 0;                                  // ready for the next launch on this stream
+        XYZZ9 R = sh[0];
+        if (odd) {
+            XYZZ9 T = ld_xyzz9(tsum + b);  // (block 0 stored it before its fence and ticket)
+            R = xyzz9_add(R, R);
+            T.y = f9_neg(T.y);
+            R = xyzz9_add(R, T);
+        }
+        st_xyzz(out + b, xyzz9_to_xyzz(R, false));  // back to the library's packed form
+        tickets[b] = 0;                              // ready for the next launch on this stream
     }
 }
 
@@ -997,7 +1009,6 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     // "W" the digit slots per scalar; the throughput form's kernels take both as they take windows
     // (a bit-position table serves any digit width: naf_width picks it per launch, 0 = the width the table was made for)
     const uint32_t naf = bases->naf_w ? (naf_width ? naf_width : bases->naf_w) : 0;
-    ZG_REQUIRE(!naf || !ctx->msm_pair, ZG_ERR_UNSUPPORTED, "zg_msm: a bit-position table serves the throughput form only");
     ZG_REQUIRE(!naf || (naf >= 3 && naf <= 16), ZG_ERR_INVALID_ARG, "zg_msm: digit width %u", naf);
     ZG_REQUIRE(!bases_b || (bases_b->naf_w != 0) == (naf != 0), ZG_ERR_INVALID_ARG, "zg_msm: the two base sets differ in their digit form");
     // (digits sit at least `naf` positions apart, the first at >= 0, the last at <= 254: at most 254 / naf + 1 of them)
@@ -1058,6 +1069,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     uint32_t* sorted = ws.get<uint32_t>((size_t)B * entries);
     XYZZ9* partial = ws.get<XYZZ9>((size_t)B * max_tasks);
     XYZZ9* blk_w = ws.get<XYZZ9>((size_t)B * nblk);
+    XYZZ9* tsum = ws.get<XYZZ9>(B);  // (odd-digit buckets: the vectors' plain bucket sums, msm_bucket_sum_kernel)
     XYZZ9* blk_p = ws.get<XYZZ9>((size_t)B * nblk);
     XYZZ9* sfx = ws.get<XYZZ9>((size_t)B * nblk * rb);
     // a hot bucket holds more than MSM_HEAVY * MSM_K entries
@@ -1139,7 +1151,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
             ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<L, RB>), dim3(nblk, B), dim3(L * RB), 0,
                       partial, toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
             ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<L, RB>), dim3(nblk, B), dim3(L * RB), 0, sfx,
-                      blk_p, blk_w, nblk, ctx->msm_tickets, d_out);
+                      blk_p, blk_w, nblk, ctx->msm_tickets, d_out, naf ? 1u : 0u, tsum);
         };
         using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>;
@@ -1153,7 +1165,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<1>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
         static const bool strips = !(getenv("ZG_MSM_STRIPS") && atoi(getenv("ZG_MSM_STRIPS")) == 0);  // A/B knob
-        if (strips || naf) {
+        if (strips) {
             // (sfx has room for nb points per vector: the strip sums and strip-local weighted sums share it)
             static const uint32_t s_env = getenv("ZG_MSM_STRIP") ? (uint32_t)atoi(getenv("ZG_MSM_STRIP")) : 0;  // A/B knob
             const uint32_t S = s_env == 2 || s_env == 4 || s_env == 8 || s_env == 16 ? s_env : MSM_STRIP;
@@ -1169,7 +1181,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
             ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
                       toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
             ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
-                      blk_w, nblk, ctx->msm_tickets, d_out);
+                      blk_w, nblk, ctx->msm_tickets, d_out, naf ? 1u : 0u, tsum);
         }
     }
     ZG_HIP(hipGetLastError());

@@ -270,7 +270,10 @@ namespace {
 // the bit-position table of a base set for the throughput form's commitments of full-size scalars (the sorted a' / s'
 // columns and the products in their run form, the random vectors), else the base set itself
 static const zg_bases* naf_of(const zg_prover* p, const zg_bases* b) {
-    return b && b->dense && b->dense->naf_w && !p->ctx->msm_pair ? b->dense : b;
+    // (a lone proof keeps the window tables: from the 0.27 GB bit-position table, which no cache holds, its few waves
+    //  wait on the gathers -- 3.27 against 3.01 ms with the same bucket count; ZG_MSM_NAF_LATENCY=1 for A/B)
+    static const bool lat = getenv("ZG_MSM_NAF_LATENCY") && atoi(getenv("ZG_MSM_NAF_LATENCY")) != 0;
+    return b && b->dense && b->dense->naf_w && (lat || !p->ctx->msm_pair) ? b->dense : b;
 }
 
 // Digit width of the free-position form for the run-form commitments against g_lagrange (the sorted a' / s' columns and
@@ -285,10 +288,14 @@ static uint32_t naf_gl_width(const zg_prover* p) {
     return w >= 3 && w <= 16 ? w : 0u;
 }
 
+// the second table of g for the all-random commitments: the bit-position table (a lone proof recodes at the width that
+// keeps its bucket count, dense_width), or the larger-window table (throughput form only, unless asked otherwise)
 static const zg_bases* dense_g(const zg_prover* p) {
     static const bool lat = getenv("ZG_MSM_DENSE_LATENCY") && atoi(getenv("ZG_MSM_DENSE_LATENCY"));
+    if (p->g->dense && p->g->dense->naf_w) return naf_of(p, p->g);
     return p->g->dense && (lat || !p->ctx->msm_pair) ? p->g->dense : p->g;
 }
+static uint32_t dense_width(const zg_prover* p) { return p->ctx->msm_pair ? naf_gl_width(p) : 0u; }
 
 // Commitments of a phase: one MSM launch sequence over `count` = groups x per scalar vectors (msm_batch4_dev), against
 // this prover's point range of the base sets; the XYZZ results go to the host behind it.
@@ -1344,7 +1351,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
         ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
     }
-    ZG_TRY(commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0));
+    ZG_TRY(commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0, dense_width(p)));
     ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
     for (uint32_t b = 0; b < nb; b++)
         for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
@@ -1499,7 +1506,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
                                   wp_bs, p->ktmp, n));
         // the witness polynomials sit at odd slots: stride 2n
-        ZG_TRY(commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0));
+        ZG_TRY(commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0, dense_width(p)));
         ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
         for (uint32_t b = 0; b < nb; b++)
             for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
