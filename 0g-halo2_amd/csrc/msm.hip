@@ -965,6 +965,9 @@ int bases_enable_runs(zg_ctx* ctx, zg_bases* b) {
 
 int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch,
                   size_t n, XYZZ* d_out) {
+    // (a base set with a bit-position table, zg_bases_enable_bit_table, is multiplied in the free-position form by a
+    //  context in its throughput form; a latency-form context keeps the window table -- DESIGN.md 4)
+    if (bases->dense && bases->dense->naf_w && !ctx->msm_pair) bases = bases->dense;
     return msm_batch2_dev(ctx, bases, nullptr, batch, d_scalars, stride, batch, n, d_out);
 }
 
@@ -1248,6 +1251,15 @@ void zg_bases_free(zg_bases* b) {
         delete b->dense;
     }
     delete b;
+}
+
+int zg_bases_enable_bit_table(zg_ctx* ctx, zg_bases* bases, uint32_t digit_width) {
+    ZG_REQUIRE(ctx && bases, ZG_ERR_INVALID_ARG, "zg_bases_enable_bit_table: null argument");
+    ZG_REQUIRE(bases->device == ctx->device, ZG_ERR_INVALID_ARG, "zg_bases_enable_bit_table: bases live on another device");
+    ZG_REQUIRE(!bases->dense || bases->dense->naf_w == digit_width, ZG_ERR_INVALID_ARG,
+               "zg_bases_enable_bit_table: the base set already has a second table of another form");
+    ZG_ENTER(ctx);
+    return bases_enable_naf(ctx, bases, digit_width);
 }
 
 size_t zg_bases_len(const zg_bases* b) { return b ? b->n : 0; }

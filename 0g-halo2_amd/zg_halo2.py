@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
     "zg_witness_plan_create", "zg_witness_plan_destroy", "zg_witness_plan_image_bytes", "zg_witness_plan_instance_len",
-    "zg_witness_run_dev", "zg_prover_prove_images", "zg_prover_set_shard_rccl", "zg_xyzz_sum_ranks_dev",
+    "zg_witness_run_dev", "zg_prover_prove_images", "zg_prover_set_shard_rccl", "zg_xyzz_sum_ranks_dev", "zg_bases_enable_bit_table",
 ]
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
@@ -249,6 +249,10 @@ class Ctx:
         _check(self.lib.zg_bases_register(self.h, _ptr(bases), c_size_t(bases.shape[0]),
                                           c_uint32(window_bits), ctypes.byref(h)))
         return Bases(self, h)
+
+    def enable_bit_table(self, bases: "Bases", digit_width: int):
+        """Bit-position table + free-position odd digits for this context's throughput-form MSMs (zg_bases_enable_bit_table)."""
+        _check(self.lib.zg_bases_enable_bit_table(self.h, bases.h, c_uint32(digit_width)))
 
     def register_bases_dev(self, d_ptr: int, n: int, window_bits: int = 0) -> "Bases":
         h = c_void_p()

@@ -102,6 +102,13 @@ int zg_bases_register(zg_ctx *ctx, const zg_g1_affine *bases, size_t n, uint32_t
 int zg_bases_register_dev(zg_ctx *ctx, const void *d_bases, size_t n, uint32_t window_bits,
                           zg_bases **out);
 void zg_bases_free(zg_bases *b);
+/* Optional second table of a base set for batches of FULL-SIZE (random) scalars: one row per bit position, 2^j * P_i for
+ * j < 255 (255 * n * 64 B -- 0.27 GB at n = 2^14), against which a scalar is recoded into odd signed digits of
+ * `digit_width` bits at free positions (width-w NAF): 254 / (w + 1) additions per scalar where c-bit windows spend
+ * 255 / c, on 2^(w-2) buckets.  Used by the zg_msm* entries of a context in its THROUGHPUT form
+ * (zg_ctx_set_msm_latency(ctx, 0)); a latency-form context keeps the window table (a lone MSM waits on the gathers from
+ * a table no cache holds).  digit_width in [3, 16]; idempotent for the same width.  Same results, bit for bit. */
+int zg_bases_enable_bit_table(zg_ctx *ctx, zg_bases *bases, uint32_t digit_width);
 size_t zg_bases_len(const zg_bases *b);
 uint32_t zg_bases_window_bits(const zg_bases *b);
 

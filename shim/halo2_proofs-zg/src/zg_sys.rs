@@ -75,6 +75,7 @@ extern "C" {
                                 gamma: *const Fr, y: *const Fr, h_out: *mut Fr) -> c_int;
     pub fn zg_prover_set_shard(p: *mut zg_prover, rank: u32, world: u32, first_point: usize, exchange: zg_exchange_fn,
                                user: *mut c_void) -> c_int;
+    pub fn zg_bases_enable_bit_table(ctx: *mut zg_ctx, bases: *mut zg_bases, digit_width: u32) -> c_int;
     pub fn zg_prover_set_shard_rccl(p: *mut zg_prover, rank: u32, world: u32, first_point: usize, nccl_comm: *mut c_void) -> c_int;
     pub fn zg_xyzz_sum_ranks_dev(ctx: *mut zg_ctx, d_parts: *const c_void, world: usize, count: usize, d_out: *mut c_void) -> c_int;
     // witness of a batch of inputs on the device (optional; the recorder is the caller's: see README.md)

@@ -131,3 +131,48 @@ def test_both_reduction_forms_match_the_oracle(ctx, zg, orc, srs, latency):
             bases.free()
     finally:
         ctx.set_msm_latency(True)
+
+
+@pytest.mark.parametrize("w", [3, 9, 13, 16])
+def test_free_position_digits_on_adversarial_scalars(zg, orc, srs, w):
+    """zg_bases_enable_bit_table: odd signed digits of w bits at free positions against the bit-position table, on a
+    throughput-form context.  The recoding walks the scalar with a 64-bit sliding register and folds a negative digit's
+    carry into it: the vectors below put runs of ones, alternating bits, single bits and the extreme values across every
+    32-bit limb boundary -- each must give the oracle's point."""
+    _, gl = srs
+    n = gl.shape[0]
+    c2 = zg.Ctx(0)
+    c2.set_msm_latency(False)
+    bases = c2.register_bases(gl)
+    c2.enable_bit_table(bases, w)
+    R = zg.FR_MODULUS
+    special = [0, 1, 2, 3, R - 1, R - 2, (R - 1) // 2, (R + 1) // 2, (1 << 253), (1 << 253) - 1, (1 << 253) + 1]
+    special += [1 << e for e in (28, 29, 30, 31, 32, 33, 47, 48, 63, 64, 65, 95, 96, 127, 128, 191, 192, 224, 250, 252)]
+    special += [(1 << e) - 1 for e in (15, 16, 17, 31, 32, 33, 63, 64, 65, 128, 200, 253)]
+    special += [int("aa" * 31, 16), int("55" * 31, 16), int("ff" * 31, 16) % R, int("0f" * 31, 16), int("f0" * 31, 16) % R]
+    special += [((1 << w) - 1) << s for s in (0, 1, 17, 31, 32, 33, 48, 64 - w, 64, 200)]
+    special += [(((1 << (w - 1)) + 1) << s) % R for s in (0, 15, 31, 32, 63, 64, 100, 230)]
+    special = [v % R for v in special]
+    rng = np.random.default_rng(w)
+    for trial in range(2):
+        s = orc.fill_fr(700 + 10 * w + trial, n)
+        pos = rng.permutation(n)[: len(special)]
+        for p_, v in zip(pos, special):
+            s[p_] = orc.fr_from_int(v)
+        assert np.array_equal(c2.msm(bases, s), orc.msm(s, gl, threads=8)), f"trial {trial}"
+    only = np.zeros((n, 4), np.uint64)  # the special values alone (no random mass to hide behind), one per point
+    for i, v in enumerate(special[:n]):
+        only[i] = orc.fr_from_int(v)
+    assert np.array_equal(c2.msm(bases, only), orc.msm(only, gl, threads=8))
+    mx = np.tile(orc.fr_from_int(R - 1), (n, 1))  # every scalar r - 1: one bucket pattern, all carries
+    assert np.array_equal(c2.msm(bases, mx), orc.msm(mx, gl, threads=8))
+    sp = orc.fill_fr_sparse(5, n)
+    assert np.array_equal(c2.msm(bases, sp), orc.msm(sp, gl, threads=8))
+    # a latency-form context on the same base set keeps the window table and gives the same point
+    c3 = zg.Ctx(0)
+    assert np.array_equal(c3.msm(bases, only), orc.msm(only, gl, threads=8))
+    c3.close()
+    with pytest.raises(zg.ZgError):
+        c2.enable_bit_table(bases, w + 1 if w < 16 else 15)  # another width: refused
+    bases.free()
+    c2.close()
