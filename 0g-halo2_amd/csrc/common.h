@@ -5,6 +5,7 @@
 #include <hip/hip_ext.h>
 
 #include <array>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -125,9 +126,11 @@ struct zg_bases {
     // the same table for the running sums Q_i = P_0 + ... + P_i (built on demand by bases_enable_runs): a scalar
     // vector with long constant runs is multiplied as sum_i (s_i - s_{i+1}) Q_i, whose coefficients vanish inside runs
     zg::Affine* run_table = nullptr;
-    // the same points under a larger window (built on demand by bases_enable_dense): for vectors of random scalars,
-    // which fill every window, fewer windows save more additions than the larger bucket set costs
-    zg_bases* dense = nullptr;
+    // the same points with one table row per BIT position (built on demand by bases_enable_naf), for vectors of
+    // full-size scalars recoded into odd digits at free positions
+    // (written once, under `mu`, before any prover that uses the set exists; readers on other contexts load it with
+    //  acquire order: bases_dense())
+    std::atomic<zg_bases*> dense{nullptr};
     // > 0: this table holds 2^j * P_i for EVERY bit position j (c = 1, 255 rows) and is multiplied with odd signed
     // digits of naf_w bits at free positions (msm.hip msm_digits_naf_kernel); only a `dense` table is built that way
     uint32_t naf_w = 0;
@@ -135,6 +138,8 @@ struct zg_bases {
 };
 
 namespace zg {
+
+inline zg_bases* bases_dense(const zg_bases* b) { return b ? b->dense.load(std::memory_order_acquire) : nullptr; }
 
 void* ws_alloc(zg_ctx* ctx, size_t bytes);  // nullptr on failure (error set)
 void ws_release(zg_ctx* ctx, void* p);
@@ -180,5 +185,36 @@ int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out);
 
 // host-side constants
 Fe host_domain_omega(uint32_t log_n);
+
+// Tuning knobs (include/zg_halo2.h, "tuning").  Each starts from its ZG_* environment variable, read once, and can be
+// changed at run time with zg_tuning_set -- tests walk all of them in ONE process.  knob() < 0 = the library's default.
+// Knobs that shape resident data (window size, tables, the forms of a proving key) are read when that object is built;
+// launch shapes (task sizes, reduction blocks) at every launch.
+enum Knob : int {
+    K_MSM_C,          // window bits of a base set registered with window_bits = 0
+    K_MSM_K,          // points per accumulate task, throughput form (4..120)
+    K_MSM_K_LAT,      // ... latency form
+    K_MSM_RB,         // buckets per reduction block, latency form (64 / 128 / 256)
+    K_MSM_LANES,      // lanes per EC addition in the latency reduction (2 / 4)
+    K_MSM_STRIP,      // buckets per lane in the throughput reduction (2 / 4 / 8 / 16)
+    K_MSM_NAF,        // digit width of the free-position form for the all-random commitments; 0 = window tables only
+    K_MSM_NAF_GL,     // ... for the run-form commitments against g_lagrange; 0 = windows
+    K_MSM_RUNS,       // 0 = no run form (summation by parts) for the sorted columns and the products
+    K_EVALH_GROUPED,  // 0 = evaluate_h folds in y term by term
+    K_EVALH9,         // 0 = evaluate_h on 8 x 32-bit limbs (implies the single extended coset)
+    K_SPLIT_DOMAIN,   // 0 = EvaluationDomain's single extended coset in the throughput form too
+    K_COUNT
+};
+int knob(Knob k);
+
+// prover.hip: what a witness program has to match before it may write into a prover's advice slots (witness.hip)
+struct ProverShape {
+    zg_ctx* ctx;
+    int device;
+    uint32_t k, n_advice, n_instance, usable_rows;
+    bool in_flight;  // a batch left through an error return: work may still be queued on the prover's streams
+};
+ProverShape prover_shape(const zg_prover* p);
+int prover_drain(zg_prover* p);  // waits for everything queued on the prover's streams
 
 }  // namespace zg

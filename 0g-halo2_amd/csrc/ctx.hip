@@ -1,4 +1,6 @@
 // Context, workspace pool and error plumbing of libzg_halo2.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace zg {
@@ -12,6 +14,29 @@ void set_error(const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_last_error = buf;
+}
+
+// ---- tuning knobs
+static const char* const kKnobNames[K_COUNT] = {"ZG_MSM_C", "ZG_MSM_K", "ZG_MSM_K_LAT", "ZG_MSM_RB", "ZG_MSM_LANES", "ZG_MSM_STRIP",
+                                                "ZG_MSM_NAF", "ZG_MSM_NAF_GL", "ZG_MSM_RUNS", "ZG_EVALH_GROUPED", "ZG_EVALH9",
+                                                "ZG_SPLIT_DOMAIN"};
+static std::atomic<int> g_knobs[K_COUNT];
+static std::once_flag g_knobs_once;
+static void knobs_init() {
+    for (int i = 0; i < K_COUNT; i++) {
+        const char* e = getenv(kKnobNames[i]);  // the ONLY getenv of the library
+        g_knobs[i].store(e && *e ? atoi(e) : -1, std::memory_order_relaxed);
+    }
+}
+int knob(Knob k) {
+    std::call_once(g_knobs_once, knobs_init);
+    return g_knobs[k].load(std::memory_order_relaxed);
+}
+static int knob_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < K_COUNT; i++)
+        if (strcmp(name, kKnobNames[i]) == 0) return i;
+    return -1;
 }
 
 void* ws_alloc(zg_ctx* ctx, size_t bytes) {
@@ -101,7 +126,25 @@ extern "C" {
 
 const char* zg_last_error(void) { return g_last_error.c_str(); }
 
-const char* zg_version(void) { return "zg_halo2 0.1 (gfx950)"; }
+const char* zg_version(void) { return "zg_halo2 0.3 (gfx950)"; }
+
+int zg_tuning_set(const char* name, int value) {
+    const int i = knob_index(name);
+    ZG_REQUIRE(i >= 0, ZG_ERR_INVALID_ARG, "zg_tuning_set: unknown knob %s", name ? name : "(null)");
+    (void)knob((Knob)i);  // (the environment is read first, so that it cannot overwrite this value later)
+    g_knobs[i].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    return ZG_OK;
+}
+int zg_tuning_get(const char* name, int* value) {
+    const int i = knob_index(name);
+    ZG_REQUIRE(i >= 0 && value, ZG_ERR_INVALID_ARG, "zg_tuning_get: unknown knob %s", name ? name : "(null)");
+    *value = knob((Knob)i);
+    return ZG_OK;
+}
+size_t zg_tuning_names(const char** out, size_t cap) {
+    for (size_t i = 0; i < (size_t)K_COUNT && i < cap && out; i++) out[i] = kKnobNames[i];
+    return (size_t)K_COUNT;
+}
 
 int zg_ctx_create(int device_id, zg_ctx** out) {
     ZG_REQUIRE(out != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_create: out is null");

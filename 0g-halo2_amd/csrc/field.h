@@ -25,6 +25,7 @@ struct FrParams {
                                    0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
         return P[i];
     }
+    static constexpr uint32_t P_TOP = 0x30644e72u;  // = p(7): the modulus is below 2^254 (msm.hip relies on it)
     static constexpr uint32_t INV = 0xefffffffu;  // -p^-1 mod 2^32
     static constexpr bool IS_FR = true;
     static ZG_HD Fe one() {  // R mod p

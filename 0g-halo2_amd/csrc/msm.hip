@@ -199,6 +199,10 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ 
 // of 19 at the same 8192 buckets (only odd values occur: bucket k holds digit 2k - 1, and the reduction's
 // sum_k k B_k becomes 2 sum_k k B_k - sum_k B_k).  Entry = bucket | row << 16 | sign << 31 in slot order; the later
 // kernels treat slots as they treat windows.
+// A reduced scalar is below r < 2^254: its digits sit at bit positions <= 254 (a carry out of bit 253 lands there), which
+// is what sizes the 255-row bit table and the 254 / w + 1 digit slots.  A modulus of 2^254 or more would read table row
+// 255 and drop digits.
+static_assert((FrParams::P_TOP >> 30) == 0, "msm_digits_naf_kernel: the scalar field's modulus must be below 2^254");
 __global__ __launch_bounds__(256) void msm_digits_naf_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t per,
                                                              size_t outer, uint32_t n, uint32_t w, uint32_t slots,
                                                              uint32_t* __restrict__ dig, uint64_t run_mask) {
@@ -256,7 +260,10 @@ __global__ __launch_bounds__(256) void msm_digits_naf_kernel(const Fe* __restric
         const uint32_t v = (uint32_t)bits & mask;  // odd
         const bool neg = v > half;
         const uint32_t d = neg ? (mask + 1u) - v : v;
-        if (slot < slots) db[(size_t)slot * n] = ((d + 1u) >> 1) | (pos << 16) | ((neg ? 0x80000000u : 0u) ^ flip);
+        // (slot < slots and pos <= 254 always: Fr::to_raw returns a value below r for ANY 256-bit input -- the Montgomery
+        //  reduction of x < 2^256 is below r + 1 before its final subtraction -- and r < 2^254 by the static_assert
+        //  above; the guard only keeps a violated assumption from writing outside the digit array)
+        if (slot < slots && pos <= 254u) db[(size_t)slot * n] = ((d + 1u) >> 1) | (pos << 16) | ((neg ? 0x80000000u : 0u) ^ flip);
         slot++;
         bits = (bits >> w) + (neg ? 1ull : 0ull);
         have = have >= w ? have - w : 0;
@@ -540,10 +547,10 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
 constexpr uint32_t MSM_RB = 256;     // buckets per reduce block
 constexpr uint32_t MSM_MAX_BATCH = 4096;  // vectors per batched MSM call
 
-// All four reduction kernels are templated on L, the lanes per addition: 1 (throughput: least work), or 2 / 4
-// (field9.h `xadd<true>`, `xadd4`: seven / four dependent products per lane instead of fourteen; the
-// prover's latency configuration and the stand-alone MSM entry points use them).  j = logical lane,
-// role = lane within the group.
+// The latency form's reduction kernels are templated on L, the lanes per addition: 2 / 4 (field9.h `xadd<true>`,
+// `xadd4`: seven / four dependent products per lane instead of fourteen; the prover's latency configuration and the
+// stand-alone MSM entry points use them); the hot-bucket merge also runs with one (throughput form: least work).
+// j = logical lane, role = lane within the group.
 
 // One workgroup per hot bucket: lanes take a strided share of its task partials, tree through LDS.
 template <int L>
@@ -603,47 +610,25 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_scan_kernel(
     const uint32_t k = blk * RB + j + 1;
     const uint32_t* to = toff + (size_t)b * (nb + 2);
     const XYZZ9* pp = partial + (size_t)b * max_tasks;
-    if constexpr (L > 1) {
-        if (role == 0) sh[j] = xyzz9_identity();
-        if (k <= nb) {
-            const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
-            if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
-                if (role == 0) sh[j] = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
-            } else {
-                const uint32_t t0 = to[k], t1 = to[k + 1];
-                for (uint32_t t = t0; t < t1; t++) xstore<true>(&sh[j], xaddl<L>(&sh[j], pp + t, role));
-            }
+    static_assert(L == 2 || L == 4, "the latency reduction spends two or four lanes per addition");
+    if (role == 0) sh[j] = xyzz9_identity();
+    if (k <= nb) {
+        const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
+        if (hs < max_heavy) {  // (hs >= max_heavy cannot happen: a hot bucket holds > MSM_HEAVY*MSM_K entries)
+            if (role == 0) sh[j] = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
+        } else {
+            const uint32_t t0 = to[k], t1 = to[k + 1];
+            for (uint32_t t = t0; t < t1; t++) xstore<true>(&sh[j], xaddl<L>(&sh[j], pp + t, role));
         }
+    }
+    __syncthreads();
+    for (uint32_t o = 1; o < RB; o <<= 1) {
+        const bool has = j + o < RB;
+        XSum s;
+        if (has) s = xaddl<L>(&sh[j], &sh[j + o], role);
         __syncthreads();
-        for (uint32_t o = 1; o < RB; o <<= 1) {
-            const bool has = j + o < RB;
-            XSum s;
-            if (has) s = xaddl<L>(&sh[j], &sh[j + o], role);
-            __syncthreads();
-            if (has) xstore<true>(&sh[j], s);
-            __syncthreads();
-        }
-    } else {
-        XYZZ9 acc = xyzz9_identity();
-        if (k <= nb) {
-            const uint32_t hs = hmap[(size_t)b * (nb + 1) + k];
-            if (hs < max_heavy) {
-                acc = ld_xyzz9(hsum + (size_t)b * max_heavy + hs);
-            } else {
-                const uint32_t t0 = to[k], t1 = to[k + 1];
-                for (uint32_t t = t0; t < t1; t++) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
-            }
-        }
-        sh[j] = acc;
+        if (has) xstore<true>(&sh[j], s);
         __syncthreads();
-        for (uint32_t o = 1; o < RB; o <<= 1) {
-            XYZZ9 v = xyzz9_identity();
-            const bool has = j + o < RB;
-            if (has) v = sh[j + o];
-            __syncthreads();
-            if (has) sh[j] = xyzz9_add(sh[j], v);
-            __syncthreads();
-        }
     }
     if (role == 0) {
         st_xyzz9(sfx + ((size_t)b * nblk + blk) * RB + j, sh[j]);
@@ -671,17 +656,13 @@ __global__ __launch_bounds__(L * RB) void msm_bucket_sum_kernel(const XYZZ9* __r
     uint32_t span = 1;
     while (span < nblk) span <<= 1;
     auto tree_step = [&](uint32_t o) {
-        if (j < o) {
-            if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(&sh[j], &sh[j + o], role));
-            else sh[j] = xyzz9_add(sh[j], sh[j + o]);
-        }
+        if (j < o) xstore<true>(&sh[j], xaddl<L>(&sh[j], &sh[j + o], role));
         __syncthreads();
     };
     for (uint32_t o = span / 2; o > 0; o >>= 1) tree_step(o);
     if (threadIdx.x == 0) bs = sh[0];
     __syncthreads();
-    if constexpr (L > 1) xstore<true>(&sh[j], xaddl<L>(sfx + ((size_t)b * nblk + blk) * RB + j, &bs, role));
-    else sh[j] = xyzz9_add(ld_xyzz9(sfx + ((size_t)b * nblk + blk) * RB + j), bs);
+    xstore<true>(&sh[j], xaddl<L>(sfx + ((size_t)b * nblk + blk) * RB + j, &bs, role));
     __syncthreads();
     // odd-digit buckets (free-position form): the vector's plain sum T = sum_k B_k is the global suffix sum at the first
     // bucket, which block 0 holds here; the last workgroup turns sum_k k B_k into 2 sum_k k B_k - T
@@ -815,10 +796,7 @@ __global__ __launch_bounds__(MSM_STRIP_LANES) void msm_strip_sum_kernel(const XY
 }
 
 static uint32_t default_window_bits(size_t n) {
-    if (const char* e = getenv("ZG_MSM_C")) {  // tuning override
-        int v = atoi(e);
-        if (v >= 2 && v <= (int)MSM_MAX_C) return (uint32_t)v;
-    }
+    if (const int v = knob(K_MSM_C); v >= 2 && v <= (int)MSM_MAX_C) return (uint32_t)v;  // tuning override
     uint32_t lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) lg++;
     // measured inside the full proof (tools/sweep_c.sh): k=14 -> 12, k=15 -> 13, k=17 -> 15.  (One less and
@@ -873,28 +851,17 @@ __global__ void msm_untable_kernel(const Affine* __restrict__ table, Affine* __r
 }
 
 // The same points with one table row per bit position (c = 1: 255 rows, 255 * n * 64 B -- 0.27 GB at k = 14, 2.1 GB at
-// k = 17, what 288 GB of HBM are for) for free-position odd digits of `w` bits (idempotent; excludes bases_enable_dense).
-int bases_enable_naf(zg_ctx* ctx, zg_bases* b, uint32_t w) {
-    std::lock_guard<std::mutex> lock(b->mu);
-    if (b->dense) return ZG_OK;
+// k = 17, what 288 GB of HBM are for) for free-position odd digits of `w` bits (idempotent).
+int bases_enable_naf(zg_ctx* ctx, zg_bases* b, uint32_t w, bool strict) {
     ZG_REQUIRE(w >= 3 && w <= 16, ZG_ERR_INVALID_ARG, "bases_enable_naf: digit width %u not in [3,16]", w);
-    WsScope ws(ctx);
-    Affine* d = ws.get<Affine>(b->n);
-    if (!d) return ZG_ERR_OOM;
-    const Fe un = Fq::inv(Fq9Params::c261_fe());
-    hipLaunchKernelGGL(msm_untable_kernel, dim3((uint32_t)((b->n + 255) / 256)), dim3(256), 0, ctx->stream, b->table, d,
-                       (uint32_t)b->n, un);
-    ZG_HIP(hipGetLastError());
-    ZG_TRY(bases_register_dev(ctx, d, b->n, 1, &b->dense));
-    b->dense->naf_w = w;
-    return ZG_OK;
-}
-
-// A second window table of the same points with `window_bits` bits per window (idempotent; the first call decides
-// the window).  msm_batch*_dev never picks it by itself: the prover names `b->dense` for its all-random phases.
-int bases_enable_dense(zg_ctx* ctx, zg_bases* b, uint32_t window_bits) {
     std::lock_guard<std::mutex> lock(b->mu);
-    if (b->dense || window_bits == b->c) return ZG_OK;
+    if (zg_bases* have = b->dense.load(std::memory_order_acquire)) {
+        // (the table serves any digit width -- msm_batch4_dev takes one per launch; naf_w is only its default: the
+        //  first call decides it, and the public entry refuses to pretend otherwise)
+        ZG_REQUIRE(!strict || have->naf_w == w, ZG_ERR_INVALID_ARG,
+                   "zg_bases_enable_bit_table: the base set already has its bit-position table, made for width %u", have->naf_w);
+        return ZG_OK;
+    }
     WsScope ws(ctx);
     Affine* d = ws.get<Affine>(b->n);
     if (!d) return ZG_ERR_OOM;
@@ -902,7 +869,11 @@ int bases_enable_dense(zg_ctx* ctx, zg_bases* b, uint32_t window_bits) {
     hipLaunchKernelGGL(msm_untable_kernel, dim3((uint32_t)((b->n + 255) / 256)), dim3(256), 0, ctx->stream, b->table, d,
                        (uint32_t)b->n, un);
     ZG_HIP(hipGetLastError());
-    return bases_register_dev(ctx, d, b->n, window_bits, &b->dense);
+    zg_bases* made = nullptr;
+    ZG_TRY(bases_register_dev(ctx, d, b->n, 1, &made));
+    made->naf_w = w;
+    b->dense.store(made, std::memory_order_release);  // (published complete: the table kernel has been waited for)
+    return ZG_OK;
 }
 
 // Running sums Q_i = P_0 + ... + P_i of the registered points and their window table (once per base set; the
@@ -967,7 +938,7 @@ int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_
                   size_t n, XYZZ* d_out) {
     // (a base set with a bit-position table, zg_bases_enable_bit_table, is multiplied in the free-position form by a
     //  context in its throughput form; a latency-form context keeps the window table -- DESIGN.md 4)
-    if (bases->dense && bases->dense->naf_w && !ctx->msm_pair) bases = bases->dense;
+    if (const zg_bases* d = bases_dense(bases); d && d->naf_w && !ctx->msm_pair) bases = d;
     return msm_batch2_dev(ctx, bases, nullptr, batch, d_scalars, stride, batch, n, d_out);
 }
 
@@ -1023,11 +994,11 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         return ZG_OK;
     }
-    static const uint32_t k_env = getenv("ZG_MSM_K") ? (uint32_t)atoi(getenv("ZG_MSM_K")) : 0;  // A/B knob
-    // (A/B knob; a lone k = 14 proof with 12 / 16 / 24 / 32 / 48 points per task: 3.38 / 3.01 / 3.15 / 3.21 / 3.42 ms)
-    static const uint32_t kl_env = getenv("ZG_MSM_K_LAT") ? (uint32_t)atoi(getenv("ZG_MSM_K_LAT")) : 0;
-    const uint32_t MSM_K = ctx->msm_pair ? (kl_env >= 4 && kl_env <= 120 ? kl_env : MSM_K_LATENCY)
-                                         : (k_env >= 4 && k_env <= 120 ? k_env : MSM_K_THROUGHPUT);
+    const int k_env = knob(K_MSM_K);
+    // (a lone k = 14 proof with 12 / 16 / 24 / 32 / 48 points per task: 3.38 / 3.01 / 3.15 / 3.21 / 3.42 ms)
+    const int kl_env = knob(K_MSM_K_LAT);
+    const uint32_t MSM_K = ctx->msm_pair ? (kl_env >= 4 && kl_env <= 120 ? (uint32_t)kl_env : MSM_K_LATENCY)
+                                         : (k_env >= 4 && k_env <= 120 ? (uint32_t)k_env : MSM_K_THROUGHPUT);
     const uint64_t entries = (uint64_t)N * W;
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
     uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
@@ -1040,8 +1011,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     if (ctx->msm_pair) {
         // tuning overrides (tools/sweep_rb.sh, tools/sweep_lanes.sh); by default 64-bucket blocks with four
         // lanes per addition when the block totals fit (c <= 13), else 128-bucket blocks with two
-        static const int rb_env = getenv("ZG_MSM_RB") ? atoi(getenv("ZG_MSM_RB")) : 0;
-        static const int lanes_env = getenv("ZG_MSM_LANES") ? atoi(getenv("ZG_MSM_LANES")) : 0;
+        const int rb_env = knob(K_MSM_RB), lanes_env = knob(K_MSM_LANES);
         // (64-bucket blocks only while each gets a CU to itself: tools/chain_probe.hip, 3.9 us per dependent addition
         //  against 6.3 us once two workgroups share a CU and 4.3 us for two lanes on 128-bucket blocks)
         const uint32_t nblk64 = (nb + 63) / 64;
@@ -1103,7 +1073,6 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         if (tbits > 10) tbits = 10;  // (c = 12, W = 22 leaves 9 spare bits: the top window then spreads over ~1500 buckets;
                                      // capped at 6 it spread over ~200, each just past the hot-bucket threshold)
     }
-    if (const char* e = getenv("ZG_MSM_BALANCE")) tbits = atoi(e) ? tbits : 0;
     if (naf)
         ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_naf_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
                   (uint32_t)per, outer, N, naf, W, dig, run_mask);
@@ -1114,23 +1083,6 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               slot);
     ZG_LAUNCH(ctx, "msm_scan", msm_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
               ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket);
-    if (getenv("ZG_MSM_DEBUG")) {  // tuning aid: hot buckets and tasks per vector
-        std::vector<uint32_t> hn(B), tt(B);
-        ZG_HIP(hipStreamSynchronize(ctx->stream));
-        ZG_HIP(hipMemcpy(hn.data(), nheavy, B * 4, hipMemcpyDeviceToHost));
-        ZG_HIP(hipMemcpy(tt.data(), ttotal, B * 4, hipMemcpyDeviceToHost));
-        for (uint32_t b = 0; b < B; b++) {
-            fprintf(stderr, "zg_msm: vector %u of %u: n=%u c=%u windows=%u tasks=%u hot buckets=%u", b, B, N, c, W, tt[b], hn[b]);
-            for (uint32_t h = 0; h < hn[b] && h < 4 && h < max_heavy; h++) {
-                uint32_t k = 0, t0 = 0, t1 = 0;
-                ZG_HIP(hipMemcpy(&k, hlist + (size_t)b * max_heavy + h, 4, hipMemcpyDeviceToHost));
-                ZG_HIP(hipMemcpy(&t0, toff + (size_t)b * (nb + 2) + k, 4, hipMemcpyDeviceToHost));
-                ZG_HIP(hipMemcpy(&t1, toff + (size_t)b * (nb + 2) + k + 1, 4, hipMemcpyDeviceToHost));
-                fprintf(stderr, "  [bucket %u: %u tasks]", k, t1 - t0);
-            }
-            fprintf(stderr, "\n");
-        }
-    }
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted, naf);
     if (ctx->msm_pair) {
@@ -1167,25 +1119,17 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     } else {
         ZG_LAUNCH(ctx, "msm_heavy", msm_bytes, msm_heavy_kernel<1>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum);
-        static const bool strips = !(getenv("ZG_MSM_STRIPS") && atoi(getenv("ZG_MSM_STRIPS")) == 0);  // A/B knob
-        if (strips) {
-            // (sfx has room for nb points per vector: the strip sums and strip-local weighted sums share it)
-            static const uint32_t s_env = getenv("ZG_MSM_STRIP") ? (uint32_t)atoi(getenv("ZG_MSM_STRIP")) : 0;  // A/B knob
-            const uint32_t S = s_env == 2 || s_env == 4 || s_env == 8 || s_env == 16 ? s_env : MSM_STRIP;
-            const uint32_t nstrips = (nb + S - 1) / S;
-            uint32_t per = 1;
-            while (per * MSM_STRIP_LANES < nstrips) per <<= 1;
-            XYZZ9 *strip_u = sfx, *strip_loc = sfx + (size_t)B * nstrips;
-            ZG_LAUNCH(ctx, "msm_strip", msm_bytes, msm_strip_kernel, dim3((nstrips + 255) / 256, B), dim3(256), 0, partial,
-                      toff, hmap, hsum, max_tasks, max_heavy, c, nstrips, strip_u, strip_loc, S);
-            ZG_LAUNCH(ctx, "msm_strip_sum", msm_bytes, msm_strip_sum_kernel, dim3(B), dim3(MSM_STRIP_LANES), 0, strip_u, strip_loc,
-                      nstrips, per, d_out, S, naf ? 1u : 0u);
-        } else {
-            ZG_LAUNCH(ctx, "msm_bucket_scan", msm_bytes, (msm_bucket_scan_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, partial,
-                      toff, hmap, hsum, max_tasks, max_heavy, c, sfx, blk_p, nblk);
-            ZG_LAUNCH(ctx, "msm_bucket_sum", msm_bytes, (msm_bucket_sum_kernel<1, MSM_RB>), dim3(nblk, B), dim3(MSM_RB), 0, sfx, blk_p,
-                      blk_w, nblk, ctx->msm_tickets, d_out, naf ? 1u : 0u, tsum);
-        }
+        // (sfx has room for nb points per vector: the strip sums and strip-local weighted sums share it)
+        const int s_env = knob(K_MSM_STRIP);
+        const uint32_t S = s_env == 2 || s_env == 4 || s_env == 8 || s_env == 16 ? (uint32_t)s_env : MSM_STRIP;
+        const uint32_t nstrips = (nb + S - 1) / S;
+        uint32_t per = 1;
+        while (per * MSM_STRIP_LANES < nstrips) per <<= 1;
+        XYZZ9 *strip_u = sfx, *strip_loc = sfx + (size_t)B * nstrips;
+        ZG_LAUNCH(ctx, "msm_strip", msm_bytes, msm_strip_kernel, dim3((nstrips + 255) / 256, B), dim3(256), 0, partial,
+                  toff, hmap, hsum, max_tasks, max_heavy, c, nstrips, strip_u, strip_loc, S);
+        ZG_LAUNCH(ctx, "msm_strip_sum", msm_bytes, msm_strip_sum_kernel, dim3(B), dim3(MSM_STRIP_LANES), 0, strip_u, strip_loc,
+                  nstrips, per, d_out, S, naf ? 1u : 0u);
     }
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -1246,9 +1190,10 @@ void zg_bases_free(zg_bases* b) {
     (void)hipDeviceSynchronize();  // any context of the device may have been reading the tables
     (void)hipFree(b->table);
     if (b->run_table) (void)hipFree(b->run_table);
-    if (b->dense) {
-        (void)hipFree(b->dense->table);
-        delete b->dense;
+    if (zg_bases* d = b->dense.load()) {
+        (void)hipFree(d->table);
+        if (d->run_table) (void)hipFree(d->run_table);
+        delete d;
     }
     delete b;
 }
@@ -1256,10 +1201,8 @@ void zg_bases_free(zg_bases* b) {
 int zg_bases_enable_bit_table(zg_ctx* ctx, zg_bases* bases, uint32_t digit_width) {
     ZG_REQUIRE(ctx && bases, ZG_ERR_INVALID_ARG, "zg_bases_enable_bit_table: null argument");
     ZG_REQUIRE(bases->device == ctx->device, ZG_ERR_INVALID_ARG, "zg_bases_enable_bit_table: bases live on another device");
-    ZG_REQUIRE(!bases->dense || bases->dense->naf_w == digit_width, ZG_ERR_INVALID_ARG,
-               "zg_bases_enable_bit_table: the base set already has a second table of another form");
     ZG_ENTER(ctx);
-    return bases_enable_naf(ctx, bases, digit_width);
+    return bases_enable_naf(ctx, bases, digit_width, true);  // (takes the set's own lock; refuses another width)
 }
 
 size_t zg_bases_len(const zg_bases* b) { return b ? b->n : 0; }

@@ -16,20 +16,10 @@
 //   store so a polynomial crosses HBM exactly twice per transform.
 // The kernel is integer-ALU bound (one 254-bit Montgomery product per butterfly), not MFMA work.
 //
-// Two arithmetic back ends share this structure.  The default one keeps packed canonical elements in
-// LDS and multiplies on 8 x 32-bit limbs.  The nine-limb one (field9.h; opt-in with ZG_NTT9=1, for
-// transforms whose passes have at most 9 butterfly stages) keeps 36-byte lazily reduced elements in LDS: the sum output of a butterfly
-// is a carry-normalised limb-wise add, the difference a plain limb-wise subtract that goes straight
-// into the product, and because the twiddles are stored as w * 2^261 the product w * d needs no
-// domain conversion of the data (d stays in the library's x * 2^256 form).  Magnitudes grow by one bit
-// per stage on the sum path (a product resets them to ~p), 2^253.6 * 2^9 < 2^263 fits the top limb, and
-// the store reduces to the canonical packed form.  It is bit-exact and issues 18 % fewer instructions per
-// butterfly (385 vs 470).  With nine 4-byte LDS accesses per element it measured slower than the packed
-// back end (1.75 vs 1.65 ms/proof); with limbs 0..7 as two 16-byte LDS words plus a 4-byte one it is on
-// par (1.56 vs 1.56) -- the transform is bound by its LDS round trips and barriers before its VALU work,
-// so the default stays with the packed back end.
-#include <cstdlib>
-
+// A nine-limb back end (field9.h; 36-byte lazily reduced elements in LDS, 18 % fewer instructions per butterfly) was
+// built, bit-exact, and measured on par at best (1.56 vs 1.56 ms/proof; 1.75 vs 1.65 with 4-byte LDS accesses): the
+// transform is bound by its LDS round trips and barriers before its VALU work.  It was removed in round 3 with its
+// ZG_NTT9 switch (git history has it); the twiddle tables keep their second half, omega^i * 2^5, which evaluate_h reads.
 #include "poly.h"
 #include "field9.h"
 
@@ -295,148 +285,6 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
     }
 }
 
-// ---- the nine-limb pass: same tiling, indices and fused first-load / last-store work as ntt_pass_kernel
-__device__ __forceinline__ F9 lds_ld9(const F9* p) { return *p; }
-
-template <int LOG_T, bool COLS, bool FIRST>
-__global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) {
-    constexpr uint32_t T = 1u << LOG_T;
-    constexpr uint32_t NT = T / 4;
-    // 2048 nine-limb elements are 72 KB: with the sub-transform twiddles beside them only one workgroup
-    // would fit a CU, so the large tile reads its twiddles from the (L2-resident) HBM table instead
-    constexpr bool TWL = LOG_T <= 10;
-    extern __shared__ __align__(16) unsigned char smem[];
-    // LDS layout: limbs 0..3 and 4..7 of an element as two 16-byte words in two arrays, limb 8 in a third
-    // (three LDS accesses per element instead of nine 4-byte ones), slots XOR-folded as in ntt_pass_kernel
-    uint4* XL = reinterpret_cast<uint4*>(smem);
-    uint4* XH = XL + T;
-    int32_t* X8 = reinterpret_cast<int32_t*>(XH + T);
-    F9* TW = reinterpret_cast<F9*>(X8 + T);
-    auto slot = [](uint32_t i) { return i ^ ((i >> 3) & 7u) ^ ((i >> 6) & 7u) ^ ((i >> 9) & 7u); };
-    auto ldx = [&](uint32_t i) {
-        const uint32_t s = slot(i);
-        const uint4 lo = XL[s], hi = XH[s];
-        F9 r;
-        r.l[0] = (int32_t)lo.x; r.l[1] = (int32_t)lo.y; r.l[2] = (int32_t)lo.z; r.l[3] = (int32_t)lo.w;
-        r.l[4] = (int32_t)hi.x; r.l[5] = (int32_t)hi.y; r.l[6] = (int32_t)hi.z; r.l[7] = (int32_t)hi.w;
-        r.l[8] = X8[s];
-        return r;
-    };
-    auto stx = [&](uint32_t i, const F9& v) {
-        const uint32_t s = slot(i);
-        XL[s] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
-        XH[s] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
-        X8[s] = v.l[8];
-    };
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t log_m = COLS ? a.log_n1 : a.log_n2;
-    const uint32_t M = 1u << log_m;
-    const uint32_t N1 = 1u << a.log_n1, N2 = 1u << a.log_n2;
-    uint32_t log_cnt = LOG_T - log_m;
-    if (!COLS && log_cnt > a.log_n1) log_cnt = a.log_n1;
-    const uint32_t cnt = 1u << log_cnt;
-    const uint32_t tile = M << log_cnt;
-
-    uint32_t nblk = gridDim.x, bid = blockIdx.x;
-    if ((nblk & 7u) == 0) bid = (bid & 7u) * (nblk >> 3) + (bid >> 3);
-    const uint32_t base = bid << log_cnt;
-
-    const Fe* in = a.in + (size_t)(blockIdx.y / a.in_per) * a.in_outer + (size_t)(blockIdx.y % a.in_per) * a.in_stride;
-    Fe* out = a.out + (size_t)(blockIdx.y / a.out_per) * a.out_outer + (size_t)(blockIdx.y % a.out_per) * a.out_stride;
-    const Fe* tw9 = a.tw + ((size_t)1 << a.log_n);  // omega^i * 2^5
-
-    const uint32_t tw_shift = a.log_n - log_m;
-    if (TWL)
-        for (uint32_t t = tid; t < M / 2; t += NT) TW[t] = f9_unpack(ld_fe(tw9 + ((size_t)t << tw_shift)));
-
-    for (uint32_t e = tid; e < tile; e += NT) {
-        uint32_t g;
-        if (COLS) {
-            uint32_t c = e & (cnt - 1), j1 = e >> log_cnt;
-            g = j1 * N2 + base + c;
-        } else {
-            uint32_t j2 = e & (M - 1), r = e >> log_m;
-            g = (base + r) * N2 + j2;
-        }
-        F9 v;
-        if (FIRST) {
-            if (g < a.in_len) {
-                v = f9_unpack(ld_fe(in + g));
-                if (a.coset_in) {  // (zin are in the 2^261 form: the product stays below 1.01 p)
-                    uint32_t m3 = g % 3u;
-                    if (m3 == 1) v = Fr9::mul(v, f9_unpack(a.zin1));
-                    else if (m3 == 2) v = Fr9::mul(v, f9_unpack(a.zin2));
-                    else if (a.coset_in == 2) v = Fr9::mul(v, f9_unpack(a.zin0));
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 9; i++) v.l[i] = 0;
-            }
-        } else {
-            v = f9_unpack(ld_fe(in + g));
-        }
-        stx(e, v);
-    }
-    __syncthreads();
-
-    const uint32_t nbf = tile / 2;
-    for (uint32_t st = 0; st < log_m; st++) {
-        const uint32_t log_half = log_m - st - 1;
-        const uint32_t half = 1u << log_half;
-        for (uint32_t bf = tid; bf < nbf; bf += NT) {
-            uint32_t s, b;
-            if (COLS) {
-                s = bf & (cnt - 1);
-                b = bf >> log_cnt;
-            } else {
-                b = bf & (M / 2 - 1);
-                s = bf >> (log_m - 1);
-            }
-            uint32_t blk = b >> log_half, i = b & (half - 1);
-            uint32_t lo = (blk << (log_half + 1)) + i, hi = lo + half;
-            uint32_t ilo = COLS ? (lo << log_cnt) + s : (s << log_m) + lo;
-            uint32_t ihi = COLS ? (hi << log_cnt) + s : (s << log_m) + hi;
-            const F9 u = ldx(ilo), v = ldx(ihi);
-            stx(ilo, f9_norm(f9_add(u, v)));
-            const F9 d = f9_sub(u, v);
-            const uint32_t twi = i << st;
-            if (twi != 0)
-                stx(ihi, Fr9::mul(d, TWL ? TW[twi] : f9_unpack(ld_fe(tw9 + ((size_t)twi << tw_shift)))));
-            else
-                stx(ihi, f9_norm(d));
-        }
-        __syncthreads();
-    }
-
-    if (COLS) {
-        for (uint32_t e = tid; e < tile; e += NT) {
-            uint32_t c = e & (cnt - 1), pos = e >> log_cnt;
-            uint32_t k1 = bitrev(pos, log_m);
-            uint32_t j2 = base + c;
-            F9 v = ldx(e);
-            uint32_t ti = j2 * k1;  // < N
-            if (ti != 0) v = Fr9::mul(v, f9_unpack(ld_fe(tw9 + ti)));
-            st_fe(out + (size_t)k1 * N2 + j2, f9_reduce_pack<Fr9Params>(v));
-        }
-    } else {
-        for (uint32_t e = tid; e < tile; e += NT) {
-            uint32_t r = e & (cnt - 1), k2 = e >> log_cnt;
-            uint32_t pos = bitrev(k2, log_m);
-            uint32_t k = (base + r) + N1 * k2;
-            if (k >= a.out_len) continue;
-            F9 v = ldx((r << log_m) + pos);
-            if (a.scale_out) v = Fr9::mul(v, f9_unpack(a.scale));
-            if (a.coset_out) {
-                uint32_t m3 = k % 3u;
-                if (m3 == 1) v = Fr9::mul(v, f9_unpack(a.zout1));
-                else if (m3 == 2) v = Fr9::mul(v, f9_unpack(a.zout2));
-            }
-            st_fe(out + k, f9_reduce_pack<Fr9Params>(v));
-        }
-    }
-}
-
 // tw[i] = omega^i, tw[n + i] = omega^i in the 2^261 Montgomery form (nine-limb butterflies), i < n
 __global__ void twiddle_kernel(Fe* tw, Fe omega, uint32_t n) {
     constexpr uint32_t CH = 16;
@@ -497,21 +345,10 @@ struct NttPlan {
     Fe zin0, zin1, zin2, zout1, zout2, scale;
 };
 
-static bool ntt9_enabled() {
-    static int on = -1;
-    if (on < 0) {
-        const char* e = getenv("ZG_NTT9");  // opt-in, see the file header
-        on = (e && atoi(e) != 0) ? 1 : 0;
-    }
-    return on == 1;
-}
-// nine-limb butterflies: no pass may have more than 9 stages (magnitude rule, see the file header)
-static bool ntt_use9(uint32_t log_n) { return ntt9_enabled() && log_n <= 18; }
-
-template <int LOG_T, bool NINE>
+template <int LOG_T>
 static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, size_t tmp_stride) {
     constexpr uint32_t T = 1u << LOG_T;
-    constexpr size_t ELEM = NINE ? sizeof(F9) : sizeof(Fe);
+    constexpr size_t ELEM = sizeof(Fe);
     NttArgs a;
     memset(&a, 0, sizeof(a));
     a.tw = tw;
@@ -522,18 +359,12 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
     a.coset_out = p.coset_out;
     a.scale_out = p.scale_out;
     a.zin0 = p.zin0; a.zin1 = p.zin1; a.zin2 = p.zin2; a.zout1 = p.zout1; a.zout2 = p.zout2; a.scale = p.scale;
-    if (NINE) {  // constants go in as c * 2^261: a product with them leaves the data in its own form
-        const Fe c261 = Fr9Params::c261_fe();
-        if (p.coset_in) { a.zin0 = Fr::mul(p.zin0, c261); a.zin1 = Fr::mul(p.zin1, c261); a.zin2 = Fr::mul(p.zin2, c261); }
-        if (p.coset_out) { a.zout1 = Fr::mul(p.zout1, c261); a.zout2 = Fr::mul(p.zout2, c261); }
-        if (p.scale_out) a.scale = Fr::mul(p.scale, c261);
-    }
     const uint32_t N = 1u << p.log_n;
     const uint32_t gper = p.grp.per ? p.grp.per : 0xffffffffu;
     // algorithmic bytes of a transform: input entries read + output entries written
     const double pass_bytes = (double)p.batch * ((double)p.in_len + (double)p.out_len) * 32.0;
     dim3 block(T / 4);
-    const bool single = NINE ? p.log_n <= 9 : p.log_n <= (uint32_t)LOG_T;
+    const bool single = p.log_n <= (uint32_t)LOG_T;
     if (single) {
         // one workgroup holds the whole transform: single rows pass, in-place safe
         a.log_n1 = 0;
@@ -541,13 +372,9 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.in = p.in; a.in_stride = p.in_stride;
         a.out = p.out; a.out_stride = p.out_stride;
         a.in_per = a.out_per = gper; a.in_outer = p.grp.in_outer; a.out_outer = p.grp.out_outer;
-        size_t lds = (size_t)(T + (NINE && LOG_T > 10 ? 0 : N / 2)) * ELEM;
-        if (NINE)
-            ZG_LAUNCH(ctx, "ntt_single", pass_bytes, (ntt9_pass_kernel<LOG_T, false, true>),
-                      dim3(1, (uint32_t)p.batch), block, lds, a);
-        else
-            ZG_LAUNCH(ctx, "ntt_single", pass_bytes, (ntt_pass_kernel<LOG_T, false, true>),
-                      dim3(1, (uint32_t)p.batch), block, lds, a);
+        size_t lds = (size_t)(T + N / 2) * ELEM;
+        ZG_LAUNCH(ctx, "ntt_single", pass_bytes, (ntt_pass_kernel<LOG_T, false, true>),
+                  dim3(1, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
@@ -560,13 +387,9 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.in_per = gper; a.in_outer = p.grp.in_outer;
         a.out_per = 0xffffffffu; a.out_outer = 0;
         uint32_t cnt = T / N1;
-        size_t lds = (size_t)(T + (NINE && LOG_T > 10 ? 0 : N1 / 2)) * ELEM;
-        if (NINE)
-            ZG_LAUNCH(ctx, "ntt_cols", pass_bytes * 0.5, (ntt9_pass_kernel<LOG_T, true, true>),
-                      dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
-        else
-            ZG_LAUNCH(ctx, "ntt_cols", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, true, true>),
-                      dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
+        size_t lds = (size_t)(T + N1 / 2) * ELEM;
+        ZG_LAUNCH(ctx, "ntt_cols", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, true, true>),
+                  dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }
     {   // pass 2: tmp -> out
@@ -576,13 +399,9 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.out_per = gper; a.out_outer = p.grp.out_outer;
         uint32_t cnt = T / N2;
         if (cnt > N1) cnt = N1;
-        size_t lds = (size_t)(T + (NINE && LOG_T > 10 ? 0 : N2 / 2)) * ELEM;
-        if (NINE)
-            ZG_LAUNCH(ctx, "ntt_rows", pass_bytes * 0.5, (ntt9_pass_kernel<LOG_T, false, false>),
-                      dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
-        else
-            ZG_LAUNCH(ctx, "ntt_rows", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, false, false>),
-                      dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
+        size_t lds = (size_t)(T + N2 / 2) * ELEM;
+        ZG_LAUNCH(ctx, "ntt_rows", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, false, false>),
+                  dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }
     return ZG_OK;
@@ -591,19 +410,15 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
 // Runs the plan on the context stream.  `tmp` must hold batch * 2^log_n elements whenever the
 // transform takes two passes (see ntt_needs_tmp).
 static uint32_t ntt_log_t(uint32_t log_n) { return log_n <= 16 ? 10u : 11u; }
-bool ntt_needs_tmp(uint32_t log_n) { return ntt_use9(log_n) ? log_n > 9 : log_n > ntt_log_t(log_n); }
+bool ntt_needs_tmp(uint32_t log_n) { return log_n > ntt_log_t(log_n); }
 
 int ntt_run(zg_ctx* ctx, const NttPlan& p, Fe* tmp, size_t tmp_stride) {
     ZG_REQUIRE(p.log_n <= 22, ZG_ERR_UNSUPPORTED, "ntt: log_n %u > 22 not built", p.log_n);
     if (p.batch == 0) return ZG_OK;
     Fe* tw = nullptr;
     ZG_TRY(get_twiddles(ctx, p.log_n, p.omega, &tw));
-    if (ntt_use9(p.log_n)) {
-        if (p.log_n <= 16) return launch_passes<10, true>(ctx, p, tw, tmp, tmp_stride);
-        return launch_passes<11, true>(ctx, p, tw, tmp, tmp_stride);
-    }
-    if (ntt_log_t(p.log_n) == 10) return launch_passes<10, false>(ctx, p, tw, tmp, tmp_stride);
-    return launch_passes<11, false>(ctx, p, tw, tmp, tmp_stride);
+    if (ntt_log_t(p.log_n) == 10) return launch_passes<10>(ctx, p, tw, tmp, tmp_stride);
+    return launch_passes<11>(ctx, p, tw, tmp, tmp_stride);
 }
 
 static int ensure_lds_attr(zg_ctx* ctx) {
@@ -612,16 +427,6 @@ static int ensure_lds_attr(zg_ctx* ctx) {
     if (ds.ntt_attrs) return ZG_OK;
     // tiles above 64 KB need the opt-in dynamic LDS limit
     const int big = 160 * 1024;
-    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<11, true, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<11, false, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<10, true, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<10, false, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
-    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<10, false, true>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, big));
     ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<11, true, true>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
     ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<11, false, true>,

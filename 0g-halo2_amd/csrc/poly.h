@@ -230,8 +230,8 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                    size_t stride, size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask,
                    uint32_t naf_width);
 int bases_enable_runs(zg_ctx* ctx, zg_bases* b);  // running-sum table for the run form (idempotent)
-int bases_enable_dense(zg_ctx* ctx, zg_bases* b, uint32_t window_bits);  // b->dense: the same points, larger window
-int bases_enable_naf(zg_ctx* ctx, zg_bases* b, uint32_t w);  // b->dense: one row per bit position, odd w-bit digits
+// b->dense: one row per bit position, odd w-bit digits (strict: refuse a table made for another default width)
+int bases_enable_naf(zg_ctx* ctx, zg_bases* b, uint32_t w, bool strict = false);
 int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t window_bits, zg_bases** out);
 void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
 

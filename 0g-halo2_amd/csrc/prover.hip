@@ -94,6 +94,7 @@ struct PkDev {
     // evaluate_h on nine 29-bit limbs: the coset slabs, l-polynomials, t_eval and the monomial coefficients it
     // reads are kept in the 2^261 Montgomery form (x * 2^5 of the library form); ZG_EVALH9=0 turns it off
     bool hat = true;
+    bool grouped = true;  // the terms after the gates are weighted by powers of y and summed per l-polynomial (ZG_EVALH_GROUPED)
     DMono* monos_hat = nullptr;
     zg_poly* gates_hat = nullptr;
     uint32_t* gate_common = nullptr;
@@ -141,6 +142,7 @@ struct zg_prover {
     };
     std::shared_ptr<OwnedBases> owned_bases;
     bool use_side = true;   // coefficient / coset forms on a side stream (latency) or inline (throughput)
+    uint32_t naf_gl_w = 0;  // digit width of the run-form commitments' free-position form, 0 = windows (naf_gl_default)
     // point-range shard of the commitments (zg_prover_set_shard): this prover's base sets hold points
     // [shard_lo, shard_lo + shard_n) of the SRS; partial commitments of all ranks are exchanged and summed
     uint32_t shard_lo = 0, shard_n = 0, world = 1, rank = 0;
@@ -269,33 +271,29 @@ namespace {
 
 // the bit-position table of a base set for the throughput form's commitments of full-size scalars (the sorted a' / s'
 // columns and the products in their run form, the random vectors), else the base set itself
+// (a lone proof keeps the window tables: from the 0.27 GB bit-position table, which no cache holds, its few waves wait on
+//  the gathers -- 3.27 against 3.01 ms with the same bucket count)
 static const zg_bases* naf_of(const zg_prover* p, const zg_bases* b) {
-    // (a lone proof keeps the window tables: from the 0.27 GB bit-position table, which no cache holds, its few waves
-    //  wait on the gathers -- 3.27 against 3.01 ms with the same bucket count; ZG_MSM_NAF_LATENCY=1 for A/B)
-    static const bool lat = getenv("ZG_MSM_NAF_LATENCY") && atoi(getenv("ZG_MSM_NAF_LATENCY")) != 0;
-    return b && b->dense && b->dense->naf_w && (lat || !p->ctx->msm_pair) ? b->dense : b;
+    const zg_bases* d = bases_dense(b);
+    return d && d->naf_w && !p->ctx->msm_pair ? d : b;
 }
 
 // Digit width of the free-position form for the run-form commitments against g_lagrange (the sorted a' / s' columns and
 // the products: full-size coefficients wherever a row changes something, but half-empty vectors -- so the width that
 // keeps the bucket count of the window form, c + 1: 254 / (c + 2) digits per coefficient instead of 255 / c windows.
 // Same-box A/B at k = 14: 0.7122 -> 0.7060 ms/proof at 13; 12: 0.718, 14: 0.722; 15, the random vectors' width: 0.740.)
-// ZG_MSM_NAF_GL = width, 0 = the window form.
-static uint32_t naf_gl_width(const zg_prover* p) {
-    static const int v = getenv("ZG_MSM_NAF_GL") ? atoi(getenv("ZG_MSM_NAF_GL")) : -1;
+// ZG_MSM_NAF_GL = width, 0 = the window form; fixed when the prover is created (zg_prover::naf_gl_w).
+static uint32_t naf_gl_default(const zg_bases* gl) {
+    const int v = knob(K_MSM_NAF_GL);
     if (v >= 0) return v >= 3 && v <= 16 ? (uint32_t)v : 0u;
-    const uint32_t w = p->gl->c + 1;
+    const uint32_t w = gl->c + 1;
     return w >= 3 && w <= 16 ? w : 0u;
 }
+static uint32_t naf_gl_width(const zg_prover* p) { return p->naf_gl_w; }
 
-// the second table of g for the all-random commitments: the bit-position table (a lone proof recodes at the width that
-// keeps its bucket count, dense_width), or the larger-window table (throughput form only, unless asked otherwise)
-static const zg_bases* dense_g(const zg_prover* p) {
-    static const bool lat = getenv("ZG_MSM_DENSE_LATENCY") && atoi(getenv("ZG_MSM_DENSE_LATENCY"));
-    if (p->g->dense && p->g->dense->naf_w) return naf_of(p, p->g);
-    return p->g->dense && (lat || !p->ctx->msm_pair) ? p->g->dense : p->g;
-}
-static uint32_t dense_width(const zg_prover* p) { return p->ctx->msm_pair ? naf_gl_width(p) : 0u; }
+// the table of g for the all-random commitments (the quotient pieces, the opening quotients): its bit-position table in
+// the throughput form, recoded at the width the table was made for
+static const zg_bases* dense_g(const zg_prover* p) { return naf_of(p, p->g); }
 
 // Commitments of a phase: one MSM launch sequence over `count` = groups x per scalar vectors (msm_batch4_dev), against
 // this prover's point range of the base sets; the XYZZ results go to the host behind it.
@@ -359,7 +357,7 @@ int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
 // terms of evaluate_h after the gates: permutation (l0, llast, one l0 per further set, one lactive per set) and five per
 // lookup; 0 when they are too many for ProofConst::eh_ypow (or switched off): the kernel then folds in y term by term
 uint32_t evalh_terms(const PkDev& pk) {
-    static const bool grouped = !(getenv("ZG_EVALH_GROUPED") && atoi(getenv("ZG_EVALH_GROUPED")) == 0);  // A/B knob
+    const bool grouped = pk.grouped;
     const uint32_t t = (pk.sets ? 2 + (pk.sets - 1) + pk.sets : 0) + 5 * pk.NL;
     // (at most 40: the sums that multiply l0 / lactive then stay below the operand bound of Fr9::mul2)
     return grouped && pk.hat && t >= 1 && t <= 40 && t + 1 <= EH_MAX_YPOW ? t : 0;
@@ -589,6 +587,19 @@ GateFactor factor_gate(const std::vector<DMono>& monos, zg_poly g, uint32_t f, c
 
 }  // namespace
 
+namespace zg {
+ProverShape prover_shape(const zg_prover* p) {
+    const PkDev& k = *p->pk;
+    return ProverShape{p->ctx, k.device, k.k, k.A, k.I, k.usable, p->in_flight};
+}
+int prover_drain(zg_prover* p) {
+    ZG_ENTER(p->ctx);
+    ZG_HIP(hipStreamSynchronize(p->ctx->stream));
+    if (p->ctx->side) ZG_HIP(hipStreamSynchronize(p->ctx->side->stream));
+    return ZG_OK;
+}
+}  // namespace zg
+
 extern "C" {
 
 void zg_keccak256(const uint8_t* data, size_t len, uint8_t out[32]) { keccak256(data, len, out); }
@@ -681,7 +692,8 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     const uint32_t n = pk->n, en = pk->en;
     hipStream_t st = ctx->stream;
     ZG_TRY(prover_events(p));
-    if (const char* e = getenv("ZG_EVALH9")) pk->hat = atoi(e) != 0;
+    pk->hat = knob(K_EVALH9) != 0;
+    pk->grouped = knob(K_EVALH_GROUPED) != 0;
     if (p->use_side && !ctx->side) ZG_TRY(zg_ctx_create(ctx->device, &ctx->side));
     auto dalloc = [&](auto** o, size_t count) { return dalloc_into(pk->owned, o, count); };
 
@@ -822,36 +834,30 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     // (fewer points than 2^k: a point-range shard of the SRS; zg_prover_set_shard names the range before the first proof)
     p->shard_lo = 0;
     p->shard_n = (uint32_t)p->g->n;
-    static const bool run_form = !(getenv("ZG_MSM_RUNS") && atoi(getenv("ZG_MSM_RUNS")) == 0);  // A/B knob
+    const bool run_form = knob(K_MSM_RUNS) != 0;
     if (run_form && pk->sets + pk->NL > 0) ZG_TRY(bases_enable_runs(ctx, p->gl));
-    {   // The quotient pieces and the opening quotients are vectors of random scalars, which fill every window: two more
-        // bits per window save more additions (22 -> 19 per scalar at k = 14) than the four-fold bucket set costs, which
-        // the sparse and run-form columns of g_lagrange would pay for nothing.  Measured in the throughput form:
-        // -1.3 % ms/proof at k = 14 (c 12 -> 13 or 14) and at k = 15 (13 -> 15), nothing at k = 17 (15 -> 16); a lone
-        // proof does not gain (dense_g).  +W'/W of the table memory of g.
-        static const int dense_env = getenv("ZG_MSM_C_DENSE") ? atoi(getenv("ZG_MSM_C_DENSE")) : -1;  // A/B knob; 0 = none
-        uint32_t cd = p->g->c + 2 <= 15 ? p->g->c + 2 : 15;
-        if (dense_env >= 0) cd = (uint32_t)dense_env;
-        // ... and better than a larger window: odd signed digits at FREE bit positions against a table with one row per
-        // bit (bases_enable_naf; 255 rows: 0.27 GB at k = 14, 2.1 GB at k = 17) -- 254 / (w + 1) additions per scalar
-        // and only odd buckets: 15.9 where the 14-bit windows above spend 19, on the same 8192 buckets.  Same-box A/B at
-        // k = 14: 0.7447 -> 0.7319 ms/proof (w = 15; 14: 0.7355, 13: 0.744, 16: 0.753); k = 17, w = 16: 5.97 -> 5.895.
-        // ZG_MSM_NAF = digit width, 0 = the larger-window table above instead (A/B).
-        static const int naf_env = getenv("ZG_MSM_NAF") ? atoi(getenv("ZG_MSM_NAF")) : -1;
+    p->naf_gl_w = naf_gl_default(p->gl);
+    {   // The quotient pieces and the opening quotients are vectors of random scalars, which fill every window.  With
+        // 288 GB of HBM the base set gets a table with one row per BIT position (bases_enable_naf; 255 rows: 0.27 GB at
+        // k = 14, 2.1 GB at k = 17) and a scalar is recoded into odd signed digits at FREE positions: 254 / (w + 1)
+        // additions per scalar and only odd buckets -- 15.9 at w = 15 where 12-bit windows spend 22.  Same-box A/B at
+        // k = 14: 0.7447 -> 0.7319 ms/proof against a larger-window table (w = 15; 14: 0.7355, 13: 0.744, 16: 0.753);
+        // k = 17, w = 16: 5.97 -> 5.895.  ZG_MSM_NAF = digit width, 0 = the window table only.
+        const int naf_env = knob(K_MSM_NAF);
         uint32_t lg = 0;
         while ((2u << lg) <= p->g->n) lg++;
         uint32_t nw = lg >= 16 ? 16u : lg >= 14 ? 15u : lg + 1 < 3 ? 3u : lg + 1;
         if (naf_env >= 0) nw = (uint32_t)naf_env;
-        const bool naf_gl = naf_gl_width(p) != 0;  // (the same tables serve any digit width: naf_gl_width)
         if (nw >= 3 && nw <= 16) {
             ZG_TRY(bases_enable_naf(ctx, p->g, nw));
-            if (naf_gl && p->gl->run_table && p->g->dense && p->g->dense->naf_w) {
+            const zg_bases* gd = bases_dense(p->g);
+            if (p->naf_gl_w && p->gl->run_table && gd && gd->naf_w) {
                 // the same for g_lagrange and its running sums: the sorted columns and the products are committed in the
                 // run form, whose coefficients s_i - s_{i+1} are full-size scalars wherever a row changes something
-                ZG_TRY(bases_enable_naf(ctx, p->gl, p->g->dense->naf_w));
-                if (p->gl->dense && p->gl->dense->naf_w == p->g->dense->naf_w) ZG_TRY(bases_enable_runs(ctx, p->gl->dense));
+                ZG_TRY(bases_enable_naf(ctx, p->gl, gd->naf_w));
+                if (zg_bases* gld = bases_dense(p->gl)) ZG_TRY(bases_enable_runs(ctx, gld));
             }
-        } else if (cd > p->g->c && cd <= 16) ZG_TRY(bases_enable_dense(ctx, p->g, cd));
+        }
     }
 
     // ---- proving-key slabs
@@ -861,7 +867,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
     ZG_TRY(dalloc(&pk->sigma_val, (size_t)P * n));
     // parts of the extended domain
     {
-        static const bool split_env = !(getenv("ZG_SPLIT_DOMAIN") && atoi(getenv("ZG_SPLIT_DOMAIN")) == 0);  // A/B knob
+        const bool split_env = knob(K_SPLIT_DOMAIN) != 0;
         uint32_t m1 = 1;
         while (m1 * 2 <= Q) m1 *= 2;
         const uint32_t m2 = Q - m1;
@@ -1002,6 +1008,7 @@ int zg_prover_fork(const zg_prover* parent, zg_ctx* ctx, zg_prover** out) {
     p->gl = parent->gl;
     p->owned_bases = parent->owned_bases;  // (joint ownership; null when the caller registered the tables)
     p->use_side = parent->use_side;
+    p->naf_gl_w = parent->naf_gl_w;
     p->shard_lo = parent->shard_lo; p->shard_n = parent->shard_n; p->world = parent->world; p->rank = parent->rank;
     p->exchange = parent->exchange; p->exchange_user = parent->exchange_user;
     // (a communicator serialises its collectives on ONE stream: a fork does not inherit it)
@@ -1351,7 +1358,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
         ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
     }
-    ZG_TRY(commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0, dense_width(p)));
+    ZG_TRY(commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0));
     ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
     for (uint32_t b = 0; b < nb; b++)
         for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
@@ -1506,7 +1513,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
                                   wp_bs, p->ktmp, n));
         // the witness polynomials sit at odd slots: stride 2n
-        ZG_TRY(commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0, dense_width(p)));
+        ZG_TRY(commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0));
         ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
         for (uint32_t b = 0; b < nb; b++)
             for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);

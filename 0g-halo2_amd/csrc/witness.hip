@@ -271,6 +271,11 @@ int zg_witness_plan_create(zg_ctx* ctx, const zg_witness_op* ops, size_t n_ops, 
     // The program runs on the GPU unchecked, so everything static is checked here: levels partition the operations in
     // order, an operand is a slot of an EARLIER level (straight-line, no cycles), immediates index inside their pools.
     ZG_REQUIRE(level_start[0] == 0 && level_start[n_levels] == n_ops, ZG_ERR_INVALID_ARG, "zg_witness_plan_create: levels do not cover the operations");
+    // the WHOLE array, not only the levels that hold an operation: witness_run_kernel walks every level's
+    // [level_start[l], level_start[l + 1]) and a trailing level beyond n_ops would read ops[] and write slots[] out of bounds
+    for (size_t l = 0; l < n_levels; l++)
+        ZG_REQUIRE(level_start[l] <= level_start[l + 1] && level_start[l + 1] <= n_ops, ZG_ERR_INVALID_ARG,
+                   "zg_witness_plan_create: level %zu spans [%u, %u) of %zu operations", l, level_start[l], level_start[l + 1], n_ops);
     std::vector<WOp> dev_ops(n_ops);
     size_t lv = 0;
     for (size_t i = 0; i < n_ops; i++) {
@@ -391,7 +396,20 @@ int zg_prover_prove_images(zg_prover* p, zg_witness_plan* plan, const uint8_t* i
         ZG_REQUIRE(slots[b] != nullptr, ZG_ERR_INVALID_ARG, "zg_prover_prove_images: the prover has no slot %zu", b);
         inst[b] = outputs + b * plan->n_instance;
     }
-    // (the program writes [n_advice][2^k] columns: the prover checks the instance length, a slot's size is the circuit's)
+    // The program writes [n_advice][2^k] columns into the prover's slots: a plan recorded for another model (other k or
+    // column count) would overrun them, so its shape must be the prover's circuit's, on the prover's device.
+    const ProverShape sh = prover_shape(p);
+    ZG_REQUIRE(plan->ctx->device == sh.device, ZG_ERR_INVALID_ARG, "zg_prover_prove_images: the plan lives on device %d, the prover on %d",
+               plan->ctx->device, sh.device);
+    ZG_REQUIRE(plan->k == sh.k && plan->n_advice == sh.n_advice, ZG_ERR_INVALID_ARG,
+               "zg_prover_prove_images: the plan writes %u advice columns of 2^%u rows, the prover's circuit has %u of 2^%u", plan->n_advice,
+               plan->k, sh.n_advice, sh.k);
+    ZG_REQUIRE((plan->n_instance == 0 || sh.n_instance == 1) && plan->n_instance <= sh.usable_rows, ZG_ERR_INVALID_ARG,
+               "zg_prover_prove_images: the plan yields %u instance values for a circuit with %u instance column(s) of %u usable rows",
+               plan->n_instance, sh.n_instance, sh.usable_rows);
+    // The witness runs on the plan's stream, the proofs on the prover's: when those differ (or a batch left through an
+    // error return and its kernels may still read the slots) the prover's streams are drained before the slots are rewritten.
+    if (sh.in_flight || plan->ctx != sh.ctx) ZG_TRY(prover_drain(p));
     ZG_TRY(zg_witness_run_dev(plan, images, count, slots, outputs));
     return zg_prover_prove_batch_dev(p, count, nullptr, inst, plan->n_instance, rng_keys, proofs, proof_cap, proof_lens, statuses);
 }

@@ -73,7 +73,29 @@ ABI_SYMBOLS = [
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
     "zg_witness_plan_create", "zg_witness_plan_destroy", "zg_witness_plan_image_bytes", "zg_witness_plan_instance_len",
     "zg_witness_run_dev", "zg_prover_prove_images", "zg_prover_set_shard_rccl", "zg_xyzz_sum_ranks_dev", "zg_bases_enable_bit_table",
+    "zg_tuning_set", "zg_tuning_get", "zg_tuning_names",
 ]
+
+def tuning_names() -> list:
+    """Names of the library's tuning knobs (include/zg_halo2.h, "tuning")."""
+    lib = load()
+    lib.zg_tuning_names.restype = c_size_t
+    n = int(lib.zg_tuning_names(None, c_size_t(0)))
+    arr = (c_char_p * n)()
+    lib.zg_tuning_names(arr, c_size_t(n))
+    return [a.decode() for a in arr]
+
+
+def tuning_set(name: str, value: int) -> None:
+    """value < 0 restores the default.  Knobs that shape a proving key are read when a prover is created."""
+    _check(load().zg_tuning_set(name.encode(), c_int(value)))
+
+
+def tuning_get(name: str) -> int:
+    v = c_int(0)
+    _check(load().zg_tuning_get(name.encode(), ctypes.byref(v)))
+    return v.value
+
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(c_int, c_void_p, c_void_p, c_size_t, c_void_p)
 
@@ -438,8 +460,11 @@ class Prover:
         lib.zg_prover_batch.argtypes = [c_void_p]
         lib.zg_prover_advice_slot.restype = c_void_p
         lib.zg_prover_advice_slot.argtypes = [c_void_p, c_size_t]
-        self._keep = _keep
+        self._keep = _keep  # (a fork holds its parent: the parent's exchange trampolines outlive every fork)
         self._exchange = None
+        # every exchange trampoline this prover was ever given: zg_prover_fork copies the raw function pointer into the
+        # fork on the C side, so a superseded callback must stay alive for as long as a fork may still call it
+        self._exchanges = [] if _keep is None else _keep._exchanges
         if _handle is not None:
             h = _handle
         else:
@@ -493,6 +518,8 @@ class Prover:
                 return 1
 
         self._exchange = EXCHANGE_FN(_cb) if world > 1 else None
+        if self._exchange is not None:
+            self._exchanges.append(self._exchange)
         fn = self._exchange if self._exchange is not None else ctypes.cast(None, EXCHANGE_FN)
         _check(self.ctx.lib.zg_prover_set_shard(self.h, c_uint32(rank), c_uint32(world), c_size_t(first_point), fn, None))
 

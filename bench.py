@@ -231,25 +231,42 @@ def load_pmc():
         return None
 
 
-def cpu_baseline(c: Circuit, proof_len: int, threads: int):
-    """The oracle's create_proof (CPU restatement of halo2's algorithms, OpenMP over MSM chunks, FFT
-    butterflies and row loops) timed on this box's host cores on the SAME circuit and witness (its own
-    seeded SRS of the same size).  kind = "port": halo2's own Rust prover cannot be built here (no cargo/rustc)."""
+def cpu_baseline(c: Circuit, proof_len: int, threads: int, repeats: int = 7):
+    """The oracle's create_proof (CPU restatement of halo2's algorithms, OpenMP over MSM chunks, FFT butterflies and row
+    loops) timed on this box's host cores on the SAME circuit and witness (its own seeded SRS of the same size): the
+    MEDIAN of `repeats` proofs after one untimed warm-up, every sample and the per-phase split of
+    the median proof in the record.  kind = "port": halo2's own Rust prover cannot be built here (no cargo/rustc)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import orc
 
     orc.load().orc_set_threads(threads)
     params = orc.params_new(c.k, 0x5EED)
     pk = orc.ProvingKey(c.img, c.fixed, c.sigma, params, c.vk_repr)
-    t0 = time.perf_counter()
-    st, proof, _ = orc.create_proof(pk, c.advice, c.instance, 1)
-    dt = time.perf_counter() - t0
+    st, proof, _ = orc.create_proof(pk, c.advice, c.instance, 1)  # warm-up: page in, OpenMP team up
     assert st == 0 and len(proof) == proof_len
+    samples, phases = [], []
+    for i in range(repeats):
+        t0 = time.perf_counter()
+        st, proof, _ = orc.create_proof(pk, c.advice, c.instance, 2 + i)
+        samples.append(time.perf_counter() - t0)
+        phases.append(orc.last_phase_ms())
+        assert st == 0 and len(proof) == proof_len
+    order = sorted(range(repeats), key=lambda i: samples[i])
+    mid = order[repeats // 2]
+    dt = samples[mid]
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:
+        affinity = os.cpu_count() or 1
     return {
         "value": 3600.0 / dt, "unit": "proofs/hour", "cores": threads, "kind": "port",
-        "sample": f"1 full create_proof of the same k={c.k} circuit in {dt:.2f} s: oracle/prover.c "
-                  f"(plain-C restatement of halo2 create_proof, OpenMP {threads} threads)",
-        "wall_s": dt,
+        "sample": f"median of {repeats} full create_proofs of the same k={c.k} circuit (after 1 warm-up): {dt:.3f} s each; "
+                  f"oracle/prover.c (plain-C restatement of halo2 create_proof, OpenMP {threads} threads)",
+        "wall_s": dt, "samples_s": [round(x, 4) for x in samples], "min_s": min(samples), "max_s": max(samples),
+        "openmp": {"threads": threads, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"),
+                   "cores_in_affinity_mask": affinity, "machine_cores": os.cpu_count()},
+        "phase_ms": dict(zip(["advice", "lookups_permuted", "products", "h", "evals", "gwc", "total"],
+                             [round(x, 2) for x in phases[mid][:7]])),
     }
 
 

@@ -61,6 +61,31 @@ const char *zg_last_error(void);
 /* Library version string and the gfx target it was compiled for ("gfx950"). */
 const char *zg_version(void);
 
+/* ------------------------------------------------------------------ tuning
+ * Every switch of the library, by name.  A knob starts from the environment variable of the same name (read once, when
+ * the first knob is asked for) and may be set at run time; value < 0 restores the library's default.  None changes a
+ * result: every form computes the same group elements and field elements, bit for bit (tests/test_gpu_knobs.py walks
+ * them all against the oracle).  Knobs that shape resident data are read when that object is built (ZG_MSM_C: a base
+ * set registered with window_bits = 0; ZG_MSM_NAF, ZG_MSM_NAF_GL, ZG_MSM_RUNS, ZG_EVALH9, ZG_EVALH_GROUPED,
+ * ZG_SPLIT_DOMAIN: zg_prover_create*), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
+ * ZG_MSM_STRIP).
+ *   ZG_MSM_C          window bits of the MSM tables, 2..16 (default from n: k - 2)
+ *   ZG_MSM_K          points per bucket-accumulation task in the throughput form, 4..120 (48)
+ *   ZG_MSM_K_LAT      ... in the latency form (16)
+ *   ZG_MSM_RB         buckets per block of the latency form's bucket reduction: 64 / 128 / 256
+ *   ZG_MSM_LANES      lanes per EC addition there: 2 / 4
+ *   ZG_MSM_STRIP      buckets per lane in the throughput form's reduction: 2 / 4 / 8 / 16 (8)
+ *   ZG_MSM_NAF        digit width of the free-position form for all-random commitments, 3..16; 0 = window tables only
+ *   ZG_MSM_NAF_GL     ... for the run-form commitments against g_lagrange (c + 1); 0 = windows
+ *   ZG_MSM_RUNS       0 = no run form (summation by parts over running base sums)
+ *   ZG_EVALH_GROUPED  0 = evaluate_h folds in y term by term (the fallback of circuits with > 40 such terms)
+ *   ZG_EVALH9         0 = evaluate_h on 8 x 32-bit limbs; implies the single extended coset
+ *   ZG_SPLIT_DOMAIN   0 = EvaluationDomain's single extended coset in the throughput form too */
+int zg_tuning_set(const char *name, int value);
+int zg_tuning_get(const char *name, int *value);
+/* out[i] = name of knob i for i < min(cap, count); returns the count. */
+size_t zg_tuning_names(const char **out, size_t cap);
+
 /* ------------------------------------------------------------------ context */
 /* Creates a context on HIP device `device_id`.  Fails with ZG_ERR_NO_DEVICE when no GPU is
  * visible: there is deliberately no CPU fallback.  (SURVEY.md's sketch had zg_ctx_create(n_devices, device_ids):

@@ -273,6 +273,13 @@ def create_proof(pk: ProvingKey, advice: np.ndarray, instance: np.ndarray, seed,
     return st, bytes(buf[: plen.value]), tr
 
 
+def last_phase_ms() -> list:
+    """Per-phase wall-clock of this thread's last create_proof (slots of zg_prover_phase_ms)."""
+    out = (ctypes.c_double * 8)()
+    load().orc_last_phase_ms(out, c_size_t(8))
+    return list(out)
+
+
 def verify_proof(pk: ProvingKey, instance: np.ndarray, proof: bytes) -> int:
     instance = np.ascontiguousarray(instance, dtype=np.uint64)
     inst_len = instance.shape[1] if instance.ndim == 3 and instance.shape[0] else 0

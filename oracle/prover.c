@@ -314,6 +314,27 @@ typedef struct {
 } query;
 
 /* ------------------------------------------------------------------ create_proof */
+/* Wall-clock milliseconds the LAST orc_create_proof of this thread spent per phase, in the slots of the product's
+ * zg_prover_phase_ms (0 instance + advice commitments, 1 permuted lookups, 2 products + random polynomial, 3 coefficient
+ * forms + evaluate_h + h commitments, 4 evaluations, 5 GWC openings, 6 total): bench.py's cpu_baseline prints them
+ * beside the GPU's. */
+#include <time.h>
+static __thread double g_phase_ms[8];
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+void orc_last_phase_ms(double *out, size_t cap) {
+    for (size_t i = 0; i < cap && i < 8; i++) out[i] = g_phase_ms[i];
+}
+#define PHASE_LAP(slot)                          \
+    do {                                         \
+        const double now_ = now_ms();            \
+        g_phase_ms[slot] = now_ - t_prev_;       \
+        t_prev_ = now_;                          \
+    } while (0)
+
 int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *instance_in, size_t instance_len,
                      const uint8_t seed[32], uint8_t *proof, size_t cap, size_t *proof_len, orc_trace *trace) {
     const zg_circuit *cs = pk->cs;
@@ -329,6 +350,8 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     const size_t qpd = dom.quotient_poly_degree;
     const int64_t rs = (int64_t)(en / n); /* rotation scale on the extended domain */
     int status = 0;
+    const double t_start_ = now_ms();
+    double t_prev_ = t_start_;
 
     transcript tr;
     tr_init(&tr, proof, cap);
@@ -358,6 +381,7 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     }
     orc_fr theta;
     tr_squeeze(&tr, &theta);
+    PHASE_LAP(0);
 
     /* ---- lookups: commit_permuted */
     orc_fr *cin = (orc_fr *)malloc((NL ? NL : 1) * n * sizeof(orc_fr));  /* compressed input  */
@@ -396,6 +420,7 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     orc_fr beta, gamma;
     tr_squeeze(&tr, &beta);
     tr_squeeze(&tr, &gamma);
+    PHASE_LAP(1);
 
     /* ---- permutation argument: permutation::prover::commit */
     const size_t chunk = cs->cs_degree - 2;
@@ -476,6 +501,7 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     }
     orc_fr y;
     tr_squeeze(&tr, &y);
+    PHASE_LAP(2);
 
     /* ---- coefficient forms */
     orc_fr *adv_poly = (orc_fr *)malloc((A ? A : 1) * n * sizeof(orc_fr));
@@ -681,6 +707,7 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     }
     orc_fr x, xn;
     tr_squeeze(&tr, &x);
+    PHASE_LAP(3);
     orc_fr_pow_u64(&xn, &x, (uint64_t)n);
 
     /* ---- evaluations */
@@ -779,6 +806,7 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     /* ---- ProverGWC::create_proof */
     orc_fr v;
     tr_squeeze(&tr, &v);
+    PHASE_LAP(4);
     {
         int *done = (int *)calloc(nq, sizeof(int));
         orc_fr *batch = (orc_fr *)malloc(n * sizeof(orc_fr));
@@ -818,6 +846,8 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
         trace->permuted_table = ptab; ptab = NULL;
         trace->h_pieces = h_coeff; h_coeff = NULL;
     }
+    PHASE_LAP(5);
+    g_phase_ms[6] = t_prev_ - t_start_;
     free(qs); free(fq); free(sq); free(pz_eval); free(lk_eval); free(h_poly); free(h_coeff); free(h);
     free(l0); free(llast); free(lactive);
     free(adv_cos); free(inst_cos); free(fix_cos); free(sig_cos); free(pz_cos); free(lz_cos); free(pin_cos);

@@ -83,6 +83,10 @@ int orc_verify_proof(const orc_pk *pk, const orc_fr *instance, size_t instance_l
 int orc_verify_proof_pairing(const orc_pk *pk, const orc_fr *instance, size_t instance_len, const uint8_t *proof,
                              size_t proof_len);
 
+/* Milliseconds the calling thread's last orc_create_proof spent per phase, in the slots of zg_prover_phase_ms (0 advice,
+ * 1 permuted lookups, 2 products, 3 coefficient forms + evaluate_h + h, 4 evaluations, 5 openings, 6 total). */
+void orc_last_phase_ms(double *out, size_t cap);
+
 /* Stand-alone pieces, used by the piecewise GPU parity tests. */
 void orc_grand_product(orc_fr *z, const orc_fr *num, const orc_fr *den, const orc_fr *z0, size_t n);
 size_t orc_proof_size(const zg_circuit *cs);

@@ -7,7 +7,7 @@
 //!   * once per `ProvingKey`: `pk.vk.cs` is flattened into a `zg_circuit` (`flatten`: queries, every gate / lookup
 //!     expression expanded into monomials by `expand`, permutation columns, advice / fixed query order) and handed to
 //!     `zg_prover_create` with `pk.fixed_values`, `pk.permutation.permutations`, `params.g`, `params.g_lagrange` and
-//!     `pk.vk.transcript_repr`; the prover (proving key resident in HBM) is cached by the key's address;
+//!     `pk.vk.transcript_repr`; the prover (proving key resident in HBM) is cached by CONTENT (`Fingerprint`);
 //!   * per proof: the witness is synthesised exactly as upstream's prover does (`WitnessCollection`, one phase), the
 //!     `Assigned` values are batch-inverted, the advice columns go to `zg_prover_prove` with the instance values and 32
 //!     bytes from the caller's RNG as blinding key, and the returned bytes -- the EvmTranscript stream -- are replayed
@@ -199,8 +199,33 @@ struct Handle {
 }
 unsafe impl Send for Handle {} // every call into the library takes the context's lock
 
-/// one resident prover per ProvingKey (keyed by its address: `Wnn::proof` passes the same `&pk` for every image)
-static PROVERS: Lazy<Mutex<HashMap<usize, Handle>>> = Lazy::new(|| Mutex::new(HashMap::new()));
+/// What a resident prover was built FROM, by content: the verifying key's transcript representation (a hash of the
+/// whole constraint system and the fixed / permutation commitments), k, and the SRS through its second point
+/// g[1] = [s]_1 (which fixes the toxic scalar and with it every base).  A key's ADDRESS is no identity: after a
+/// `ProvingKey` is dropped another key or circuit can be allocated at the same address and would silently get the stale
+/// GPU prover.
+#[derive(Clone, Copy, PartialEq, Eq, Hash)]
+struct Fingerprint {
+    vk_repr: [u8; 32],
+    k: u32,
+    srs_g1: [u8; 64],
+    batch: bool, // the lock-step form keeps a handle of its own: its slot count and scheduling never leak into lone proofs
+}
+
+fn fingerprint(params: &ParamsKZG<Bn256>, pk: &ProvingKey<G1Affine>, batch: bool) -> Fingerprint {
+    let mut vk_repr = [0u8; 32];
+    vk_repr.copy_from_slice(pk.get_vk().transcript_repr.to_repr().as_ref());
+    let mut srs_g1 = [0u8; 64];
+    if let Some(p) = params.get_g().get(1) {
+        let c = p.coordinates().unwrap();
+        srs_g1[..32].copy_from_slice(c.x().to_repr().as_ref());
+        srs_g1[32..].copy_from_slice(c.y().to_repr().as_ref());
+    }
+    Fingerprint { vk_repr, k: params.k(), srs_g1, batch }
+}
+
+/// one resident prover per (proving key, SRS) content and form
+static PROVERS: Lazy<Mutex<HashMap<Fingerprint, Handle>>> = Lazy::new(|| Mutex::new(HashMap::new()));
 
 fn device() -> c_int {
     std::env::var("ZG_HALO2_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0)
@@ -389,7 +414,7 @@ where
     let params_kzg: &ParamsKZG<Bn256> = unsafe { &*(params as *const Scheme::ParamsProver as *const ParamsKZG<Bn256>) };
     let pk_g1: &ProvingKey<G1Affine> = unsafe { &*(pk as *const ProvingKey<Scheme::Curve> as *const ProvingKey<G1Affine>) };
 
-    let key = pk as *const _ as usize;
+    let key = fingerprint(params_kzg, pk_g1, false);
     let mut cache = PROVERS.lock().unwrap();
     if !cache.contains_key(&key) {
         cache.insert(key, build_handle(params_kzg, pk_g1)?);
@@ -431,15 +456,20 @@ pub fn create_proofs_zg<ConcreteCircuit: Circuit<Fr>, R: RngCore>(
     params: &ParamsKZG<Bn256>, pk: &ProvingKey<G1Affine>, circuits: &[ConcreteCircuit], instances: &[&[&[Fr]]], rng: &mut R,
 ) -> Result<Vec<Vec<u8>>, Error> {
     assert_eq!(circuits.len(), instances.len());
-    let key = pk as *const _ as usize;
+    // (a handle of its own: the slot count and the throughput scheduling set here must not leak into the lone-proof
+    //  path of try_create_proof, which keeps its latency form)
+    let key = fingerprint(params, pk, true);
     let mut cache = PROVERS.lock().unwrap();
     if !cache.contains_key(&key) {
-        cache.insert(key, build_handle(params, pk).expect("circuit outside the backend's scope"));
+        let h = build_handle(params, pk).expect("circuit outside the backend's scope");
+        check(unsafe { zg_prover_set_overlap(h.prover, 0) })?; // throughput form
+        cache.insert(key, h);
     }
     let h = cache.get(&key).unwrap();
     let count = circuits.len();
-    check(unsafe { zg_prover_set_batch(h.prover, count) })?;
-    check(unsafe { zg_prover_set_overlap(h.prover, 0) })?; // throughput form
+    if unsafe { zg_prover_batch(h.prover) } < count {
+        check(unsafe { zg_prover_set_batch(h.prover, count) })?;
+    }
     let inst_len = instances[0].iter().map(|c| c.len()).max().unwrap_or(0);
     let mut adv = Vec::with_capacity(count);
     let mut inst = Vec::with_capacity(count);

@@ -89,3 +89,107 @@ def test_product_keccak_kat(zg):
     for n in (1, 31, 32, 33, 135, 136, 137, 272, 1000):
         data = bytes((7 * i + n) & 0xFF for i in range(n))
         assert zg.keccak256(data) == orc.keccak256(data), n
+
+
+# ---- the three descriptions of the boundary's structs must agree: C (the header, through gcc -std=c99), Python
+# (ctypes Structures of the harness / binding) and Rust (#[repr(C)] structs of shim/.../zg_sys.rs, layout computed here)
+def _c_layout(tmp_path):
+    import json
+    import subprocess
+
+    exe = str(tmp_path / "layout")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "abi", "layout.c"), "-o", exe], check=True)
+    return json.loads(subprocess.run([exe], check=True, capture_output=True, text=True).stdout)
+
+
+def test_header_is_c99_and_layouts_match_ctypes(zg, tmp_path):
+    import circuit as hc
+
+    c = _c_layout(tmp_path)
+    pairs = {"zg_query": hc._Query, "zg_monomial": hc._Monomial, "zg_poly": hc._Poly, "zg_lookup": hc._Lookup,
+             "zg_circuit": hc.CCircuit, "zg_kernel_stat": zg.KernelStat}
+    for name, struct in pairs.items():
+        assert ctypes.sizeof(struct) == c[name]["size"], name
+        for field, off in c[name]["fields"].items():
+            assert getattr(struct, field).offset == off, (name, field)
+        assert [f[0] for f in struct._fields_] == list(c[name]["fields"]), name
+    # zg_witness_op crosses as a uint64[n, 4] numpy array
+    assert c["zg_witness_op"] == {"size": 32, "fields": {"op": 0, "a": 8, "b": 16, "imm": 24}}
+
+
+def _rust_structs():
+    src = open(os.path.join(ROOT, "shim", "halo2_proofs-zg", "src", "zg_sys.rs")).read()
+    consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (\w+): usize = (\d+);", src)}
+    out = {}
+    for m in re.finditer(r"#\[repr\(C\)\](?:\s*#\[derive\([^)]*\)\])?\s*pub struct (\w+)\s*\{(.*?)\}", src, flags=re.S):
+        fields = re.findall(r"pub (\w+): ([^,}]+?)\s*(?:,|$)", m.group(2).strip() + ",")
+        out[m.group(1)] = fields
+    return out, consts
+
+
+def _rust_layout(structs, consts, name):
+    prim = {"u8": (1, 1), "c_char": (1, 1), "u32": (4, 4), "i32": (4, 4), "u64": (8, 8), "f64": (8, 8), "Fr": (32, 8), "Fq": (32, 8)}
+
+    def size_align(t):
+        t = t.strip()
+        if t.startswith("*"):
+            return 8, 8
+        m = re.match(r"\[(.+); (\w+)\]", t)
+        if m:
+            s, a = size_align(m.group(1))
+            n = int(m.group(2)) if m.group(2).isdigit() else consts[m.group(2)]
+            return s * n, a
+        if t in prim:
+            return prim[t]
+        return _rust_layout(structs, consts, t)[:2]
+
+    off, align, offsets = 0, 1, {}
+    for fname, ftype in structs[name]:
+        s, a = size_align(ftype)
+        off = (off + a - 1) // a * a
+        offsets[fname] = off
+        off += s
+        align = max(align, a)
+    return (off + align - 1) // align * align, align, offsets
+
+
+def test_rust_repr_c_structs_match_the_header(tmp_path):
+    c = _c_layout(tmp_path)
+    structs, consts = _rust_structs()
+    for name in ("zg_query", "zg_monomial", "zg_poly", "zg_lookup", "zg_circuit", "zg_witness_op", "zg_kernel_stat"):
+        size, _, offsets = _rust_layout(structs, consts, name)
+        assert size == c[name]["size"], name
+        assert offsets == c[name]["fields"], name  # (dict equality + insertion order of both = same field order)
+        assert list(offsets) == list(c[name]["fields"]), name
+
+
+def test_rust_extern_block_is_generated_from_the_header():
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_zg_sys.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    src = open(os.path.join(ROOT, "shim", "halo2_proofs-zg", "src", "zg_sys.rs")).read()
+    declared = sorted(set(re.findall(r"pub fn (zg_[a-z0-9_]+)\(", src)))
+    assert declared == header_functions()
+
+
+def test_plain_c_driver_builds_against_the_library(tmp_path):
+    """tests/abi/c_driver.c (C99, -pedantic) links against libzg_halo2.so with nothing but the header; without a GPU it
+    stops at zg_ctx_create with the library's own no-device error (the run itself is tests/test_gpu_abi_c.py)."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "abi", "gen_c_driver_data.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    exe = str(tmp_path / "c_driver")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I",
+                    os.path.join(ROOT, "tests", "abi"), os.path.join(ROOT, "tests", "abi", "c_driver.c"), "-L",
+                    os.path.join(ROOT, "0g-halo2_amd"), "-lzg_halo2", "-Wl,-rpath," + os.path.join(ROOT, "0g-halo2_amd"), "-o", exe],
+                   check=True)
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr

@@ -20,8 +20,9 @@ def test_ntt_matches_oracle(ctx, zg, orc, log_n):
 
 
 @pytest.mark.parametrize("log_n", [18, 20])
-def test_ntt_large_roundtrip_and_spot_check(ctx, zg, orc, log_n):
-    """Full extended-domain sizes (k=15 -> 2^18, k=17 -> 2^20): oracle FFT is still seconds."""
+def test_ntt_extended_domain_sizes_match_oracle(ctx, zg, orc, log_n):
+    """Full extended-domain sizes (k=15 -> 2^18, k=17 -> 2^20): the WHOLE array against the oracle's best_fft (still
+    seconds on the host), then the inverse transform back to the input."""
     n = 1 << log_n
     a = orc.fill_fr(77, n)
     om, omi = zg.domain_omega(log_n)
@@ -59,7 +60,7 @@ def test_ntt_batch(ctx, zg, orc):
     assert np.array_equal(ctx.ntt_batch(got, omi, div), a)
 
 
-@pytest.mark.parametrize("k,j", [(4, 6), (8, 6), (10, 4), (14, 6), (15, 6)])
+@pytest.mark.parametrize("k,j", [(4, 6), (8, 6), (10, 4), (14, 6), (15, 6), (17, 6)])
 def test_coeff_to_extended_and_back(ctx, zg, orc, k, j):
     d = orc.domain(j, k)
     n = 1 << k
@@ -79,19 +80,3 @@ def test_ntt_rejects_bad_arguments(ctx, zg):
     with pytest.raises(zg.ZgError) as e:
         ctx.ntt(a, om)
     assert e.value.status == -4  # ZG_ERR_UNSUPPORTED
-
-
-def test_nine_limb_butterflies_are_bit_exact():
-    """The opt-in nine-limb NTT back end (ZG_NTT9=1, read once per process) must give the same bytes:
-    rerun this file's transforms and the golden NTT / proof vectors in a child process with it enabled."""
-    import os
-    import subprocess
-    import sys
-
-    if os.environ.get("ZG_NTT9") == "1":
-        pytest.skip("already inside the nine-limb run")
-    env = dict(os.environ, ZG_NTT9="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_ntt.py"),
-                        os.path.join(here, "test_golden.py")], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -341,7 +341,7 @@ def test_large_shape_k17_verifies(ctx, zg, orc):
     assert orc.verify_proof_pairing(pk, inst, want) == 1
 
 
-@pytest.mark.parametrize("k,force_degree", [(6, None), (7, 6)])
+@pytest.mark.parametrize("k,force_degree", [(6, None), (7, 6), (12, 6), (14, None)])
 def test_stand_alone_evaluate_h_matches_oracle(ctx, zg, orc, k, force_degree):
     """zg_prover_evaluate_h (the arithmetic-level entry for Evaluator::evaluate_h + the division by X^n - 1): fed the
     coefficient forms of the oracle's own witness-side polynomials and its challenges, it must return the oracle's h on
@@ -377,24 +377,3 @@ def test_stand_alone_evaluate_h_matches_oracle(ctx, zg, orc, k, force_degree):
     # the prover still proves afterwards (slot 0 was used as scratch)
     assert prover.prove(adv, inst, 5) == orc.create_proof(pk, adv, inst, 5)[1]
     prover.close()
-
-
-def test_ab_knob_variants_give_the_same_bytes():
-    """The forms the default replaced stay selectable for A/B (read once per process): evaluate_h folding in y term by
-    term (ZG_EVALH_GROUPED=0) and the quotient / opening commitments against the one table of g (ZG_MSM_C_DENSE=0,
-    ZG_MSM_NAF=0) or against a second table with larger windows (ZG_MSM_NAF=0 alone) instead of the bit-position table.
-    Rerun the proof-parity tests of this file in child processes with those."""
-    import os
-    import subprocess
-    import sys
-
-    if os.environ.get("ZG_EVALH_GROUPED") == "0":
-        pytest.skip("already inside the variant run")
-    here = os.path.abspath(__file__)
-    pick = "test_proof_bytes_match_oracle_and_verify or test_circuit_variants_match_oracle or test_split_extended_domain"
-    # (1) one table of g, term-by-term fold; (2) the larger-window second table instead of the bit-position one
-    # (3) free-position digits for the random vectors only
-    for knobs in (dict(ZG_EVALH_GROUPED="0", ZG_MSM_C_DENSE="0", ZG_MSM_NAF="0"), dict(ZG_MSM_NAF="0"), dict(ZG_MSM_NAF_GL="0")):
-        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", here, "-k", pick], env=dict(os.environ, **knobs),
-                           capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -213,7 +213,47 @@ def test_plan_rejects_malformed_programs(ctx, zg):
         dict(level_start=np.array([0, 2, 2], dtype=np.uint32)),                         # operand in the same level
         dict(cell_slot=np.full((1, 4), 2, np.uint32)),                                  # cell shows a missing slot
         dict(instance_slots=np.array([2], dtype=np.uint32)),
+        # trailing levels that hold no operation are walked by the kernel all the same: a level that
+        # reaches beyond the operations, and a tail that runs backwards
+        dict(ops=np.array([[1, 0, 0, 0], [1, 0, 0, 1], [0, 0, 0, 0]], dtype=np.uint64), instance_slots=np.array([2], dtype=np.uint32),
+             level_start=np.array([0, 3, 1000000, 3], dtype=np.uint32)),
+        dict(level_start=np.array([0, 1, 2, 1, 2], dtype=np.uint32)),
+        dict(level_start=np.array([0, 1, 3, 2], dtype=np.uint32)),
     ]
     for over in bad:
         with pytest.raises(zg.ZgError):
             zg.WitnessPlan(ctx, arrays(**over))
+
+
+def test_prove_images_refuses_a_plan_of_another_shape(ctx, zg, orc):
+    """zg_prover_prove_images writes the plan's [n_advice][2^k] columns into the prover's slots: a plan recorded for
+    another circuit shape (more columns, more rows) must be refused, not overrun the slot."""
+    from circuits import toy_circuit
+
+    cs, asg, ilen = toy_circuit(6)
+    params = orc.params_new(6, 0xABCDEF)
+    prover = zg.Prover(ctx, cs.to_c(), asg.fixed_values(), asg.sigma_values(), params.g_np(), params.g_lagrange_np(), orc.fr_from_int(5))
+
+    def plan(n_advice, k):
+        return zg.WitnessPlan(ctx, dict(ops=np.array([[1, 0, 0, 0], [5, 0, 0, 7]], dtype=np.uint64),
+                                        level_start=np.array([0, 1, 2], dtype=np.uint32), consts=np.zeros((1, 4), np.uint64),
+                                        table=np.zeros(1, np.uint64), cell_slot=np.full((n_advice, 1 << k), 0xFFFFFFFF, np.uint32),
+                                        instance_slots=np.array([1], dtype=np.uint32), image_bytes=2))
+
+    img = np.array([[5, 9]], dtype=np.uint8)
+    for n_advice, k in ((cs.n_advice + 1, 6), (cs.n_advice, 7), (cs.n_advice, 5)):
+        bad = plan(n_advice, k)
+        with pytest.raises(zg.ZgError) as e:
+            prover.prove_images(bad, img, [1])
+        assert e.value.status == -1
+        bad.close()
+    # the matching shape goes through (the all-zero witness with instance 12 is no valid statement: bytes, not validity)
+    ok = plan(cs.n_advice, 6)
+    proofs, outputs, sts = prover.prove_images(ok, img, [1], raise_on_error=False)
+    assert zg.fr_to_int(outputs[0, 0]) == 12
+    ok.close()
+    # ... and the prover still proves the real witness afterwards
+    pk = orc.ProvingKey(cs.to_c(), asg.fixed_values(), asg.sigma_values(), params, orc.fr_from_int(5))
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    assert prover.prove(adv, inst, 3) == orc.create_proof(pk, adv, inst, 3)[1]
+    prover.close()
