@@ -95,8 +95,8 @@ class RcclComm:
     def __init__(self, rank: int, world: int, device_index: int, dist_mod=None, group=None):
         import ctypes
 
-        class UniqueId(ctypes.Structure):
-            _fields_ = [("internal", ctypes.c_char * 128)]
+        class UniqueId(ctypes.Structure):  # ncclUniqueId: 128 opaque bytes (c_ubyte: a c_char array would read as a
+            _fields_ = [("internal", ctypes.c_ubyte * 128)]  # NUL-terminated string and truncate the id)
 
         self._rccl = ctypes.CDLL("librccl.so.1")
         hip = ctypes.CDLL("libamdhip64.so")
@@ -105,7 +105,7 @@ class RcclComm:
         if rank == 0:
             assert self._rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0, "ncclGetUniqueId failed"
         if world > 1:
-            box = [bytes(uid.internal) if rank == 0 else None]
+            box = [ctypes.string_at(ctypes.byref(uid), 128) if rank == 0 else None]
             dist_mod.broadcast_object_list(box, src=0, group=group)
             ctypes.memmove(ctypes.byref(uid), box[0], 128)
         comm = ctypes.c_void_p()
@@ -114,6 +114,15 @@ class RcclComm:
         assert st == 0, f"ncclCommInitRank failed with {st}"
         self.handle = comm.value
         self.rank, self.world = rank, world
+
+    def count(self) -> int:
+        """the communicator's size as RCCL reports it (ncclCommCount)"""
+        import ctypes
+
+        n = ctypes.c_int(0)
+        self._rccl.ncclCommCount.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
+        assert self._rccl.ncclCommCount(ctypes.c_void_p(self.handle), ctypes.byref(n)) == 0
+        return n.value
 
     def close(self):
         if getattr(self, "handle", None):

@@ -112,8 +112,10 @@ class Stream:
         self.ctx, self.prover, self.c, self.batch = ctx, prover, c, batch
         prover.set_batch(batch)
         prover.set_overlap(False)  # throughput configuration: one HIP stream per prover, split extended domain
-        if shard[1] > 1 and isinstance(exchange, int):  # an ncclComm_t: the all-gather runs inside the library
-            prover.set_shard_rccl(shard[0], shard[1], c.lo, exchange)
+        # `exchange` is THIS prover's: a communicator serialises its collectives on one stream, so every prover of a
+        # rank has one of its own (an RcclComm: the all-gather runs inside the library; else a host callback)
+        if shard[1] > 1 and hasattr(exchange, "handle"):
+            prover.set_shard_rccl(shard[0], shard[1], c.lo, exchange.handle)
         elif shard[1] > 1:
             prover.set_shard(shard[0], shard[1], c.lo, exchange)
         # the witness into every slot, once: a proof rewrites only the last blinding_factors+1 rows of its advice
@@ -149,7 +151,7 @@ class Stream:
         return self.last
 
 
-def make_streams(dev_index: int, c: Circuit, ctx0: zg.Ctx, nprovers: int, batch: int, rank: int, exchange=None, shard=(0, 1),
+def make_streams(dev_index: int, c: Circuit, ctx0: zg.Ctx, nprovers: int, batch: int, rank: int, exchanges=None, shard=(0, 1),
                  probe=None):
     """The provers of one GPU: the first, then its forks (same proving key and base tables) on contexts of their own.
     ORDER MATTERS: HIP hands out hardware queues in stream-creation order and the chip runs four compute pipes, so
@@ -162,7 +164,7 @@ def make_streams(dev_index: int, c: Circuit, ctx0: zg.Ctx, nprovers: int, batch:
     first = zg.Prover(ctx0, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
     first.set_overlap(False)  # (before forking: a fork of a single-stream prover creates no side stream of its own)
     provers = [first] + [first.fork(x) for x in ctxs[1:]]
-    streams = [Stream(ctxs[i], provers[i], c, batch, base + i, exchange, shard) for i in range(nprovers)]
+    streams = [Stream(ctxs[i], provers[i], c, batch, base + i, exchanges[i] if exchanges else None, shard) for i in range(nprovers)]
     probed = None
     if probe:
         pctx = zg.Ctx(dev_index)
@@ -393,11 +395,15 @@ def main():
     ap.add_argument("--model", choices=sorted(MODELS), default="tiny",
                     help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
     ap.add_argument("--batch", type=int, default=16, help="proofs per lock-step batch (zg_prover_prove_batch)")
-    ap.add_argument("--provers", type=int, default=12, help="proof streams per GPU (provers sharing one proving key)")
+    ap.add_argument("--provers", type=int, default=None,
+                    help="proof streams per GPU (provers sharing one proving key): 12; 4 in shard-msm, where every prover "
+                         "holds a communicator of its own")
     ap.add_argument("--mode", choices=["replicas", "shard-msm"], default="replicas")
-    ap.add_argument("--exchange", choices=["host", "rccl"], default="host",
-                    help="shard-msm: all-gather through the host callback (torch.distributed) or inside the library on a raw "
-                         "RCCL communicator (zg_prover_set_shard_rccl; needs one GPU per rank)")
+    ap.add_argument("--exchange", choices=["host", "rccl"], default=None,
+                    help="shard-msm: all-gather inside the library on raw RCCL communicators, one per prover "
+                         "(zg_prover_set_shard_rccl; the default when every rank owns a GPU) or through a host callback on "
+                         "torch.distributed groups, one per prover (the default of one-GPU rehearsals: RCCL refuses two "
+                         "ranks on one device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other three models")
@@ -445,24 +451,30 @@ def main():
 
     sharded = args.mode == "shard-msm" and world > 1
     shard = (rank, world) if sharded else (0, 1)
-    nprov = 1 if sharded else max(1, args.provers)  # (the exchange is a collective: one stream of batches per rank)
+    nprov = max(1, args.provers if args.provers else (4 if sharded else 12))
     batch = max(1, args.batch)
     if args.model == "large":
         batch = min(batch, 8)  # (a k = 17 proof slot is 1.4 GiB; 8 provers x 8 slots + workspaces stay well inside 288 GB)
-    exchange = None
+    exchanges, rccl_ranks, exchange_kind = None, None, None
     if sharded:
         import multi_gpu
 
-        if args.exchange == "rccl":
-            rccl = multi_gpu.RcclComm(rank, world, dev_index, dist)
-            exchange = rccl.handle
+        # every rank on a GPU of its own (the driver's launch): RCCL; ranks sharing a card (rehearsal): host callback
+        own_gpu = backend == "nccl" and "ZG_BENCH_DEVICE" not in os.environ
+        exchange_kind = args.exchange or ("rccl" if own_gpu else "host")
+        # ONE exchange PER PROVER (prover i of every rank forms a group with prover i of the others): the provers of a
+        # rank work through their phases independently, each on its own stream / host thread
+        if exchange_kind == "rccl":
+            exchanges = [multi_gpu.RcclComm(rank, world, dev_index, dist) for _ in range(nprov)]
+            rccl_ranks = exchanges[0].count()
         else:
-            exchange = multi_gpu.make_exchange(dist, dev if backend == "nccl" else None)
+            groups = [dist.new_group(backend=None) for _ in range(nprov)]  # (collective calls: same order on every rank)
+            exchanges = [multi_gpu.make_exchange(dist, dev if backend == "nccl" else None, g) for g in groups]
 
     ctx0 = zg.Ctx(dev_index)
     circuit = Circuit(ctx0, args.model, shard)
     want_probe = not (sharded or args.no_latency_probe)
-    ctxs, streams, probed = make_streams(dev_index, circuit, ctx0, nprov, batch, rank, exchange, shard,
+    ctxs, streams, probed = make_streams(dev_index, circuit, ctx0, nprov, batch, rank, exchanges, shard,
                                          probe=latency_probe if want_probe else None)
 
     def barrier():
@@ -557,11 +569,14 @@ def main():
                                       if args.model == "large" else ""),
                        "class_scores": circuit.scores,
                        "proofs_per_step": proofs_per_step,
-                       "parallelism": (f"{world} GPU(s), commitments sharded by point range (one all-gather per phase, "
-                                       f"{'inside the library on RCCL' if args.exchange == 'rccl' else 'host callback'}), "
-                                       f"1 lock-step batch of {batch} proofs in flight" if sharded else
+                       "parallelism": (f"{world} rank(s), commitments of every proof sharded by point range (one all-gather per "
+                                       f"commitment phase and prover, "
+                                       f"{'inside the library on RCCL' if exchange_kind == 'rccl' else 'host callback on ' + backend}), "
+                                       f"{nprov} prover(s) per rank x lock-step batches of {batch} proofs" if sharded else
                                        f"{world} GPU(s) x {nprov} prover stream(s) x lock-step batches of {batch} proofs")},
             "mode": args.mode if world > 1 else "single-gpu",
+            "exchange": exchange_kind, "rccl_ranks": rccl_ranks,
+            "ranks_share_a_device": bool(world > 1 and "ZG_BENCH_DEVICE" in os.environ),
             "inputs": "host memory, uploaded per proof" if HOST_ADVICE else "resident in HBM",
             "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
             "create_proof_wall_s": latency_s, "provers_per_gpu": nprov, "batch": batch,
@@ -576,8 +591,7 @@ def main():
                                                "total", "host_sort"], [round(x, 3) for x in phases])),
         }
         if not args.no_verify:
-            out.update(verify_last_step(circuit, streams, host_cores()) if not sharded else
-                       verify_last_step_sharded(circuit, streams, host_cores()))
+            out.update(verify_last_step(circuit, streams, host_cores()))  # (a sharded rank holds whole proofs: same check)
     if rank == 0 and not args.no_image_to_proof and not sharded and args.model == "tiny" and world == 1 and not HOST_ADVICE:
         out["image_to_proof"] = image_to_proof(circuit, streams, ctxs, barrier, host_cores(), not args.no_verify)
     # the other three models of BASELINE.json: a few steps each, same driver (after the headline's timed region)
@@ -614,10 +628,6 @@ def main():
     if dist is not None:
         dist.barrier()  # (rank 0 checks its proofs against the oracle after the timed region: the others wait here)
         dist.destroy_process_group()
-
-
-def verify_last_step_sharded(c: Circuit, streams, threads: int) -> dict:
-    return verify_last_step(c, streams, threads)
 
 
 if __name__ == "__main__":
