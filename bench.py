@@ -410,6 +410,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--host-advice", action="store_true",
                     help="every proof uploads its advice columns from host memory (PCIe-inclusive rate, for DESIGN.md)")
+    ap.add_argument("--no-serialised", action="store_true", help="skip the one-prover pass behind roofline.serialised")
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the lone-proof latency measurement (counter passes)")
     ap.add_argument("--no-image-to-proof", action="store_true", help="skip the run with a different image per proof (device witness)")
     args = ap.parse_args()
@@ -592,6 +593,24 @@ def main():
         }
         if not args.no_verify:
             out.update(verify_last_step(circuit, streams, host_cores()))  # (a sharded rank holds whole proofs: same check)
+    if rank == 0 and out.get("roofline") and not args.no_serialised and not sharded and world == 1:
+        # The timed region's durations are SHARED-chip durations (eleven other provers run beside every launch).  Per-kernel
+        # cost is what a kernel takes alone: ONE prover stepping, same lock-step batches, every launch bracketed by its own
+        # events -- one stream, so the kernels run one at a time.
+        dt1, st1 = measure(streams[:1], ctxs[:1], 3, 1, barrier, profile=True)
+        dev1 = sum(v[1] for v in st1.values())
+        ser = {}
+        for name, (l, ms, by) in sorted(st1.items(), key=lambda kv: -kv[1][1]):
+            gbps = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            ser[name] = {"avg_launch_ms": round(ms / max(l, 1), 4), "share_of_device_time": round(ms / dev1, 4) if dev1 else 0.0,
+                         "algo_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 5)}
+        dom = out["roofline"]["kernel"]
+        out["roofline"]["serialised"] = {
+            "note": "one prover alone on the chip (one stream: kernels run one at a time), same batches of "
+                    f"{batch}; per-launch HIP events; algorithmic bytes / launch duration against the HBM peak",
+            "ms_per_proof": dt1 / (3 * batch) * 1e3, "device_ms_per_proof": dev1 / (3 * batch),
+            "kernel": dom, "achieved": ser.get(dom, {}).get("algo_GBps"), "frac": ser.get(dom, {}).get("frac_of_hbm_peak"),
+            "avg_launch_ms": ser.get(dom, {}).get("avg_launch_ms"), "kernels": ser}
     if rank == 0 and not args.no_image_to_proof and not sharded and args.model == "tiny" and world == 1 and not HOST_ADVICE:
         out["image_to_proof"] = image_to_proof(circuit, streams, ctxs, barrier, host_cores(), not args.no_verify)
     # the other three models of BASELINE.json: a few steps each, same driver (after the headline's timed region)

@@ -1,0 +1,38 @@
+#!/bin/bash
+# Round-3 profile on the GPU box:  ./tools/profile_r03.sh TAG     (outputs under gpurun_out/prof_TAG/)
+#   1. SERIALISED kernel stats: rocprofv3 --kernel-trace --stats of ONE prover making lock-step batches of 16 (one
+#      stream: every kernel alone on the chip) -- the per-kernel table of DESIGN.md section 4
+#   2. the same trace of the default bench command (12 provers sharing the chip): the roofline object's cross-check
+#   3. counter passes of ONE prover x 16 (kernels serialised under counter collection), separate passes, no tracing flags:
+#        sq1: SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU
+#             SQ_INSTS_VALU + GRBM_GUI_ACTIVE      (issue saturation: active / wait split of the wave cycles, clock)
+#        sq2: SQ_INST_CYCLES_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS
+#             SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT
+#        FETCH_SIZE, WRITE_SIZE
+#   4. tools/fetch_calib.bin under FETCH_SIZE: what the counter reports for 16-B streaming reads and for 64-B / 32-B gathers
+#   5. the bench line itself, without the profiler
+# tools/install_r03.py TAG copies the summaries into profiles/r03/.
+set -e
+TAG=${1:-cur}
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+ONE="--steps 3 --warmup 1 --provers 1 --batch 16 --no-kernel-events --no-cpu-baseline --no-other-configs --no-verify --no-latency-probe --no-image-to-proof --no-serialised"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- python3 $R/bench.py $ONE > $OUT/serial_bench.json 2> $OUT/serial.log
+echo "serial trace done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --no-other-configs --no-image-to-proof > $OUT/bench_under_trace.json 2> $OUT/trace.log
+echo "shared trace done"
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq1 -- python3 $R/bench.py $ONE > /dev/null 2> $OUT/pmc_sq1.log
+echo "sq1 done"
+rocprofv3 --pmc SQ_INST_CYCLES_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py $ONE > /dev/null 2> $OUT/pmc_sq2.log
+echo "sq2 done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- python3 $R/bench.py $ONE > /dev/null 2> $OUT/pmc_$c.log
+  echo "$c done"
+done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- $R/tools/fetch_calib.bin > $OUT/calib_true.json 2> $OUT/calib.log
+echo "calibration done"
+cd $R
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+ls $OUT
