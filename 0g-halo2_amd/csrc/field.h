@@ -178,29 +178,45 @@ struct Field {
         reduce_once(o);
         return o;
 #else
-        uint32_t t[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) t[i] = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            uint64_t A = (uint64_t)a.l[0] * b.l[i] + t[0];
-            uint32_t m = (uint32_t)A * P::INV;
-            uint64_t C = (uint64_t)m * P::p(0) + (uint32_t)A;
-            A >>= 32;
-            C >>= 32;
-#pragma unroll
-            for (int j = 1; j < 8; j++) {
-                A += (uint64_t)a.l[j] * b.l[i] + t[j];
-                C += (uint64_t)m * P::p(j) + (uint32_t)A;
-                t[j - 1] = (uint32_t)C;
-                A >>= 32;
-                C >>= 32;
+        // four 64-bit limbs, CIOS over unsigned __int128 (the transcript's host arithmetic -- normalising commitments,
+        // opening-point powers, evaluation batches -- sits between the phases of every proof)
+        typedef unsigned __int128 u128;
+        uint64_t A[4], B[4], M[4], t[6] = {0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            A[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+            B[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+            M[i] = (uint64_t)P::p(2 * i) | ((uint64_t)P::p(2 * i + 1) << 32);
+        }
+        // -p^-1 mod 2^64 from the 32-bit constant (one Newton step doubles the valid bits)
+        const uint64_t ninv32 = P::INV;
+        const uint64_t inv64 = ninv32 * (2 + M[0] * ninv32);  // (-x)(2 + m(-x)) = -(x(2 - mx)) for x = p^-1 mod 2^32
+        for (int i = 0; i < 4; i++) {
+            u128 c = 0;
+            for (int j = 0; j < 4; j++) {
+                c += (u128)A[j] * B[i] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
             }
-            t[7] = (uint32_t)(A + C);
+            c += t[4];
+            t[4] = (uint64_t)c;
+            t[5] = (uint64_t)(c >> 64);
+            const uint64_t m = t[0] * inv64;
+            c = (u128)m * M[0] + t[0];
+            c >>= 64;
+            for (int j = 1; j < 4; j++) {
+                c += (u128)m * M[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[4];
+            t[3] = (uint64_t)c;
+            t[4] = t[5] + (uint64_t)(c >> 64);
         }
         Fe o;
-#pragma unroll
-        for (int i = 0; i < 8; i++) o.l[i] = t[i];
+        for (int i = 0; i < 4; i++) {
+            o.l[2 * i] = (uint32_t)t[i];
+            o.l[2 * i + 1] = (uint32_t)(t[i] >> 32);
+        }
         reduce_once(o);
         return o;
 #endif
@@ -262,6 +278,70 @@ struct Field {
     // single lane has to do it (grand-product denominators, affine normalisation).  0 -> 0.
     static ZG_HD Fe inv(const Fe& a) {
         if (fe_is_zero(a)) return a;
+#if !defined(__HIP_DEVICE_COMPILE__)
+        // Host: the same algorithm on four 64-bit limbs (the inversion behind every commitment phase's affine
+        // normalisation sits on the critical path of a proof: 21 us with 32-bit limbs, 4 us this way).
+        {
+            typedef unsigned __int128 u128;
+            uint64_t pm4[4], u[4], v[4], x1[4] = {1, 0, 0, 0}, x2[4] = {0, 0, 0, 0};
+            for (int i = 0; i < 4; i++) {
+                pm4[i] = (uint64_t)P::p(2 * i) | ((uint64_t)P::p(2 * i + 1) << 32);
+                u[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+                v[i] = pm4[i];
+            }
+            auto add4 = [](uint64_t* o, const uint64_t* x, const uint64_t* y) {
+                u128 c = 0;
+                for (int i = 0; i < 4; i++) {
+                    c += (u128)x[i] + y[i];
+                    o[i] = (uint64_t)c;
+                    c >>= 64;
+                }
+                return (uint64_t)c;
+            };
+            auto sub4 = [](uint64_t* o, const uint64_t* x, const uint64_t* y) {  // returns the borrow
+                uint64_t b = 0;
+                for (int i = 0; i < 4; i++) {
+                    const uint64_t d = x[i] - y[i], b1 = x[i] < y[i];
+                    o[i] = d - b;
+                    b = b1 | (d < b);
+                }
+                return b;
+            };
+            auto shr1 = [](uint64_t* w, uint64_t top) {
+                for (int i = 0; i < 3; i++) w[i] = (w[i] >> 1) | (w[i + 1] << 63);
+                w[3] = (w[3] >> 1) | (top << 63);
+            };
+            auto is_one = [](const uint64_t* w) { return ((w[0] ^ 1ull) | w[1] | w[2] | w[3]) == 0; };
+            auto geq = [](const uint64_t* x, const uint64_t* y) {
+                for (int i = 3; i >= 0; i--)
+                    if (x[i] != y[i]) return x[i] > y[i];
+                return true;
+            };
+            auto halve_mod = [&](uint64_t* w) {
+                uint64_t carry = 0;
+                if (w[0] & 1ull) carry = add4(w, w, pm4);
+                shr1(w, carry);
+            };
+            auto sub_mod = [&](uint64_t* x, const uint64_t* y) {
+                if (sub4(x, x, y)) add4(x, x, pm4);
+            };
+            int budget = 1100;  // (see the device loop below: ends for every input)
+            while (!is_one(u) && !is_one(v) && budget > 0) {
+                while ((u[0] & 1ull) == 0 && --budget > 0) { shr1(u, 0); halve_mod(x1); }
+                while ((v[0] & 1ull) == 0 && --budget > 0) { shr1(v, 0); halve_mod(x2); }
+                --budget;
+                if (geq(u, v)) { sub4(u, u, v); sub_mod(x1, x2); }
+                else { sub4(v, v, u); sub_mod(x2, x1); }
+            }
+            const uint64_t* res = is_one(u) ? x1 : x2;
+            Fe r;
+            for (int i = 0; i < 4; i++) {
+                r.l[2 * i] = (uint32_t)res[i];
+                r.l[2 * i + 1] = (uint32_t)(res[i] >> 32);
+            }
+            return mul(mul(r, P::r2()), P::r2());
+        }
+#endif
         uint32_t pm[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) pm[i] = P::p(i);
@@ -303,15 +383,20 @@ struct Field {
             uint32_t borrow = sub8(x, x, y);
             if (borrow) add8(x, x, pm);
         };
-        while (!is_one(u) && !is_one(v)) {
-            while ((u[0] & 1u) == 0) {
+        // Every step removes a bit of u or v: 512 halvings end the loop for any input coprime to p.  The budget makes
+        // the loop end for EVERY input (a multiple of p, a wrong modulus): a wave that never finishes takes the GPU
+        // with it -- round 3 lost three runs to this loop when an edit dropped the initialisation of pm above.
+        int budget = 1100;
+        while (!is_one(u) && !is_one(v) && budget > 0) {
+            while ((u[0] & 1u) == 0 && --budget > 0) {
                 shr1(u, 0);
                 halve_mod(x1);
             }
-            while ((v[0] & 1u) == 0) {
+            while ((v[0] & 1u) == 0 && --budget > 0) {
                 shr1(v, 0);
                 halve_mod(x2);
             }
+            --budget;
             if (geq(u, v)) {
                 sub8(u, u, v);
                 sub_mod(x1, x2);

@@ -339,6 +339,9 @@ int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, co
 // ... and waits for ONLY that copy; with a sharded SRS the partial commitments of all ranks are exchanged
 // (all-gather) and summed here -- EC addition is not a reduction operator of the collective library
 int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
+    // (hipEventSynchronize already polls: the events are created without hipEventBlockingSync.  A hand-written
+    //  hipEventQuery loop in its place never saw the event complete on this runtime -- round 3, gpurun_out/r3_t3.log --
+    //  and bought nothing: the wait was never a sleep.)
     ZG_HIP(hipEventSynchronize(p->ev));
     const XYZZ* local = (const XYZZ*)((char*)p->pinned + p->pin_results);
     out.resize(count);

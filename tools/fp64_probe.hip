@@ -37,8 +37,9 @@ constexpr int64_t HI_BIAS = (int64_t)0x467ull << 52;  // bit pattern of 2^104
 constexpr int64_t LO_BIAS = (int64_t)0x433ull << 52;  // bit pattern of 2^52
 
 __device__ __forceinline__ void round_toward_zero_f64() {
-    // s_setreg_b32 hwreg(HW_REG_MODE, offset 2, size 2), 3
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);
+    // (inline asm: given the builtin, the compiler's mode-register pass puts the default mode back before the first
+    //  FP64 instruction)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
 }
 
 // a * b (0 <= a, b < 2^52, integers): hi = floor(ab / 2^52), lo = ab mod 2^52; both as the raw bit patterns of doubles
