@@ -49,7 +49,7 @@ import zg_halo2 as zg
 
 R = zg.FR_MODULUS
 MONT = (1 << 256) % R
-PROFILES = os.path.join(ROOT, "profiles", "r02")
+PROFILES = os.path.join(ROOT, "profiles", "r03")
 # the four configurations of BASELINE.json: (k, model); "large" is a seeded stand-in of the same shape
 # because model_49input_8192entry_4hash_6bpi.hdf5 is not in the reference checkout (.MISSING_LARGE_BLOBS)
 MODELS = {"tiny": wnn_model.MNIST_TINY, "small": wnn_model.MNIST_SMALL, "medium": wnn_model.MNIST_MEDIUM,
@@ -225,8 +225,8 @@ def family_of(kernel: str) -> str:
 
 
 def load_pmc():
-    """Counter figures of the same configuration (rocprofv3 --pmc passes, tools/pmc_round.py; committed under
-    profiles/r02): HBM bytes per launch per kernel and VALU wave-instructions per proof."""
+    """Counter figures of the same configuration (rocprofv3 --pmc passes, tools/profile_r03.sh + tools/install_r03.py;
+    committed under profiles/r03): HBM bytes per launch per kernel and VALU wave-instructions per proof."""
     try:
         return json.load(open(os.path.join(PROFILES, "pmc_traffic.json")))
     except (OSError, ValueError):
@@ -372,6 +372,21 @@ def measure(streams, ctxs, steps, warmup, barrier, profile=False):
     return dt, stats
 
 
+class stdout_to_stderr:
+    """RCCL and gloo announce themselves on STDOUT when a communicator / group comes up ("RCCL version : ...", "[Gloo] Rank 0
+    is connected to ..."); the contract is ONE json line there, so file descriptor 1 points at stderr meanwhile."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def latency_probe(stream: Stream):
     """One proof alone: transforms overlapped on a side stream, several lanes per EC addition (set_overlap(True))."""
     p, c = stream.prover, stream.c
@@ -433,22 +448,13 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        # RCCL announces itself on STDOUT when its communicator comes up ("RCCL version : ..."); the contract is
-        # ONE json line there, so file descriptor 1 points at stderr until the first collective has run
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():
             if backend == "nccl":
                 dist.init_process_group("nccl", device_id=dev)
             else:
                 dist.init_process_group(backend)
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
 
     sharded = args.mode == "shard-msm" and world > 1
     shard = (rank, world) if sharded else (0, 1)
@@ -465,12 +471,15 @@ def main():
         exchange_kind = args.exchange or ("rccl" if own_gpu else "host")
         # ONE exchange PER PROVER (prover i of every rank forms a group with prover i of the others): the provers of a
         # rank work through their phases independently, each on its own stream / host thread
-        if exchange_kind == "rccl":
-            exchanges = [multi_gpu.RcclComm(rank, world, dev_index, dist) for _ in range(nprov)]
-            rccl_ranks = exchanges[0].count()
-        else:
-            groups = [dist.new_group(backend=None) for _ in range(nprov)]  # (collective calls: same order on every rank)
-            exchanges = [multi_gpu.make_exchange(dist, dev if backend == "nccl" else None, g) for g in groups]
+        with stdout_to_stderr():
+            if exchange_kind == "rccl":
+                exchanges = [multi_gpu.RcclComm(rank, world, dev_index, dist) for _ in range(nprov)]
+                rccl_ranks = exchanges[0].count()
+            else:
+                groups = [dist.new_group(backend=None) for _ in range(nprov)]  # (collective calls: same order on every rank)
+                exchanges = [multi_gpu.make_exchange(dist, dev if backend == "nccl" else None, g) for g in groups]
+                for g in groups:  # (a group's transport comes up at its first collective: now, not inside the timed region)
+                    dist.barrier(group=g)
 
     ctx0 = zg.Ctx(dev_index)
     circuit = Circuit(ctx0, args.model, shard)
@@ -547,11 +556,20 @@ def main():
         if pmc and "valu" in pmc:
             per_proof = float(pmc["valu"]["wave_instructions_per_proof"])
             ach = per_proof / (ms_per_proof * 1e-3)
+            # three yardsticks: the architectural issue peak (one wave64 instruction per SIMD every 2 cycles: only
+            # v_mov-class instructions reach it), the 4-cycle rate the SQ counters price a VALU instruction at
+            # (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles; 2.1 GHz under this load), and the rate a pure stream of
+            # nine-limb Montgomery products sustains (tools/fp64_probe.hip: 173.9 G products/s x 236 instructions)
+            four_cycle = 256 * 4 * 2.1e9 / 4
+            product_loop = 173.9e9 * 236 / 64
             valu = {"wave_instructions_per_proof": per_proof, "achieved_wave_instr_per_s": ach,
                     "issue_peak_wave_instr_per_s": VALU_ISSUE_PEAK, "frac": ach / VALU_ISSUE_PEAK,
                     "peak_note": "one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32), 256 CUs x 4 SIMDs x 2.4 GHz",
-                    "v_add_co_u32_stream_rate_wave_instr_per_s": 31263.2e9 / 64,
-                    "frac_of_v_add_co_u32_stream_rate": ach / (31263.2e9 / 64),
+                    "four_cycle_issue_rate_wave_instr_per_s": four_cycle, "frac_of_four_cycle_issue_rate": ach / four_cycle,
+                    "nine_limb_product_loop_rate_wave_instr_per_s": product_loop,
+                    "frac_of_nine_limb_product_loop_rate": ach / product_loop,
+                    "per_kernel_alone": "profiles/r03/sq_issue.json (ntt 0.93-0.98, evaluate_h 0.74, msm_accumulate 0.66 of the "
+                                        "4-cycle rate when alone on the chip; the reductions 0.03-0.12)",
                     "source": pmc["valu"].get("source")}
         cs = circuit.cs
         out = {
