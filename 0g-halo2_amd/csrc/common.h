@@ -203,6 +203,7 @@ enum Knob : int {
     K_EVALH_GROUPED,  // 0 = evaluate_h folds in y term by term
     K_EVALH9,         // 0 = evaluate_h on 8 x 32-bit limbs (implies the single extended coset)
     K_SPLIT_DOMAIN,   // 0 = EvaluationDomain's single extended coset in the throughput form too
+    K_LAT_SPLIT_K,    // smallest k at which a LONE proof (latency form) takes the quotient from the split domain as well
     K_COUNT
 };
 int knob(Knob k);

@@ -997,7 +997,10 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     const int k_env = knob(K_MSM_K);
     // (a lone k = 14 proof with 12 / 16 / 24 / 32 / 48 points per task: 3.38 / 3.01 / 3.15 / 3.21 / 3.42 ms)
     const int kl_env = knob(K_MSM_K_LAT);
-    const uint32_t MSM_K = ctx->msm_pair ? (kl_env >= 4 && kl_env <= 120 ? (uint32_t)kl_env : MSM_K_LATENCY)
+    // (... and at n = 2^17, where a lone launch fills the chip several times over, longer tasks win again -- fewer
+    //  partial sums to merge: 16 / 32 / 48 -> 10.56 / 10.34 / 10.23 ms for a lone k = 17 proof; 8: every bucket turns hot, 36 ms)
+    const uint32_t k_lat_default = n >= (1u << 17) ? 48u : n >= (1u << 16) ? 32u : MSM_K_LATENCY;
+    const uint32_t MSM_K = ctx->msm_pair ? (kl_env >= 4 && kl_env <= 120 ? (uint32_t)kl_env : k_lat_default)
                                          : (k_env >= 4 && k_env <= 120 ? (uint32_t)k_env : MSM_K_THROUGHPUT);
     const uint64_t entries = (uint64_t)N * W;
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");

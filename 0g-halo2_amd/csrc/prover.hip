@@ -142,6 +142,9 @@ struct zg_prover {
     };
     std::shared_ptr<OwnedBases> owned_bases;
     bool use_side = true;   // coefficient / coset forms on a side stream (latency) or inline (throughput)
+    // what a LONE proof (latency form) borrows from the throughput form once the circuit is large enough for the work
+    // to outweigh the launches (from k: K_LAT_SPLIT_K)
+    bool lat_split = false;
     uint32_t naf_gl_w = 0;  // digit width of the run-form commitments' free-position form, 0 = windows (naf_gl_default)
     // point-range shard of the commitments (zg_prover_set_shard): this prover's base sets hold points
     // [shard_lo, shard_lo + shard_n) of the SRS; partial commitments of all ranks are exchanged and summed
@@ -192,6 +195,14 @@ struct zg_prover {
 };
 
 namespace {
+
+// A lone proof of a LARGER circuit is bound by work, not by launches: from this size on it takes the quotient from the
+// split domain as the throughput form does (39n instead of 68n butterflies per polynomial, 5n instead of 8n evaluate_h
+// rows), its coset transforms still phase by phase on the side stream.  gpurun_out/lone_forms3/4.txt -> profiles/r03/
+// lone_forms.txt: k = 14 2.96 -> 3.10 ms (the interpolation's extra launches), k = 15 4.24 -> 4.19 (small) and 4.34 ->
+// 4.33 (medium), k = 17 11.74 -> 10.39.  (The bit-position tables lose at every size for a lone proof -- k = 17: 11.57 ->
+// 11.74 -- and stay a throughput-form choice.)
+constexpr int LAT_SPLIT_K_DEFAULT = 15;
 
 template <class T>
 int dalloc_into(std::vector<void*>& owned, T** out, size_t count) {
@@ -290,6 +301,11 @@ static uint32_t naf_gl_default(const zg_bases* gl) {
     return w >= 3 && w <= 16 ? w : 0u;
 }
 static uint32_t naf_gl_width(const zg_prover* p) { return p->naf_gl_w; }
+
+static bool lone_split(const zg_prover* p, bool latency_form) {
+    const int sk = knob(K_LAT_SPLIT_K);
+    return latency_form && p->pk->k >= (uint32_t)(sk >= 0 ? sk : LAT_SPLIT_K_DEFAULT);
+}
 
 // the table of g for the all-random commitments (the quotient pieces, the opening quotients): its bit-position table in
 // the throughput form, recoded at the width the table was made for
@@ -969,6 +985,7 @@ static int prover_create_impl(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fi
         ZG_TRY(get_twiddles(ctx, d.ek, ext_omega, &d.ext_tw));
     }
     ZG_HIP(hipStreamSynchronize(st));
+    p->lat_split = lone_split(p, p->use_side);  // (a prover starts in the latency form)
     ZG_TRY(alloc_slots(p, 1));
     *out = guard.release();
     return ZG_OK;
@@ -1011,6 +1028,7 @@ int zg_prover_fork(const zg_prover* parent, zg_ctx* ctx, zg_prover** out) {
     p->gl = parent->gl;
     p->owned_bases = parent->owned_bases;  // (joint ownership; null when the caller registered the tables)
     p->use_side = parent->use_side;
+    p->lat_split = parent->lat_split;
     p->naf_gl_w = parent->naf_gl_w;
     p->shard_lo = parent->shard_lo; p->shard_n = parent->shard_n; p->world = parent->world; p->rank = parent->rank;
     p->exchange = parent->exchange; p->exchange_user = parent->exchange_user;
@@ -1097,7 +1115,10 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     const uint32_t A = pk.A, I = pk.I, P = pk.P, NL = pk.NL, S = pk.sets, Q = pk.qpd;
     const bool hat = pk.hat;
     // extended-domain parts of this proof: the split pair in the throughput configuration, the single coset otherwise
-    const bool split = pk.nparts == 3 && !p->use_side;
+    const bool split = pk.nparts == 3 && (!p->use_side || p->lat_split);
+    // the coset forms of a phase's columns: on the side stream while that phase's commitments run (latency form), or all
+    // at once before evaluate_h (throughput form)
+    const bool phase_cosets = p->use_side || !split;
     const uint32_t dlo = split ? 1u : 0u, dhi = split ? 3u : 1u;
     // strides between consecutive proofs
     const size_t pp_bs = (size_t)p->npp * n, adv_bs = (size_t)A * n, inst_bs = (size_t)I * n, perm_bs = (size_t)(2 * NL + 1) * n,
@@ -1201,13 +1222,13 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     if (I) {
         const Grouping g = grouping(I, inst_bs, pp_bs);
         ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, pp_at(p->ix_inst), n, (size_t)nb * I, k, pk.omega_inv, &pk.ifft_div, &g));
-        if (!split) ZG_TRY(to_cosets(sx, p->ix_inst, I));
+        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_inst, I));
     }
     if (A) {
         ZG_TRY(commit(p, p->gl, nullptr, A, adv, n, A, adv_bs, (size_t)nb * A, 0));
         const Grouping g = grouping(A, adv_bs, pp_bs);
         ZG_TRY(ntt_batch_to_dev(sx, adv, pp_at(p->ix_adv), n, (size_t)nb * A, k, pk.omega_inv, &pk.ifft_div, &g));
-        if (!split) ZG_TRY(to_cosets(sx, p->ix_adv, A));
+        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_adv, A));
         ZG_TRY(wait_points(p, (size_t)nb * A, pts));
         for (uint32_t b = 0; b < nb; b++)
             for (uint32_t c = 0; c < A; c++) tr[b].write_point(pts[(size_t)b * A + c]);
@@ -1252,7 +1273,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
             const Grouping g = grouping(2 * NL, perm_bs, pp_bs);
             ZG_TRY(ntt_batch_to_dev(sx, p->perm, pp_at(p->ix_perm), n, (size_t)nb * 2 * NL, k, pk.omega_inv, &pk.ifft_div, &g));
         }
-        if (!split) ZG_TRY(to_cosets(sx, p->ix_perm, 2 * NL));
+        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_perm, 2 * NL));
         ZG_TRY(wait_points(p, (size_t)nb * (2 * NL + 1), pts));
         for (uint32_t b = 0; b < nb; b++) {
             for (uint32_t l = 0; l < NL; l++)
@@ -1309,7 +1330,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
             const Grouping g = grouping(mb, zs_bs, pp_bs);
             ZG_TRY(ntt_batch_to_dev(sx, p->zs, pp_at(p->ix_pz), n, (size_t)nb * mb, k, pk.omega_inv, &pk.ifft_div, &g));
         }
-        if (!split) ZG_TRY(to_cosets(sx, p->ix_pz, mb));
+        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_pz, mb));
         ZG_TRY(wait_points(p, (size_t)nb * per, pts));
         for (uint32_t b = 0; b < nb; b++) {
             const Jac* q = &pts[(size_t)b * per];
@@ -1329,9 +1350,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     ZG_TRY(upload_consts(p, nb));
     lap(2);
 
-    // (split form: nothing overlaps in the throughput configuration, so every witness polynomial goes to both cosets
-    //  here, in one batch per coset, instead of phase by phase)
-    if (split) ZG_TRY(to_cosets(ctx, p->ix_adv, p->ncos));
+    // (throughput configuration: nothing overlaps, so every witness polynomial goes to its cosets here, in one batch per
+    //  coset, instead of phase by phase)
+    if (!phase_cosets) ZG_TRY(to_cosets(ctx, p->ix_adv, p->ncos));
     // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
     for (uint32_t di = dlo; di < dhi; di++) {
         const EvalHArgs a = evalh_args(p, di);
@@ -1586,6 +1607,7 @@ int zg_prover_set_overlap(zg_prover* p, int enable) {
     }
     p->use_side = enable != 0;
     p->ctx->msm_pair = enable != 0;  // latency configuration: two lanes per addition in the MSM reduction
+    p->lat_split = lone_split(p, enable != 0);
     return ZG_OK;
 }
 

@@ -67,7 +67,7 @@ const char *zg_version(void);
  * result: every form computes the same group elements and field elements, bit for bit (tests/test_gpu_knobs.py walks
  * them all against the oracle).  Knobs that shape resident data are read when that object is built (ZG_MSM_C: a base
  * set registered with window_bits = 0; ZG_MSM_NAF, ZG_MSM_NAF_GL, ZG_MSM_RUNS, ZG_EVALH9, ZG_EVALH_GROUPED,
- * ZG_SPLIT_DOMAIN: zg_prover_create*), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
+ * ZG_SPLIT_DOMAIN: zg_prover_create*; ZG_LAT_SPLIT_K: zg_prover_create* and zg_prover_set_overlap), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
  * ZG_MSM_STRIP).
  *   ZG_MSM_C          window bits of the MSM tables, 2..16 (default from n: k - 2)
  *   ZG_MSM_K          points per bucket-accumulation task in the throughput form, 4..120 (48)
@@ -80,7 +80,8 @@ const char *zg_version(void);
  *   ZG_MSM_RUNS       0 = no run form (summation by parts over running base sums)
  *   ZG_EVALH_GROUPED  0 = evaluate_h folds in y term by term (the fallback of circuits with > 40 such terms)
  *   ZG_EVALH9         0 = evaluate_h on 8 x 32-bit limbs; implies the single extended coset
- *   ZG_SPLIT_DOMAIN   0 = EvaluationDomain's single extended coset in the throughput form too */
+ *   ZG_SPLIT_DOMAIN   0 = EvaluationDomain's single extended coset in the throughput form too
+ *   ZG_LAT_SPLIT_K    smallest k at which a lone proof (the latency form) takes the quotient from the split domain too (17) */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */

@@ -3,6 +3,12 @@ import os
 import sys
 
 import pytest
+# PyTorch-ROCm ships its OWN HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7); libzg_halo2.so needs
+# libamdhip64.so.7 as well.  Whichever is loaded first decides: with torch first the loader hands libzg torch's copy (one
+# runtime in the process); with libzg first /opt/rocm's copy is loaded, torch brings its own beside it, and the SECOND
+# runtime to initialise finds no device ("No HIP GPUs are available" / ZG_ERR_NO_DEVICE -- the round-2 incident, DESIGN.md
+# toolchain notes).  So: torch before anything can load the library, in every process that uses both.
+import torch  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "0g-halo2_amd"))

@@ -30,12 +30,14 @@ SETTINGS = {
     "ZG_EVALH_GROUPED": [0],
     "ZG_EVALH9": [0],
     "ZG_SPLIT_DOMAIN": [0],
+    "ZG_LAT_SPLIT_K": [0, 99],
 }
 # knobs that act together: walked as pairs as well
 PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2, 4)] + [
     {"ZG_MSM_NAF": 0, "ZG_MSM_NAF_GL": 0, "ZG_MSM_RUNS": 0},   # plain window tables everywhere
     {"ZG_EVALH9": 0, "ZG_EVALH_GROUPED": 0},
     {"ZG_MSM_C": 6, "ZG_MSM_NAF_GL": 0},
+    {"ZG_LAT_SPLIT_K": 0, "ZG_SPLIT_DOMAIN": 0},
 ]
 CASES = [{k: v} for k, vs in SETTINGS.items() for v in vs] + PAIRS
 

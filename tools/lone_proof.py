@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A few lone proofs of the headline circuit in the latency form (for rocprofv3 --kernel-trace + tools/timeline.py)."""
+"""A few lone proofs of a model's circuit in both scheduling forms (for rocprofv3 --kernel-trace + tools/timeline.py):
+    python tools/lone_proof.py [tiny|small|medium|large] [latency|throughput|both]"""
 import os
 import sys
 import time
@@ -11,12 +12,19 @@ import bench  # noqa: E402  (sets the paths and GPU_MAX_HW_QUEUES)
 zg = bench.zg
 ctx = zg.Ctx(0)
 c = bench.Circuit(ctx, sys.argv[1] if len(sys.argv) > 1 else "tiny")
+which = sys.argv[2] if len(sys.argv) > 2 else "both"
 p = zg.Prover(ctx, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
-p.set_overlap(True)
-for i in range(4):
-    p.prove(c.advice, c.instance, i)
-t0 = time.perf_counter()
-for i in range(4):
-    p.prove_dev(p.advice_slot(0), c.instance, 10 + i)
-print("lone proof ms", (time.perf_counter() - t0) / 4 * 1e3, p.phase_ms())
+for form, overlap in (("latency", True), ("throughput", False)):
+    if which not in (form, "both"):
+        continue
+    p.set_overlap(overlap)
+    for i in range(3):
+        p.prove(c.advice, c.instance, i)
+    each = []
+    for i in range(5):
+        t0 = time.perf_counter()
+        p.prove_dev(p.advice_slot(0), c.instance, 10 + i)
+        each.append((time.perf_counter() - t0) * 1e3)
+    print(f"{c.model} k={c.k} lone proof, {form} form: {sorted(each)[2]:.3f} ms (median of 5: {[round(x, 2) for x in each]})",
+          [round(x, 3) for x in p.phase_ms()])
 p.close()
