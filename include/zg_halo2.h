@@ -71,7 +71,7 @@ const char *zg_version(void);
  * ZG_MSM_STRIP).
  *   ZG_MSM_C          window bits of the MSM tables, 2..16 (default from n: k - 2)
  *   ZG_MSM_K          points per bucket-accumulation task in the throughput form, 4..120 (48)
- *   ZG_MSM_K_LAT      ... in the latency form (16)
+ *   ZG_MSM_K_LAT      ... in the latency form (16; 32 / 48 from n = 2^16 / 2^17)
  *   ZG_MSM_RB         buckets per block of the latency form's bucket reduction: 64 / 128 / 256
  *   ZG_MSM_LANES      lanes per EC addition there: 2 / 4
  *   ZG_MSM_STRIP      buckets per lane in the throughput form's reduction: 2 / 4 / 8 / 16 (8)
@@ -81,7 +81,7 @@ const char *zg_version(void);
  *   ZG_EVALH_GROUPED  0 = evaluate_h folds in y term by term (the fallback of circuits with > 40 such terms)
  *   ZG_EVALH9         0 = evaluate_h on 8 x 32-bit limbs; implies the single extended coset
  *   ZG_SPLIT_DOMAIN   0 = EvaluationDomain's single extended coset in the throughput form too
- *   ZG_LAT_SPLIT_K    smallest k at which a lone proof (the latency form) takes the quotient from the split domain too (17) */
+ *   ZG_LAT_SPLIT_K    smallest k at which a lone proof (the latency form) takes the quotient from the split domain too (15) */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */
