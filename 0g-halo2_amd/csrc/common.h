@@ -134,6 +134,14 @@ struct zg_bases {
     // > 0: this table holds 2^j * P_i for EVERY bit position j (c = 1, 255 rows) and is multiplied with odd signed
     // digits of naf_w bits at free positions (msm.hip msm_digits_naf_kernel); only a `dense` table is built that way
     uint32_t naf_w = 0;
+    // Digit tables for the LATENCY form (bases_enable_full): EVERY multiple d * 2^(full_c w) * P_i, d = 1 .. 2^(full_c - 1),
+    // of every window -- [full_windows][2^(full_c-1)][n] affine points (26 GB at n = 2^14, c = 11: what 288 GB of HBM
+    // are for).  A lone MSM then needs no buckets at all: every signed digit names its summand, and the sum of n * W
+    // gathered points is a flat accumulation + a tree (msm_accumulate_full / msm_tree kernels) -- no digit sort, no
+    // bucket reduction.  Published like `dense` (complete before the pointer is stored).
+    std::atomic<zg::Affine*> full_table{nullptr};
+    std::atomic<zg::Affine*> full_run_table{nullptr};  // the same for the running sums (run-form commitments)
+    uint32_t full_c = 0, full_windows = 0;
     std::mutex mu;
 };
 
@@ -204,6 +212,8 @@ enum Knob : int {
     K_EVALH9,         // 0 = evaluate_h on 8 x 32-bit limbs (implies the single extended coset)
     K_SPLIT_DOMAIN,   // 0 = EvaluationDomain's single extended coset in the throughput form too
     K_LAT_SPLIT_K,    // smallest k at which a LONE proof (latency form) takes the quotient from the split domain as well
+    K_LAT_FULL_C,     // window bits of the latency form's digit tables (every multiple of every window); 0 = none
+    K_LAT_FULL_K,     // summands per lane pair in the digit-table accumulation (4..120)
     K_COUNT
 };
 int knob(Knob k);

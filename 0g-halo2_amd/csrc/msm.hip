@@ -934,6 +934,260 @@ int bases_enable_runs(zg_ctx* ctx, zg_bases* b) {
     return ZG_OK;
 }
 
+// ---------------------------------------------------------------- digit tables: the latency form without buckets
+// A lone proof's MSM is a chain of latency-bound launches -- digit sort, bucket accumulation, hot buckets, a suffix scan
+// and a block sum whose ~27 dependent EC additions per vector cost 3.9 us each -- on a chip that is otherwise idle.  The
+// base sets are FIXED and HBM is 288 GB: with a table of EVERY multiple d * 2^(c w) * P_i (d = 1 .. 2^(c-1), every window
+// w; c = 11: 24 x 1024 x n x 64 B = 26 GB per base set at n = 2^14) a signed digit names its summand directly, and
+//     sum_i s_i P_i = sum over the n * W non-zero digits of  +- table[w][|d|][i]
+// is a flat sum of gathered affine points: lane pairs add K summands each (xmadd_pair, as the bucket accumulation does),
+// and two tree kernels fold the partial sums -- 3 + 6 additions deep, then ceil(P / 16384) + 6 -- with no histogram, no
+// scan, no scatter, no buckets and no weights.  Same group element, same bytes.
+constexpr uint32_t MSM_FULL_MIN_C = 4, MSM_FULL_MAX_C = 12;
+constexpr uint32_t MSM_FULL_K = 16;        // summands per lane pair (K_LAT_FULL_K)
+constexpr uint32_t MSM_TREE_GROUPS = 64;   // additions in flight per workgroup of the tree kernels (4 lanes each)
+
+// full[(w * D + d - 1) * n + i] = d * win[w][i] for d = 1 .. D, affine, in the x * 2^261 form of every MSM table.  One
+// lane per (i, w): a chain of mixed additions, every multiple normalised by an inversion of its own (build time only).
+__global__ __launch_bounds__(64) void msm_full_table_kernel(const Affine* __restrict__ win, Affine* __restrict__ full, uint32_t n,
+                                                            uint32_t D, Fe un) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
+    if (i >= n) return;
+    const Fe c261 = Fq9Params::c261_fe();
+    Affine p;  // library form
+    p.x = Fq::mul(ld_fe_g(&win[(size_t)w * n + i].x), un);
+    p.y = Fq::mul(ld_fe_g(&win[(size_t)w * n + i].y), un);
+    Affine* dst = full + (size_t)w * D * n + i;
+    if (affine_is_identity(p)) {
+        for (uint32_t d = 0; d < D; d++) {
+            st_fe_g(&dst[(size_t)d * n].x, fe_zero());
+            st_fe_g(&dst[(size_t)d * n].y, fe_zero());
+        }
+        return;
+    }
+    XYZZ acc = xyzz_from_affine(p);
+    st_fe_g(&dst[0].x, Fq::mul(p.x, c261));
+    st_fe_g(&dst[0].y, Fq::mul(p.y, c261));
+    for (uint32_t d = 1; d < D; d++) {
+        acc = xyzz_madd(acc, p);  // (d + 1) P: never the identity, never P again -- P has prime order r > D
+        const Affine a = xyzz_to_affine(acc);
+        st_fe_g(&dst[(size_t)d * n].x, Fq::mul(a.x, c261));
+        st_fe_g(&dst[(size_t)d * n].y, Fq::mul(a.y, c261));
+    }
+}
+
+// One lane PAIR per task: pair t adds the summands of the digit entries e = t, t + tasks, t + 2 tasks, ... (dig[b][w][i] in
+// memory order, as msm_digits_kernel writes them: magnitude | sign << 31, 0 = none); the summand of entry e = w * n + i with
+// digit d is table[(w * D + |d| - 1) * n_table + i].  STRIDED, not consecutive: the non-zero digits of a sparse column (only
+// its lowest windows) or of a half-empty run-form column then spread over all pairs instead of filling a few of them --
+// the launch is as long as its longest pair -- and a wave's reads of the digit array are coalesced.  The table point of
+// the NEXT entry is requested before the current one is added: a gather from a 26 GB table (an HBM and a TLB miss) takes
+// as long as the addition it hides behind.
+__global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
+    const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table, uint32_t D,
+    uint32_t windows, uint32_t n, const uint32_t* __restrict__ dig, uint32_t tasks, XYZZ9* __restrict__ partial,
+    const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask, uint32_t per) {
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = lane >> 1;
+    const bool role_a = (lane & 1u) == 0;
+    const uint32_t b = blockIdx.y;
+    if (t >= tasks) return;  // (pairs are never split: 2 * tasks lanes, even block size)
+    const uint32_t vj = b % per;
+    const bool runs = vj < 64 && ((run_mask >> vj) & 1ull);
+    const Affine* table = vj < split ? (runs ? run_a : table_a) : (runs ? run_b : table_b);
+    const uint32_t entries = n * windows;
+    const uint32_t* d = dig + (size_t)b * entries;
+    const uint32_t step_w = tasks / n, step_i = tasks - step_w * n;  // one stride in (window, point) coordinates
+    uint32_t e = t, w = t / n, i = t - w * n;
+    // the entry in hand: its digit word and, when that is non-zero, its table point (packed, as loaded)
+    uint32_t ent = d[e];
+    Fe px = fe_zero(), py = fe_zero();
+    if (ent & 0xffffu) {
+        const Affine* src = table + ((size_t)w * D + ((ent & 0xffffu) - 1)) * n_table + i;
+        px = ld_fe_g(&src->x);
+        py = ld_fe_g(&src->y);
+    }
+    PairAcc acc;
+    bool inf = true;
+    for (;;) {
+        // request the next entry's point first ...
+        const uint32_t e2 = e + tasks;
+        uint32_t w2 = w + step_w, i2 = i + step_i;
+        if (i2 >= n) {
+            i2 -= n;
+            w2++;
+        }
+        uint32_t ent2 = 0;
+        Fe nx = fe_zero(), ny = fe_zero();
+        if (e2 < entries) {
+            ent2 = d[e2];
+            if (ent2 & 0xffffu) {
+                const Affine* src = table + ((size_t)w2 * D + ((ent2 & 0xffffu) - 1)) * n_table + i2;
+                nx = ld_fe_g(&src->x);
+                ny = ld_fe_g(&src->y);
+            }
+        }
+        // ... then add the one in hand
+        if (ent & 0xffffu) {
+            const F9 qx = f9_unpack(px);
+            F9 qy = f9_unpack(py);
+            if (!(f9_limbs_zero(qx) && f9_limbs_zero(qy))) {  // (identity base point)
+                if (ent >> 31) qy = f9_neg(qy);
+                xmadd_pair(acc, inf, qx, qy, role_a);
+            }
+        }
+        if (e2 >= entries) break;
+        e = e2; w = w2; i = i2; ent = ent2; px = nx; py = ny;
+    }
+    XYZZ9* dst = partial + (size_t)b * tasks + t;
+    if (inf) {
+        if (role_a) st_xyzz9(dst, xyzz9_identity());
+    } else if (role_a) {
+        st_f9(&dst->x, acc.m);
+        st_f9(&dst->zz, acc.z);
+    } else {  // (lane B holds Y and ZZZ: PairAcc)
+        st_f9(&dst->y, acc.m);
+        st_f9(&dst->zzz, acc.z);
+    }
+}
+
+// Folds `count` points per vector: workgroup blk of vector b sums in[b * count + blk * 64 G ..) -- every one of its 64
+// four-lane groups adds G strided inputs in sequence, then a 6-level tree -- into out[b * gridDim.x + blk], or, as the
+// last stage (gridDim.x == 1), into the vector's result in the library's packed form.
+__global__ __launch_bounds__(4 * MSM_TREE_GROUPS) void msm_tree_kernel(const XYZZ9* __restrict__ in, uint32_t count, uint32_t G,
+                                                                        XYZZ9* __restrict__ out, XYZZ* __restrict__ final_out) {
+    __shared__ XYZZ9 sh[MSM_TREE_GROUPS];
+    const uint32_t j = threadIdx.x >> 2, role = threadIdx.x & 3u;
+    const uint32_t blk = blockIdx.x, b = blockIdx.y;
+    const XYZZ9* src = in + (size_t)b * count;
+    const uint32_t base = blk * MSM_TREE_GROUPS * G;
+    if (role == 0) sh[j] = xyzz9_identity();
+    for (uint32_t s = 0; s < G; s++) {
+        const uint32_t idx = base + s * MSM_TREE_GROUPS + j;
+        if (idx < count) xstore<true>(&sh[j], xaddl<4>(&sh[j], src + idx, role));
+    }
+    __syncthreads();
+    for (uint32_t o = MSM_TREE_GROUPS / 2; o > 0; o >>= 1) {
+        if (j < o) xstore<true>(&sh[j], xaddl<4>(&sh[j], &sh[j + o], role));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (final_out) st_xyzz(final_out + b, xyzz9_to_xyzz(sh[0], false));
+        else st_xyzz9(out + (size_t)b * gridDim.x + blk, sh[0]);
+    }
+}
+
+// window bits of a set's digit tables: the largest c whose three tables of a prover (g, g_lagrange, its running sums)
+// stay under 90 GB -- 11 at n = 2^14 (3 x 26 GB), 10 at 2^15 (3 x 28 GB) -- and none from n = 2^16 on, where
+// a lone proof is bound by its work and the windows' extra additions would cost more than the buckets they remove.
+static uint32_t default_full_bits(size_t n) {
+    const int env = knob(K_LAT_FULL_C);
+    if (env == 0) return 0;
+    if (env >= (int)MSM_FULL_MIN_C && env <= (int)MSM_FULL_MAX_C) return (uint32_t)env;
+    if (n >= ((size_t)1 << 16)) return 0;
+    uint32_t lg = 0;
+    while (((size_t)2 << lg) <= n) lg++;
+    // (small sets: windows of lg n - 3 bits keep the table at ~n^2 / 8 points; large ones: what the memory allows)
+    uint32_t c = lg > MSM_FULL_MIN_C + 3 ? lg - 3 : MSM_FULL_MIN_C;
+    if (c > MSM_FULL_MAX_C) c = MSM_FULL_MAX_C;
+    for (; c > MSM_FULL_MIN_C; c--) {
+        const double bytes = 3.0 * (double)((255 + c - 1) / c) * (double)(1u << (c - 1)) * (double)n * sizeof(Affine);
+        if (bytes <= 90e9) break;
+    }
+    return c;
+}
+
+static int build_full_table(zg_ctx* ctx, const Affine* table0_hat, size_t n, uint32_t c, Affine** out) {
+    const uint32_t W = (255 + c - 1) / c, D = 1u << (c - 1);
+    const size_t bytes = (size_t)W * D * n * sizeof(Affine);
+    size_t free_b = 0, total_b = 0;
+    ZG_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (bytes + ((size_t)8 << 30) > free_b) {  // (not an error: the caller keeps the bucket form)
+        *out = nullptr;
+        return ZG_OK;
+    }
+    WsScope ws(ctx);
+    Affine* lib = ws.get<Affine>(n);               // the points in the library form
+    Affine* win = ws.get<Affine>((size_t)W * n);   // 2^(c w) P_i, x * 2^261 form
+    if (ws.failed) return ZG_ERR_OOM;
+    const Fe un = Fq::inv(Fq9Params::c261_fe());
+    hipLaunchKernelGGL(msm_untable_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, table0_hat, lib, (uint32_t)n, un);
+    hipLaunchKernelGGL(msm_table_kernel, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, ctx->stream, lib, win, (uint32_t)n, c, W);
+    Affine* full = nullptr;
+    hipError_t e = hipMalloc(&full, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return ZG_OK;
+    }
+    hipLaunchKernelGGL(msm_full_table_kernel, dim3((uint32_t)((n + 63) / 64), W), dim3(64), 0, ctx->stream, win, full, (uint32_t)n, D, un);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(full);
+        set_error("bases_enable_full: %s", hipGetErrorString(e));
+        return ZG_ERR_HIP;
+    }
+    *out = full;
+    return ZG_OK;
+}
+
+int bases_enable_full(zg_ctx* ctx, zg_bases* b, uint32_t window_bits, bool with_runs) {
+    std::lock_guard<std::mutex> lock(b->mu);
+    uint32_t c = b->full_c ? b->full_c : window_bits ? window_bits : default_full_bits(b->n);
+    if (c == 0) return ZG_OK;
+    ZG_REQUIRE(c >= MSM_FULL_MIN_C && c <= MSM_FULL_MAX_C, ZG_ERR_INVALID_ARG, "bases_enable_full: window_bits %u not in [4,12]", c);
+    ZG_REQUIRE(!b->full_c || !window_bits || window_bits == b->full_c, ZG_ERR_INVALID_ARG,
+               "zg_bases_enable_digit_table: the base set already has digit tables of %u-bit windows", b->full_c);
+    if (!b->full_table.load(std::memory_order_acquire)) {
+        Affine* t = nullptr;
+        ZG_TRY(build_full_table(ctx, b->table, b->n, c, &t));
+        if (!t) return ZG_OK;  // (no room: the bucket form stays)
+        b->full_c = c;
+        b->full_windows = (255 + c - 1) / c;
+        b->full_table.store(t, std::memory_order_release);
+    }
+    if (with_runs && b->run_table && !b->full_run_table.load(std::memory_order_acquire)) {
+        Affine* t = nullptr;
+        ZG_TRY(build_full_table(ctx, b->run_table, b->n, b->full_c, &t));
+        if (t) b->full_run_table.store(t, std::memory_order_release);
+    }
+    return ZG_OK;
+}
+
+// The latency form of msm_batch4_dev over digit tables (conditions checked by the caller).
+static int msm_full_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, size_t split, const Fe* d_scalars, size_t stride,
+                        size_t per, size_t outer, size_t batch, size_t n, XYZZ* d_out, uint64_t run_mask) {
+    const uint32_t c = bases->full_c, W = bases->full_windows, D = 1u << (c - 1);
+    const uint32_t B = (uint32_t)batch, N = (uint32_t)n;
+    const uint64_t entries = (uint64_t)N * W;
+    ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
+    const int k_env = knob(K_LAT_FULL_K);
+    const uint32_t K = k_env >= 4 && k_env <= 120 ? (uint32_t)k_env : MSM_FULL_K;
+    const uint32_t tasks = (uint32_t)((entries + K - 1) / K);
+    // tree: stage 1 folds 256 partial sums per workgroup (4 per group), stage 2 the rest in one workgroup per vector
+    const uint32_t G1 = 4, n1 = (tasks + MSM_TREE_GROUPS * G1 - 1) / (MSM_TREE_GROUPS * G1);
+    const uint32_t G2 = (n1 + MSM_TREE_GROUPS - 1) / MSM_TREE_GROUPS;
+    WsScope ws(ctx);
+    uint32_t* dig = ws.get<uint32_t>((size_t)B * entries);
+    XYZZ9* partial = ws.get<XYZZ9>((size_t)B * tasks);
+    XYZZ9* stage = ws.get<XYZZ9>((size_t)B * n1);
+    if (ws.failed) return ZG_ERR_OOM;
+    const double msm_bytes = (double)B * ((double)N * 96.0 + 96.0);
+    const Affine *ta = bases->full_table.load(std::memory_order_acquire), *tb = bases_b ? bases_b->full_table.load(std::memory_order_acquire) : ta;
+    const Affine *ra = bases->full_run_table.load(std::memory_order_acquire),
+                 *rb = bases_b ? bases_b->full_run_table.load(std::memory_order_acquire) : ra;
+    ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, (uint32_t)per,
+              outer, N, c, W, 0u, dig, run_mask);
+    ZG_LAUNCH(ctx, "msm_accumulate_full", msm_bytes, msm_accumulate_full_kernel, dim3((2 * tasks + 255) / 256, B), dim3(256), 0, ta, tb,
+              (uint32_t)split, (uint32_t)bases->n, D, W, N, dig, tasks, partial, ra, rb, run_mask, (uint32_t)per);
+    ZG_LAUNCH(ctx, "msm_tree", msm_bytes, msm_tree_kernel, dim3(n1, B), dim3(4 * MSM_TREE_GROUPS), 0, partial, tasks, G1, stage,
+              (XYZZ*)nullptr);
+    ZG_LAUNCH(ctx, "msm_tree", msm_bytes, msm_tree_kernel, dim3(1, B), dim3(4 * MSM_TREE_GROUPS), 0, stage, n1, G2, (XYZZ9*)nullptr, d_out);
+    ZG_HIP(hipGetLastError());
+    return ZG_OK;
+}
+
 int msm_batch_dev(zg_ctx* ctx, const zg_bases* bases, const Fe* d_scalars, size_t stride, size_t batch,
                   size_t n, XYZZ* d_out) {
     // (a base set with a bit-position table, zg_bases_enable_bit_table, is multiplied in the free-position form by a
@@ -993,6 +1247,14 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         ZG_HIP(hipMemcpyAsync(d_out, ids.data(), batch * sizeof(XYZZ), hipMemcpyHostToDevice, ctx->stream));
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         return ZG_OK;
+    }
+    if (ctx->msm_pair && !naf && bases->full_table.load(std::memory_order_acquire) &&
+        (!bases_b || (bases_b->full_table.load(std::memory_order_acquire) && bases_b->full_c == bases->full_c))) {
+        // latency form over digit tables -- when every table this launch names exists
+        const uint64_t mask_a2 = split >= 64 ? ~0ull : (1ull << split) - 1ull;
+        const bool runs_ok = ((run_mask & mask_a2) == 0 || bases->full_run_table.load(std::memory_order_acquire)) &&
+                             ((run_mask & ~mask_a2) == 0 || (bases_b ? bases_b : bases)->full_run_table.load(std::memory_order_acquire));
+        if (runs_ok) return msm_full_dev(ctx, bases, bases_b, split, d_scalars, stride, per, outer, batch, n, d_out, run_mask);
     }
     const int k_env = knob(K_MSM_K);
     // (a lone k = 14 proof with 12 / 16 / 24 / 32 / 48 points per task: 3.38 / 3.01 / 3.15 / 3.21 / 3.42 ms)
@@ -1193,6 +1455,8 @@ void zg_bases_free(zg_bases* b) {
     (void)hipDeviceSynchronize();  // any context of the device may have been reading the tables
     (void)hipFree(b->table);
     if (b->run_table) (void)hipFree(b->run_table);
+    if (Affine* t = b->full_table.load()) (void)hipFree(t);
+    if (Affine* t = b->full_run_table.load()) (void)hipFree(t);
     if (zg_bases* d = b->dense.load()) {
         (void)hipFree(d->table);
         if (d->run_table) (void)hipFree(d->run_table);
@@ -1206,6 +1470,13 @@ int zg_bases_enable_bit_table(zg_ctx* ctx, zg_bases* bases, uint32_t digit_width
     ZG_REQUIRE(bases->device == ctx->device, ZG_ERR_INVALID_ARG, "zg_bases_enable_bit_table: bases live on another device");
     ZG_ENTER(ctx);
     return bases_enable_naf(ctx, bases, digit_width, true);  // (takes the set's own lock; refuses another width)
+}
+
+int zg_bases_enable_digit_table(zg_ctx* ctx, zg_bases* bases, uint32_t window_bits) {
+    ZG_REQUIRE(ctx && bases, ZG_ERR_INVALID_ARG, "zg_bases_enable_digit_table: null argument");
+    ZG_REQUIRE(bases->device == ctx->device, ZG_ERR_INVALID_ARG, "zg_bases_enable_digit_table: bases live on another device");
+    ZG_ENTER(ctx);
+    return bases_enable_full(ctx, bases, window_bits, false);
 }
 
 size_t zg_bases_len(const zg_bases* b) { return b ? b->n : 0; }

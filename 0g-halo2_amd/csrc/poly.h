@@ -233,6 +233,9 @@ int bases_enable_runs(zg_ctx* ctx, zg_bases* b);  // running-sum table for the r
 // b->dense: one row per bit position, odd w-bit digits (strict: refuse a table made for another default width)
 int bases_enable_naf(zg_ctx* ctx, zg_bases* b, uint32_t w, bool strict = false);
 int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t window_bits, zg_bases** out);
+// digit tables of the latency form (every multiple of every window; window_bits 0 = from n and the free memory, which may
+// decide on none); with_runs: for the running sums too (the set must have its running-sum table)
+int bases_enable_full(zg_ctx* ctx, zg_bases* b, uint32_t window_bits, bool with_runs);
 void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
 
 }  // namespace zg

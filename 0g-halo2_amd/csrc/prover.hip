@@ -145,6 +145,7 @@ struct zg_prover {
     // what a LONE proof (latency form) borrows from the throughput form once the circuit is large enough for the work
     // to outweigh the launches (from k: K_LAT_SPLIT_K)
     bool lat_split = false;
+    bool full_tried = false;  // the latency form's digit tables were asked for (once per prover; bases_enable_full is idempotent)
     uint32_t naf_gl_w = 0;  // digit width of the run-form commitments' free-position form, 0 = windows (naf_gl_default)
     // point-range shard of the commitments (zg_prover_set_shard): this prover's base sets hold points
     // [shard_lo, shard_lo + shard_n) of the SRS; partial commitments of all ranks are exchanged and summed
@@ -1133,6 +1134,13 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     if (p->in_flight) {  // the previous batch left through an error return: drain what it queued before its staging
         (void)hipStreamSynchronize(st);  // arena and slots are reused
         if (ctx->side) (void)hipStreamSynchronize(ctx->side->stream);
+    }
+    if (p->use_side && !p->full_tried) {
+        // the latency form's digit tables (msm.hip: every multiple of every window -- no buckets), built once per base
+        // set the first time a proof runs in this form; no room or n too large: the bucket form stays
+        p->full_tried = true;
+        ZG_TRY(bases_enable_full(ctx, p->g, 0, false));
+        ZG_TRY(bases_enable_full(ctx, p->gl, 0, true));
     }
     p->in_flight = true;
     p->stage_off = p->pin_stage;

@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
     "zg_witness_plan_create", "zg_witness_plan_destroy", "zg_witness_plan_image_bytes", "zg_witness_plan_instance_len",
     "zg_witness_run_dev", "zg_prover_prove_images", "zg_prover_set_shard_rccl", "zg_xyzz_sum_ranks_dev", "zg_bases_enable_bit_table",
-    "zg_tuning_set", "zg_tuning_get", "zg_tuning_names",
+    "zg_tuning_set", "zg_tuning_get", "zg_tuning_names", "zg_bases_enable_digit_table",
 ]
 
 def tuning_names() -> list:
@@ -275,6 +275,10 @@ class Ctx:
     def enable_bit_table(self, bases: "Bases", digit_width: int):
         """Bit-position table + free-position odd digits for this context's throughput-form MSMs (zg_bases_enable_bit_table)."""
         _check(self.lib.zg_bases_enable_bit_table(self.h, bases.h, c_uint32(digit_width)))
+
+    def enable_digit_table(self, bases: "Bases", window_bits: int = 0):
+        """Every multiple of every window, for lone MSMs on a latency-form context (zg_bases_enable_digit_table)."""
+        _check(self.lib.zg_bases_enable_digit_table(self.h, bases.h, c_uint32(window_bits)))
 
     def register_bases_dev(self, d_ptr: int, n: int, window_bits: int = 0) -> "Bases":
         h = c_void_p()

@@ -67,8 +67,8 @@ const char *zg_version(void);
  * result: every form computes the same group elements and field elements, bit for bit (tests/test_gpu_knobs.py walks
  * them all against the oracle).  Knobs that shape resident data are read when that object is built (ZG_MSM_C: a base
  * set registered with window_bits = 0; ZG_MSM_NAF, ZG_MSM_NAF_GL, ZG_MSM_RUNS, ZG_EVALH9, ZG_EVALH_GROUPED,
- * ZG_SPLIT_DOMAIN: zg_prover_create*; ZG_LAT_SPLIT_K: zg_prover_create* and zg_prover_set_overlap), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
- * ZG_MSM_STRIP).
+ * ZG_SPLIT_DOMAIN: zg_prover_create*; ZG_LAT_SPLIT_K: zg_prover_create* and zg_prover_set_overlap; ZG_LAT_FULL_C: the first latency-form proof), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
+ * ZG_MSM_STRIP, ZG_LAT_FULL_K).
  *   ZG_MSM_C          window bits of the MSM tables, 2..16 (default from n: k - 2)
  *   ZG_MSM_K          points per bucket-accumulation task in the throughput form, 4..120 (48)
  *   ZG_MSM_K_LAT      ... in the latency form (16; 32 / 48 from n = 2^16 / 2^17)
@@ -81,7 +81,9 @@ const char *zg_version(void);
  *   ZG_EVALH_GROUPED  0 = evaluate_h folds in y term by term (the fallback of circuits with > 40 such terms)
  *   ZG_EVALH9         0 = evaluate_h on 8 x 32-bit limbs; implies the single extended coset
  *   ZG_SPLIT_DOMAIN   0 = EvaluationDomain's single extended coset in the throughput form too
- *   ZG_LAT_SPLIT_K    smallest k at which a lone proof (the latency form) takes the quotient from the split domain too (15) */
+ *   ZG_LAT_SPLIT_K    smallest k at which a lone proof (the latency form) takes the quotient from the split domain too (15)
+ *   ZG_LAT_FULL_C     window bits of the latency form's digit tables (zg_bases_enable_digit_table); 0 = none
+ *   ZG_LAT_FULL_K     summands per lane pair in the digit-table accumulation, 4..120 (16) */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */
@@ -135,6 +137,14 @@ void zg_bases_free(zg_bases *b);
  * (zg_ctx_set_msm_latency(ctx, 0)); a latency-form context keeps the window table (a lone MSM waits on the gathers from
  * a table no cache holds).  digit_width in [3, 16]; idempotent for the same width.  Same results, bit for bit. */
 int zg_bases_enable_bit_table(zg_ctx *ctx, zg_bases *bases, uint32_t digit_width);
+/* Optional digit tables of a base set for LONE MSMs (a context in its latency form, zg_ctx_set_msm_latency(ctx, 1)): every
+ * multiple d * 2^(c w) * P_i, d <= 2^(c-1), of every c-bit window -- ceil(255 / c) * 2^(c-1) * n * 64 B (26 GB at n = 2^14,
+ * c = 11).  A signed digit then names its summand and the MSM is a flat sum of gathered points folded by a tree: no digit
+ * sort, no buckets, no bucket reduction -- the latency of a lone commitment phase drops by about half.  window_bits 0 = chosen
+ * from n and the free memory (none from n = 2^16 on, or when the card has no room: not an error); 4..12 otherwise.
+ * zg_prover_prove* enables them by itself for a prover in its latency form (ZG_LAT_FULL_C = 0 to keep it from doing so).
+ * Same results, bit for bit. */
+int zg_bases_enable_digit_table(zg_ctx *ctx, zg_bases *bases, uint32_t window_bits);
 size_t zg_bases_len(const zg_bases *b);
 uint32_t zg_bases_window_bits(const zg_bases *b);
 

@@ -31,6 +31,8 @@ SETTINGS = {
     "ZG_EVALH9": [0],
     "ZG_SPLIT_DOMAIN": [0],
     "ZG_LAT_SPLIT_K": [0, 99],
+    "ZG_LAT_FULL_C": [0, 4, 7],
+    "ZG_LAT_FULL_K": [4, 48],
 }
 # knobs that act together: walked as pairs as well
 PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2, 4)] + [
@@ -38,6 +40,7 @@ PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2,
     {"ZG_EVALH9": 0, "ZG_EVALH_GROUPED": 0},
     {"ZG_MSM_C": 6, "ZG_MSM_NAF_GL": 0},
     {"ZG_LAT_SPLIT_K": 0, "ZG_SPLIT_DOMAIN": 0},
+    {"ZG_LAT_FULL_C": 5, "ZG_MSM_RUNS": 0},
 ]
 CASES = [{k: v} for k, vs in SETTINGS.items() for v in vs] + PAIRS
 

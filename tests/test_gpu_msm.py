@@ -176,3 +176,34 @@ def test_free_position_digits_on_adversarial_scalars(zg, orc, srs, w):
         c2.enable_bit_table(bases, w + 1 if w < 16 else 15)  # another width: refused
     bases.free()
     c2.close()
+
+
+@pytest.mark.parametrize("c", [0, 4, 7, 9])
+def test_digit_tables_give_the_same_points(ctx, zg, orc, srs, c):
+    """zg_bases_enable_digit_table: the latency form without buckets (every multiple of every window; a flat sum of
+    gathered points folded by a tree) == oracle, on uniform, sparse and adversarial scalars, ragged lengths, batches."""
+    g, gl = srs
+    n = gl.shape[0]
+    bases = ctx.register_bases(gl)
+    ctx.set_msm_latency(True)
+    ctx.enable_digit_table(bases, c)
+    R = zg.FR_MODULUS
+    vectors = [orc.fill_fr(41, n), orc.fill_fr_sparse(42, n), np.zeros((n, 4), np.uint64),
+               np.tile(orc.fr_from_int(1), (n, 1)), np.tile(orc.fr_from_int(R - 1), (n, 1)),
+               np.tile(orc.fr_from_int((1 << 253) + 12345), (n, 1))]
+    # digit boundaries: runs of ones, half-window values (the signed recoding's carry), powers of two
+    edge = np.stack([orc.fr_from_int(v % R) for v in
+                     ([(1 << b) - 1 for b in range(1, 255, 5)] + [1 << b for b in range(0, 254, 7)] +
+                      [(1 << (9 * j + 8)) for j in range(20)] + [R - 1 - (1 << b) for b in range(0, 250, 11)])])
+    e = np.zeros((n, 4), np.uint64)
+    e[: len(edge)] = edge
+    vectors.append(e)
+    got = ctx.msm_batch(bases, np.stack(vectors))
+    for b, s in enumerate(vectors):
+        assert np.array_equal(got[b], orc.msm(s, gl, threads=8)), (c, b)
+    for m in (1, 2, 63, 64, 65, 1000, n - 1):  # fewer scalars than bases
+        s = orc.fill_fr(700 + m, m)
+        assert np.array_equal(ctx.msm(bases, s), orc.msm(s, gl[:m], threads=4)), (c, m)
+    r = ctx.msm(bases, np.zeros((0, 4), np.uint64))
+    assert not r[:4].any() and not r[8:].any()
+    bases.free()
