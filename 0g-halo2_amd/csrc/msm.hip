@@ -999,45 +999,59 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
     const uint32_t* d = dig + (size_t)b * entries;
     const uint32_t step_w = tasks / n, step_i = tasks - step_w * n;  // one stride in (window, point) coordinates
     uint32_t e = t, w = t / n, i = t - w * n;
-    // the entry in hand: its digit word and, when that is non-zero, its table point (packed, as loaded)
-    uint32_t ent = d[e];
-    Fe px = fe_zero(), py = fe_zero();
-    if (ent & 0xffffu) {
-        const Affine* src = table + ((size_t)w * D + ((ent & 0xffffu) - 1)) * n_table + i;
-        px = ld_fe_g(&src->x);
-        py = ld_fe_g(&src->y);
-    }
     PairAcc acc;
     bool inf = true;
-    for (;;) {
-        // request the next entry's point first ...
-        const uint32_t e2 = e + tasks;
-        uint32_t w2 = w + step_w, i2 = i + step_i;
-        if (i2 >= n) {
-            i2 -= n;
-            w2++;
+    // the point in hand (requested one non-zero entry ahead of its addition)
+    uint32_t ent = 0;
+    Fe px = fe_zero(), py = fe_zero();
+    constexpr int CH = 16;
+    __shared__ uint32_t ents[CH][256];
+    while (e < entries) {
+        // the digit words of the next CH entries of this pair at once: independent loads, one latency -- a sparse column
+        // (nearly all zero) otherwise pays a dependent load per entry just to learn that there is nothing to add
+        // (kept in LDS, a column per lane: the loop over them stays rolled -- its body is an EC addition -- and a
+        //  register array indexed by a loop counter would live in scratch)
+#pragma unroll
+        for (int s = 0; s < CH; s++) {
+            const uint64_t es = (uint64_t)e + (uint64_t)s * tasks;
+            ents[s][threadIdx.x] = es < entries ? d[es] : 0u;
         }
-        uint32_t ent2 = 0;
-        Fe nx = fe_zero(), ny = fe_zero();
-        if (e2 < entries) {
-            ent2 = d[e2];
-            if (ent2 & 0xffffu) {
-                const Affine* src = table + ((size_t)w2 * D + ((ent2 & 0xffffu) - 1)) * n_table + i2;
-                nx = ld_fe_g(&src->x);
-                ny = ld_fe_g(&src->y);
+#pragma unroll 1
+        for (int s = 0; s < CH; s++) {
+            const uint32_t cur = ents[s][threadIdx.x];
+            if (cur & 0xffffu) {
+                // request this entry's point, add the one requested before it
+                const Affine* src = table + ((size_t)w * D + ((cur & 0xffffu) - 1)) * n_table + i;
+                const Fe nx = ld_fe_g(&src->x), ny = ld_fe_g(&src->y);
+                if (ent & 0xffffu) {
+                    const F9 qx = f9_unpack(px);
+                    F9 qy = f9_unpack(py);
+                    if (!(f9_limbs_zero(qx) && f9_limbs_zero(qy))) {  // (identity base point)
+                        if (ent >> 31) qy = f9_neg(qy);
+                        xmadd_pair(acc, inf, qx, qy, role_a);
+                    }
+                }
+                ent = cur;
+                px = nx;
+                py = ny;
+            }
+            w += step_w;
+            i += step_i;
+            if (i >= n) {
+                i -= n;
+                w++;
             }
         }
-        // ... then add the one in hand
-        if (ent & 0xffffu) {
-            const F9 qx = f9_unpack(px);
-            F9 qy = f9_unpack(py);
-            if (!(f9_limbs_zero(qx) && f9_limbs_zero(qy))) {  // (identity base point)
-                if (ent >> 31) qy = f9_neg(qy);
-                xmadd_pair(acc, inf, qx, qy, role_a);
-            }
+        const uint64_t en = (uint64_t)e + (uint64_t)CH * tasks;
+        e = en < entries ? (uint32_t)en : entries;
+    }
+    if (ent & 0xffffu) {  // the last one
+        const F9 qx = f9_unpack(px);
+        F9 qy = f9_unpack(py);
+        if (!(f9_limbs_zero(qx) && f9_limbs_zero(qy))) {
+            if (ent >> 31) qy = f9_neg(qy);
+            xmadd_pair(acc, inf, qx, qy, role_a);
         }
-        if (e2 >= entries) break;
-        e = e2; w = w2; i = i2; ent = ent2; px = nx; py = ny;
     }
     XYZZ9* dst = partial + (size_t)b * tasks + t;
     if (inf) {

@@ -639,6 +639,10 @@ def main():
         for x in ctxs[1:]:
             x.close()
         ctxs = ctxs[:1]
+        # (the headline model's base sets go too: the lone-proof probe left its digit tables on them, 3 x 26 GB at k = 14,
+        #  and the k = 17 run below wants 12 provers x 8 slots x 1.4 GiB)
+        circuit.g_bases.free()
+        circuit.gl_bases.free()
         for m in ("small", "medium", "large"):
             c2 = Circuit(ctx0, m)
             b2 = batch if m != "large" else max(1, batch // 2)
