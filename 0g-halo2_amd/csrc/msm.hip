@@ -1364,7 +1364,9 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket);
     ZG_LAUNCH(ctx, "msm_scatter", msm_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
               off, slot, sorted, naf);
-    if (ctx->msm_pair) {
+    // (lane pairs per task -- half the dependent products per point -- while the launch is latency-bound; from n = 2^16
+    //  on it fills the chip several times over and the pair form's exchanges are pure cost)
+    if (ctx->msm_pair && N < (1u << 16)) {
         ZG_LAUNCH(ctx, "msm_accumulate", msm_bytes, msm_accumulate_kernel<true>, dim3((2 * max_tasks + 255) / 256, B), dim3(256),
                   0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
                   toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket);

@@ -196,26 +196,26 @@ __global__ __launch_bounds__(256) void pp_flags_kernel(const Fe* __restrict__ a,
     consumed[(size_t)b * n + lo] = 1u;
 }
 
-// exclusive prefix sums of `repeated` and of `!consumed` over the usable rows; one workgroup per lookup
-__global__ __launch_bounds__(1024) void pp_scan_kernel(uint32_t* __restrict__ repeated, uint32_t* __restrict__ consumed,
-                                                       uint32_t n, uint32_t usable, uint32_t* __restrict__ totals) {
-    __shared__ uint32_t sr[1024], sl[1024];
-    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+// Exclusive prefix sums of `repeated` and of `!consumed` over the usable rows, in two levels (one workgroup per vector
+// walking 2^17 rows in per-lane strips took 0.37 ms at k = 17 -- uncoalesced, dependent loads; round 3): every tile of 1024
+// rows is scanned by a workgroup of its own (coalesced in, coalesced out: the flag in the top bit, the TILE-LOCAL
+// exclusive prefix below it), a second kernel scans the tile totals per vector, and the two readers below add their
+// tile's offset.
+constexpr uint32_t PP_TILE = 1024;
+
+__global__ __launch_bounds__(PP_TILE) void pp_scan_local_kernel(uint32_t* __restrict__ repeated, uint32_t* __restrict__ consumed,
+                                                                uint32_t n, uint32_t usable, uint32_t ntile,
+                                                                uint32_t* __restrict__ toff) {
+    __shared__ uint32_t sr[PP_TILE], sl[PP_TILE];
+    const uint32_t tid = threadIdx.x, tile = blockIdx.x, b = blockIdx.y;
+    const uint32_t i = tile * PP_TILE + tid;
     uint32_t* rp = repeated + (size_t)b * n;
     uint32_t* cp = consumed + (size_t)b * n;
-    const uint32_t per = (usable + 1023) / 1024;
-    uint32_t lo = tid * per, hi = lo + per;
-    if (lo > usable) lo = usable;
-    if (hi > usable) hi = usable;
-    uint32_t r = 0, l = 0;
-    for (uint32_t i = lo; i < hi; i++) {
-        r += rp[i];
-        l += 1u - cp[i];
-    }
-    sr[tid] = r;
-    sl[tid] = l;
+    const uint32_t fr = i < usable ? rp[i] : 0u, fl = i < usable ? 1u - cp[i] : 0u;
+    sr[tid] = fr;
+    sl[tid] = fl;
     __syncthreads();
-    for (uint32_t o = 1; o < 1024; o <<= 1) {
+    for (uint32_t o = 1; o < PP_TILE; o <<= 1) {
         uint32_t vr = 0, vl = 0;
         if (tid >= o) {
             vr = sr[tid - o];
@@ -226,34 +226,63 @@ __global__ __launch_bounds__(1024) void pp_scan_kernel(uint32_t* __restrict__ re
         sl[tid] += vl;
         __syncthreads();
     }
-    uint32_t br = sr[tid] - r, bl = sl[tid] - l;
-    for (uint32_t i = lo; i < hi; i++) {
-        uint32_t fr = rp[i], fl = 1u - cp[i];
-        // keep the flag in the top bit, the exclusive prefix below it
-        rp[i] = br | (fr << 31);
-        cp[i] = bl | (fl << 31);
-        br += fr;
-        bl += fl;
+    if (i < usable) {
+        rp[i] = (sr[tid] - fr) | (fr << 31);
+        cp[i] = (sl[tid] - fl) | (fl << 31);
     }
-    if (tid == 1023) {
-        totals[2 * b] = sr[1023];
-        totals[2 * b + 1] = sl[1023];
+    if (tid == PP_TILE - 1) {
+        toff[((size_t)b * ntile + tile) * 2] = sr[tid];
+        toff[((size_t)b * ntile + tile) * 2 + 1] = sl[tid];
+    }
+}
+
+// tile totals -> exclusive tile offsets (in place) and the vector's totals; ntile <= 1024
+__global__ __launch_bounds__(PP_TILE) void pp_scan_tiles_kernel(uint32_t* __restrict__ toff, uint32_t ntile, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t sr[PP_TILE], sl[PP_TILE];
+    const uint32_t tid = threadIdx.x, b = blockIdx.x;
+    uint32_t* tb = toff + (size_t)b * ntile * 2;
+    const uint32_t r = tid < ntile ? tb[2 * tid] : 0u, l = tid < ntile ? tb[2 * tid + 1] : 0u;
+    sr[tid] = r;
+    sl[tid] = l;
+    __syncthreads();
+    for (uint32_t o = 1; o < PP_TILE; o <<= 1) {
+        uint32_t vr = 0, vl = 0;
+        if (tid >= o) {
+            vr = sr[tid - o];
+            vl = sl[tid - o];
+        }
+        __syncthreads();
+        sr[tid] += vr;
+        sl[tid] += vl;
+        __syncthreads();
+    }
+    if (tid < ntile) {
+        tb[2 * tid] = sr[tid] - r;
+        tb[2 * tid + 1] = sl[tid] - l;
+    }
+    if (tid == PP_TILE - 1) {
+        totals[2 * b] = sr[tid];
+        totals[2 * b + 1] = sl[tid];
     }
 }
 
 // left-over table entries, ascending
 __global__ __launch_bounds__(256) void pp_leftover_kernel(const Fe* __restrict__ t, const uint32_t* __restrict__ consumed,
-                                                          uint32_t n, uint32_t usable, Fe* __restrict__ leftover) {
+                                                          uint32_t n, uint32_t usable, Fe* __restrict__ leftover,
+                                                          const uint32_t* __restrict__ toff, uint32_t ntile) {
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (j >= usable) return;
     uint32_t c = consumed[(size_t)b * n + j];
-    if (c >> 31) stk(leftover + (size_t)b * n + (c & 0x7fffffffu), ldk(t + (size_t)b * n + j));
+    if (c >> 31) {
+        const uint32_t at = (c & 0x7fffffffu) + toff[((size_t)b * ntile + j / PP_TILE) * 2 + 1];
+        stk(leftover + (size_t)b * n + at, ldk(t + (size_t)b * n + j));
+    }
 }
 
 __global__ __launch_bounds__(256) void pp_build_kernel(const Fe* __restrict__ a, const uint32_t* __restrict__ repeated,
                                                        const Fe* __restrict__ leftover, const uint32_t* __restrict__ totals,
                                                        uint32_t n, uint32_t usable, Fe* __restrict__ sprime,
-                                                       uint32_t* __restrict__ err) {
+                                                       uint32_t* __restrict__ err, const uint32_t* __restrict__ toff, uint32_t ntile) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= usable) return;
     const uint32_t m_rep = totals[2 * b], m_left = totals[2 * b + 1];
@@ -263,7 +292,7 @@ __global__ __launch_bounds__(256) void pp_build_kernel(const Fe* __restrict__ a,
     }
     uint32_t r = repeated[(size_t)b * n + i];
     Fe v;
-    if (r >> 31) v = ldk(leftover + (size_t)b * n + (m_rep - 1 - (r & 0x7fffffffu)));
+    if (r >> 31) v = ldk(leftover + (size_t)b * n + (m_rep - 1 - ((r & 0x7fffffffu) + toff[((size_t)b * ntile + i / PP_TILE) * 2])));
     else v = ldk(a + (size_t)b * n + i);
     stk(sprime + (size_t)b * n + i, v);
 }
@@ -287,10 +316,16 @@ int poly_permute_pairs(zg_ctx* ctx, const Fe* a, const Fe* t, Fe* sprime, uint32
     dim3 g((usable + 255) / 256, batch);
     const double bytes = (double)batch * n * 96;
     ZG_LAUNCH(ctx, "permute_flags", bytes, pp_flags_kernel, g, dim3(256), 0, a, t, n, usable, repeated, consumed, d_err);
-    ZG_LAUNCH(ctx, "permute_scan", bytes, pp_scan_kernel, dim3(batch), dim3(1024), 0, repeated, consumed, n, usable, totals);
-    ZG_LAUNCH(ctx, "permute_leftover", bytes, pp_leftover_kernel, g, dim3(256), 0, t, consumed, n, usable, scratch_fe);
+    const uint32_t ntile = (usable + PP_TILE - 1) / PP_TILE;
+    ZG_REQUIRE(ntile <= PP_TILE, ZG_ERR_UNSUPPORTED, "permute_pairs: %u rows", usable);
+    WsScope ws(ctx);
+    uint32_t* toff = ws.get<uint32_t>((size_t)2 * batch * ntile);
+    if (!toff) return ZG_ERR_OOM;
+    ZG_LAUNCH(ctx, "permute_scan", bytes, pp_scan_local_kernel, dim3(ntile, batch), dim3(PP_TILE), 0, repeated, consumed, n, usable, ntile, toff);
+    ZG_LAUNCH(ctx, "permute_scan", bytes, pp_scan_tiles_kernel, dim3(batch), dim3(PP_TILE), 0, toff, ntile, totals);
+    ZG_LAUNCH(ctx, "permute_leftover", bytes, pp_leftover_kernel, g, dim3(256), 0, t, consumed, n, usable, scratch_fe, toff, ntile);
     ZG_LAUNCH(ctx, "permute_build", bytes, pp_build_kernel, g, dim3(256), 0, a, repeated, scratch_fe, totals, n, usable, sprime,
-              d_err);
+              d_err, toff, ntile);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

@@ -42,7 +42,7 @@ def launch_name(kernel: str) -> str:
     alias = {"gp_strip_scan": "grand_product_scan", "gp_strip_apply": "grand_product_apply", "gp_local": "grand_product_local",
              "gp_totals": "grand_product_totals", "gp_apply": "grand_product_apply", "kd_local": "kate_local",
              "kd_heads": "kate_heads", "kd_apply": "kate_apply", "dot": "eval_dot", "kd_strip": "kate_division",
-             "pp_flags": "permute_flags", "pp_scan": "permute_scan", "pp_leftover": "permute_leftover",
+             "pp_flags": "permute_flags", "pp_scan": "permute_scan", "pp_scan_local": "permute_scan", "pp_scan_tiles": "permute_scan", "pp_leftover": "permute_leftover",
              "pp_build": "permute_build", "random_and_blind": "random_poly", "evaluate_h9": "evaluate_h",
              "horner_combine_sets": "horner_combine", "msm_digits_naf": "msm_digits", "sort_global_fused": "sort_global",
              "gate_factor9": "gate_factor"}
