@@ -214,6 +214,7 @@ enum Knob : int {
     K_LAT_SPLIT_K,    // smallest k at which a LONE proof (latency form) takes the quotient from the split domain as well
     K_LAT_FULL_C,     // window bits of the latency form's digit tables (every multiple of every window); 0 = none
     K_LAT_FULL_K,     // summands per lane pair in the digit-table accumulation (4..120)
+    K_LAZY_DOT,       // 0 = eval_polynomial and the multiopen combinations reduce after every term (dot_kernel, Horner)
     K_COUNT
 };
 int knob(Knob k);

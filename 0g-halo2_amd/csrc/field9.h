@@ -277,6 +277,63 @@ struct Field9 {
 using Fq9 = Field9<Fq9Params>;
 using Fr9 = Field9<Fr9Params>;
 
+// sum_t a_t * b_t with ONE Montgomery reduction at the end (dot products: eval_polynomial against a power table, the
+// linear combinations of the multiopen argument).  The 17 product columns are kept as they are -- a term costs its 81
+// multiply-adds and nothing else -- and carried back to 29 bits every third term: operands are unpacked canonical
+// values (limbs in [0, 2^29)), so a column grows by at most 9 * 2^58 per term and 3 * 9 * 2^58 + 2^35 < 2^63.
+template <class P>
+struct Dot9 {
+    int64_t c[17];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < 17; k++) c[k] = 0;
+    }
+    __device__ __forceinline__ void mac(const F9& a, const F9& b) {
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (j >= 0 && j < 9) c[k] += (int64_t)a.l[i] * (int64_t)b.l[j];
+            }
+        }
+    }
+    // columns 0..15 back into [0, 2^29); the top column takes what is left (value unchanged)
+    __device__ __forceinline__ void carry() {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            c[k + 1] += c[k] >> 29;
+            c[k] &= (int64_t)MASK29;
+        }
+    }
+    // (sum) * 2^-261 mod p, normalised, value in [0, sum / 2^261 + p).  Call after carry(); the sum must stay below
+    // 2^521 (2^13 terms of canonical operands of a 254-bit field), which keeps the result under f9_reduce_pack's 2^263.
+    __device__ __forceinline__ F9 reduce() const {
+        int64_t acc = 0;
+        int32_t m[9];
+        F9 r;
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+            acc += c[k];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (i < k && j >= 0 && j < 9) acc += (int64_t)m[i] * (int64_t)P::p(j);
+            }
+            if (k < 9) {
+                m[k] = (int32_t)(((uint32_t)acc * P::INV29) & (uint32_t)MASK29);
+                acc += (int64_t)m[k] * (int64_t)P::p(0);
+                acc >>= 29;
+            } else {
+                r.l[k - 9] = (int32_t)((uint32_t)acc & (uint32_t)MASK29);
+                acc >>= 29;
+            }
+        }
+        r.l[8] = (int32_t)acc;
+        return r;
+    }
+};
+
 // Normalised value of magnitude < 2^263 -> canonical packed form.  The quotient by p is estimated from
 // the top limb in float (2^232 / p = 3.1531751e-7 for both BN254 moduli): the float product is within
 // 8e-5 of v/p and the dropped low limbs add less than 4e-7, so floor(estimate - 1e-4) is floor(v/p) or

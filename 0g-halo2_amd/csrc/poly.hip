@@ -1143,9 +1143,59 @@ __global__ __launch_bounds__(DOT_NT) void dot_kernel(PolySet ps, uint32_t n, con
     if (tid == 0) stg(out + (size_t)b * out_bs + j, sh[0]);
 }
 
+// The same dot product with ONE Montgomery reduction per lane (Dot9, field9.h): a term is its 81 multiply-adds, the
+// columns are carried every third term, and the loads of three terms are in flight at once (a lone proof has one wave per
+// SIMD here and waits on every dependent load).  Both operands are x * 2^256, so a lane's reduced sum is 2^251 * S; the
+// factor 2^5 is put back by one product per (polynomial, point) pair at the end.  Same field element as dot_kernel.
+// Workgroups of 1024 lanes for a lone proof (the latency form: a few dozen pairs have to fill the chip), of 256 in the
+// throughput form, where a 1024-lane workgroup at this register count waits for a whole CU to drain between the other
+// provers' kernels.
+template <uint32_t DOT_NT>
+__global__ __launch_bounds__(DOT_NT) void dot9_kernel(PolySet ps, uint32_t n, const uint32_t* __restrict__ poly_idx,
+                                                      const uint32_t* __restrict__ point_idx, const Fe* __restrict__ pw,
+                                                      size_t pw_bs, Fe* __restrict__ out, size_t out_bs) {
+    __shared__ Fe sh[DOT_NT];
+    const uint32_t j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const Fe* p = poly_of(ps, poly_idx[j], b);
+    const Fe* w = pw + (size_t)b * pw_bs + (size_t)point_idx[j] * n;
+    Dot9<Fr9Params> acc;
+    acc.zero();
+    uint32_t i = tid;
+    for (; i + 2 * DOT_NT < n; i += 3 * DOT_NT) {  // (three terms: what 128 VGPRs hold next to the 17 columns)
+        Fe pv[3], wv[3];
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            pv[t] = ldg(p + i + t * DOT_NT);
+            wv[t] = ldg(w + i + t * DOT_NT);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; t++) acc.mac(f9_unpack(pv[t]), f9_unpack(wv[t]));
+        acc.carry();
+    }
+    for (; i < n; i += DOT_NT) {
+        acc.mac(ld9(p + i), ld9(w + i));
+        acc.carry();
+    }
+    sh[tid] = f9_reduce_pack<Fr9Params>(acc.reduce());
+    __syncthreads();
+    for (uint32_t off = DOT_NT / 2; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] = Fr::add(sh[tid], sh[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) stg(out + (size_t)b * out_bs + j, Fr::mul(sh[0], Fr9Params::c261_fe()));
+}
+
 int poly_dot(zg_ctx* ctx, const PolySet& polys, uint32_t nb, uint32_t n, const uint32_t* d_poly_idx,
              const uint32_t* d_point_idx, const Fe* d_pow, size_t pw_bs, uint32_t count, Fe* d_out, size_t out_bs) {
     if (!count || !nb) return ZG_OK;
+    // (a lane sums n / 256 terms at most: 2^12 at n = 2^20, inside Dot9's bound of 2^13 terms)
+    if (knob(K_LAZY_DOT) != 0 && n <= (1u << 20) && ctx->msm_pair)
+        ZG_LAUNCH(ctx, "eval_dot", (double)nb * count * n * 64, dot9_kernel<1024>, dim3(count, nb), dim3(1024), 0, polys, n, d_poly_idx,
+                  d_point_idx, d_pow, pw_bs, d_out, out_bs);
+    else if (knob(K_LAZY_DOT) != 0 && n <= (1u << 20))
+        ZG_LAUNCH(ctx, "eval_dot", (double)nb * count * n * 64, dot9_kernel<256>, dim3(count, nb), dim3(256), 0, polys, n, d_poly_idx,
+                  d_point_idx, d_pow, pw_bs, d_out, out_bs);
+    else
     ZG_LAUNCH(ctx, "eval_dot", (double)nb * count * n * 64, dot_kernel, dim3(count, nb), dim3(DOT_NT), 0, polys, n, d_poly_idx,
               d_point_idx, d_pow, pw_bs, d_out, out_bs);
     ZG_HIP(hipGetLastError());
@@ -1166,9 +1216,61 @@ __global__ __launch_bounds__(256) void horner_combine_kernel(PolySet ps, const P
     stg(out + (size_t)b * out_bs + i, acc);
 }
 
+// The same combinations as ONE dot product per coefficient (Dot9, field9.h): sum_j p_j[i] * v^(count - 1 - j) against a
+// table of the powers of v in the 2^261 form -- made once per workgroup, lane e takes v^e -- so that a term costs 81
+// multiply-adds and the Montgomery reduction is paid once per coefficient instead of once per term; the loads of three
+// terms are in flight at once.  Horner's value exactly (the arithmetic is exact), SETS: v = pc[b].v and pc[b].subs[s]
+// comes off the constant term (the multiopen argument's lists), else v = pc[b].xn (h(X) from its pieces).
+struct HornerSets {
+    uint32_t count[HC_MAX_SETS];
+};
+constexpr uint32_t HC9_MAX = 128;  // longest list the power table holds (longer ones take the Horner kernels)
+template <bool SETS>
+__global__ __launch_bounds__(256) void combine9_kernel(PolySet ps, const ProofConst* __restrict__ pc,
+                                                       const uint32_t* __restrict__ lists, uint32_t list_stride, HornerSets sets,
+                                                       Fe* __restrict__ out, size_t out_stride, size_t out_bs, uint32_t n) {
+    __shared__ F9 vp[HC9_MAX];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y, b = blockIdx.z;
+    const uint32_t count = sets.count[s];
+    if (threadIdx.x < count) {
+        const Fe v = SETS ? pc[b].v : pc[b].xn;
+        vp[threadIdx.x] = f9_unpack(Fr::mul(Fr::pow_u64(v, threadIdx.x), Fr9Params::c261_fe()));
+    }
+    __syncthreads();
+    if (i >= n) return;
+    const uint32_t* list = lists + (size_t)s * list_stride;
+    Dot9<Fr9Params> acc;
+    acc.zero();
+    uint32_t j = 0;
+    for (; j + 3 <= count; j += 3) {
+        const Fe p0 = ldg(poly_of(ps, list[j], b) + i), p1 = ldg(poly_of(ps, list[j + 1], b) + i),
+                 p2 = ldg(poly_of(ps, list[j + 2], b) + i);
+        acc.mac(f9_unpack(p0), vp[count - 1 - j]);
+        acc.mac(f9_unpack(p1), vp[count - 2 - j]);
+        acc.mac(f9_unpack(p2), vp[count - 3 - j]);
+        acc.carry();
+    }
+    for (; j < count; j++) {
+        acc.mac(ld9(poly_of(ps, list[j], b) + i), vp[count - 1 - j]);
+        acc.carry();
+    }
+    Fe r = f9_reduce_pack<Fr9Params>(acc.reduce());
+    if (SETS && i == 0) r = Fr::sub(r, pc[b].subs[s]);
+    stg(out + (size_t)b * out_bs + (size_t)s * out_stride + i, r);
+}
+
 int poly_horner_combine_xn(zg_ctx* ctx, const PolySet& polys, const ProofConst* pc, uint32_t nb, const uint32_t* d_list,
                            uint32_t count, Fe* out, size_t out_bs, uint32_t n) {
     if (!nb) return ZG_OK;
+    if (knob(K_LAZY_DOT) != 0 && count <= HC9_MAX) {
+        HornerSets sets;
+        memset(&sets, 0, sizeof(sets));
+        sets.count[0] = count;
+        ZG_LAUNCH(ctx, "horner_combine", (double)nb * (count + 1) * n * 32, combine9_kernel<false>, dim3((n + 255) / 256, 1, nb),
+                  dim3(256), 0, polys, pc, d_list, 0u, sets, out, (size_t)0, out_bs, n);
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
     ZG_LAUNCH(ctx, "horner_combine", (double)nb * (count + 1) * n * 32, horner_combine_kernel, dim3((n + 255) / 256, nb), dim3(256),
               0, polys, pc, d_list, count, out, out_bs, n);
     ZG_HIP(hipGetLastError());
@@ -1178,9 +1280,6 @@ int poly_horner_combine_xn(zg_ctx* ctx, const PolySet& polys, const ProofConst* 
 // the same in pc[b].v for up to HC_MAX_SETS lists at once (GWC: one list per opening point): set s = blockIdx.y of
 // proof b = blockIdx.z reads lists + s * list_stride and writes out + b * out_bs + s * out_stride, with
 // pc[b].subs[s] taken off the constant term
-struct HornerSets {
-    uint32_t count[HC_MAX_SETS];
-};
 __global__ __launch_bounds__(256) void horner_combine_sets_kernel(PolySet ps, const ProofConst* __restrict__ pc,
                                                                   const uint32_t* __restrict__ lists, uint32_t list_stride,
                                                                   HornerSets sets, Fe* __restrict__ out, size_t out_stride,
@@ -1208,6 +1307,12 @@ int poly_horner_combine_sets(zg_ctx* ctx, const PolySet& polys, const ProofConst
         sets.count[s] = counts[s];
         total += counts[s] + 1;
     }
+    bool lazy = knob(K_LAZY_DOT) != 0;
+    for (uint32_t s = 0; s < nsets; s++) lazy = lazy && counts[s] <= HC9_MAX;
+    if (lazy)
+        ZG_LAUNCH(ctx, "horner_combine", nb * total * n * 32, combine9_kernel<true>, dim3((n + 255) / 256, nsets, nb), dim3(256), 0,
+                  polys, pc, d_lists, list_stride, sets, out, out_stride, out_bs, n);
+    else
     ZG_LAUNCH(ctx, "horner_combine", nb * total * n * 32, horner_combine_sets_kernel, dim3((n + 255) / 256, nsets, nb), dim3(256), 0,
               polys, pc, d_lists, list_stride, sets, out, out_stride, out_bs, n);
     ZG_HIP(hipGetLastError());

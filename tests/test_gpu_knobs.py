@@ -33,6 +33,7 @@ SETTINGS = {
     "ZG_LAT_SPLIT_K": [0, 99],
     "ZG_LAT_FULL_C": [0, 4, 7],
     "ZG_LAT_FULL_K": [4, 48],
+    "ZG_LAZY_DOT": [0],
 }
 # knobs that act together: walked as pairs as well
 PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2, 4)] + [

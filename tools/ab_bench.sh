@@ -7,7 +7,7 @@ for cfg in "$@"; do
   envs=${cfg#* }
   [ "$envs" = "$cfg" ] && envs=""
   for rep in 1 2; do
-    env $envs python bench.py --steps 10 --warmup 2 --no-other-configs --no-cpu-baseline --no-verify --no-latency-probe --no-image-to-proof 2>/dev/null \
+    env $envs python bench.py --steps ${STEPS:-10} --warmup 2 --no-other-configs --no-cpu-baseline --no-verify --no-latency-probe --no-image-to-proof 2>/dev/null \
       | python -c "import json,sys; d=json.load(sys.stdin); print('$label ms/proof %.4f device_ms/proof %.3f' % (d['ms_per_proof'], d['device_ms_per_proof']))" >> $out
   done
 done
