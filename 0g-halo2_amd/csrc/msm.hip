@@ -946,6 +946,7 @@ int bases_enable_runs(zg_ctx* ctx, zg_bases* b) {
 constexpr uint32_t MSM_FULL_MIN_C = 4, MSM_FULL_MAX_C = 12;
 constexpr uint32_t MSM_FULL_K = 16;        // summands per lane pair (K_LAT_FULL_K)
 constexpr uint32_t MSM_TREE_GROUPS = 64;   // additions in flight per workgroup of the tree kernels (4 lanes each)
+constexpr uint32_t MSM_FULL_PAIRS = 128;   // lane pairs per workgroup of the accumulation (256 lanes)
 
 // full[(w * D + d - 1) * n + i] = d * win[w][i] for d = 1 .. D, affine, in the x * 2^261 form of every MSM table.  One
 // lane per (i, w): a chain of mixed additions, every multiple normalised by an inversion of its own (build time only).
@@ -983,6 +984,7 @@ __global__ __launch_bounds__(64) void msm_full_table_kernel(const Affine* __rest
 // the launch is as long as its longest pair -- and a wave's reads of the digit array are coalesced.  The table point of
 // the NEXT entry is requested before the current one is added: a gather from a 26 GB table (an HBM and a TLB miss) takes
 // as long as the addition it hides behind.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
     const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table, uint32_t D,
     uint32_t windows, uint32_t n, const uint32_t* __restrict__ dig, uint32_t tasks, XYZZ9* __restrict__ partial,
@@ -991,14 +993,15 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
     const uint32_t t = lane >> 1;
     const bool role_a = (lane & 1u) == 0;
     const uint32_t b = blockIdx.y;
-    if (t >= tasks) return;  // (pairs are never split: 2 * tasks lanes, even block size)
+    // (pairs are never split: 2 * tasks lanes, even block size; a pair beyond the last task adds nothing and hands the
+    //  workgroup's tree the identity)
     const uint32_t vj = b % per;
     const bool runs = vj < 64 && ((run_mask >> vj) & 1ull);
     const Affine* table = vj < split ? (runs ? run_a : table_a) : (runs ? run_b : table_b);
     const uint32_t entries = n * windows;
     const uint32_t* d = dig + (size_t)b * entries;
     const uint32_t step_w = tasks / n, step_i = tasks - step_w * n;  // one stride in (window, point) coordinates
-    uint32_t e = t, w = t / n, i = t - w * n;
+    uint32_t e = t < tasks ? t : entries, w = t / n, i = t - w * n;
     PairAcc acc;
     bool inf = true;
     // the point in hand (requested one non-zero entry ahead of its addition)
@@ -1053,7 +1056,14 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
             xmadd_pair(acc, inf, qx, qy, role_a);
         }
     }
-    XYZZ9* dst = partial + (size_t)b * tasks + t;
+    // FUSE: the workgroup's 128 partial sums are folded here, through LDS, by 64 four-lane groups (seven levels) -- one
+    // launch and two dependent additions fewer per commitment phase than a tree kernel reading them back from HBM.  It
+    // pays while the launch fits the chip in one round (a workgroup that is done early folds while the others still add);
+    // a launch of several rounds would wait seven additions at the end of EVERY round with most lanes idle, so those
+    // write their partial sums and leave them to msm_tree_kernel (k = 15, same box: 3.64 ms fused everywhere against 3.72).
+    __shared__ XYZZ9 sums[FUSE ? MSM_FULL_PAIRS : 1];
+    XYZZ9* dst = FUSE ? &sums[threadIdx.x >> 1] : partial + (size_t)b * tasks + t;
+    if (!FUSE && t >= tasks) return;
     if (inf) {
         if (role_a) st_xyzz9(dst, xyzz9_identity());
     } else if (role_a) {
@@ -1063,6 +1073,14 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
         st_f9(&dst->y, acc.m);
         st_f9(&dst->zzz, acc.z);
     }
+    if (!FUSE) return;
+    __syncthreads();
+    const uint32_t q = threadIdx.x >> 2, role = threadIdx.x & 3u;
+    for (uint32_t o = MSM_FULL_PAIRS / 2; o > 0; o >>= 1) {
+        if (q < o) xstore<true>(&sums[q], xaddl<4>(&sums[q], &sums[q + o], role));
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st_xyzz9(partial + (size_t)b * gridDim.x + blockIdx.x, sums[0]);
 }
 
 // Folds `count` points per vector: workgroup blk of vector b sums in[b * count + blk * 64 G ..) -- every one of its 64
@@ -1179,12 +1197,15 @@ static int msm_full_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* base
     const int k_env = knob(K_LAT_FULL_K);
     const uint32_t K = k_env >= 4 && k_env <= 120 ? (uint32_t)k_env : MSM_FULL_K;
     const uint32_t tasks = (uint32_t)((entries + K - 1) / K);
-    // tree: stage 1 folds 256 partial sums per workgroup (4 per group), stage 2 the rest in one workgroup per vector
-    const uint32_t G1 = 4, n1 = (tasks + MSM_TREE_GROUPS * G1 - 1) / (MSM_TREE_GROUPS * G1);
+    // a launch that fits the chip in one round folds its workgroups' partial sums itself (128 -> 1); larger ones leave
+    // them to a first tree stage of 256 per workgroup (4 per group); the last stage is one workgroup per vector
+    const uint32_t nwg = (tasks + MSM_FULL_PAIRS - 1) / MSM_FULL_PAIRS;
+    const bool fuse = (uint64_t)B * nwg <= 2048;
+    const uint32_t G1 = 4, n1 = fuse ? nwg : (tasks + MSM_TREE_GROUPS * G1 - 1) / (MSM_TREE_GROUPS * G1);
     const uint32_t G2 = (n1 + MSM_TREE_GROUPS - 1) / MSM_TREE_GROUPS;
     WsScope ws(ctx);
     uint32_t* dig = ws.get<uint32_t>((size_t)B * entries);
-    XYZZ9* partial = ws.get<XYZZ9>((size_t)B * tasks);
+    XYZZ9* partial = fuse ? nullptr : ws.get<XYZZ9>((size_t)B * tasks);
     XYZZ9* stage = ws.get<XYZZ9>((size_t)B * n1);
     if (ws.failed) return ZG_ERR_OOM;
     const double msm_bytes = (double)B * ((double)N * 96.0 + 96.0);
@@ -1193,10 +1214,15 @@ static int msm_full_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* base
                  *rb = bases_b ? bases_b->full_run_table.load(std::memory_order_acquire) : ra;
     ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, (uint32_t)per,
               outer, N, c, W, 0u, dig, run_mask);
-    ZG_LAUNCH(ctx, "msm_accumulate_full", msm_bytes, msm_accumulate_full_kernel, dim3((2 * tasks + 255) / 256, B), dim3(256), 0, ta, tb,
-              (uint32_t)split, (uint32_t)bases->n, D, W, N, dig, tasks, partial, ra, rb, run_mask, (uint32_t)per);
-    ZG_LAUNCH(ctx, "msm_tree", msm_bytes, msm_tree_kernel, dim3(n1, B), dim3(4 * MSM_TREE_GROUPS), 0, partial, tasks, G1, stage,
-              (XYZZ*)nullptr);
+    if (fuse) {
+        ZG_LAUNCH(ctx, "msm_accumulate_full", msm_bytes, msm_accumulate_full_kernel<true>, dim3(nwg, B), dim3(2 * MSM_FULL_PAIRS), 0, ta,
+                  tb, (uint32_t)split, (uint32_t)bases->n, D, W, N, dig, tasks, stage, ra, rb, run_mask, (uint32_t)per);
+    } else {
+        ZG_LAUNCH(ctx, "msm_accumulate_full", msm_bytes, msm_accumulate_full_kernel<false>, dim3(nwg, B), dim3(2 * MSM_FULL_PAIRS), 0, ta,
+                  tb, (uint32_t)split, (uint32_t)bases->n, D, W, N, dig, tasks, partial, ra, rb, run_mask, (uint32_t)per);
+        ZG_LAUNCH(ctx, "msm_tree", msm_bytes, msm_tree_kernel, dim3(n1, B), dim3(4 * MSM_TREE_GROUPS), 0, partial, tasks, G1, stage,
+                  (XYZZ*)nullptr);
+    }
     ZG_LAUNCH(ctx, "msm_tree", msm_bytes, msm_tree_kernel, dim3(1, B), dim3(4 * MSM_TREE_GROUPS), 0, stage, n1, G2, (XYZZ9*)nullptr, d_out);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -1258,7 +1284,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     const uint32_t B = (uint32_t)batch, N = (uint32_t)n;
     if (n == 0) {
         std::vector<XYZZ> ids(batch, xyzz_identity());
-        ZG_HIP(hipMemcpyAsync(d_out, ids.data(), batch * sizeof(XYZZ), hipMemcpyHostToDevice, ctx->stream));
+        ZG_HIP(hipMemcpyAsync(d_out, ids.data(), batch * sizeof(XYZZ), hipMemcpyDefault, ctx->stream));  // (d_out may be mapped host memory)
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         return ZG_OK;
     }

@@ -174,7 +174,7 @@ struct zg_prover {
     Fe *adv_val = nullptr /* [cap][A][n] */, *inst_val = nullptr /* [cap][I][n] */;
     Fe *cin = nullptr, *ctab = nullptr /* [cap * NL][n] each */, *perm = nullptr /* [cap][2NL + 1][n]: a'_l, s'_l, random */,
        *zs = nullptr /* [cap][S + NL + 1][n] */;
-    Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *pw = nullptr, *evals = nullptr, *wpoly = nullptr, *raw = nullptr,
+    Fe *num = nullptr, *den = nullptr, *tmp = nullptr, *pw = nullptr, *wpoly = nullptr, *raw = nullptr,
        *sraw = nullptr, *sort_fe = nullptr, *ktmp = nullptr;
     uint32_t *sort_u32 = nullptr, *d_err = nullptr;
     XYZZ* xyzz = nullptr;
@@ -184,8 +184,9 @@ struct zg_prover {
     uint32_t* d_idx = nullptr;  // index lists (circuit only: the same for every proof)
     std::map<uint32_t*, std::vector<uint32_t>> uploaded_lists;  // what h2d_list left at each destination
     std::vector<size_t> inst_filled;  // per slot: rows of inst_val that may be non-zero
-    hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_err = nullptr;
     void* pinned = nullptr;
+    void* pinned_dev = nullptr;  // the same memory as the device addresses it (hipHostGetDevicePointer)
     size_t pinned_cap = 0, pin_results = 0, pin_evals = 0, pin_stage = 0;
     size_t stage_off = 0;
     bool have_last = false;
@@ -338,22 +339,26 @@ __global__ void xyzz_sum_ranks_kernel(const XYZZ* __restrict__ parts, uint32_t w
 int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, const Fe* scalars, size_t stride, size_t per,
            size_t outer, size_t count, uint64_t run_mask, uint32_t naf_width = 0) {
     ZG_REQUIRE(count <= p->maxv * (size_t)p->cap, ZG_ERR_INVALID_ARG, "zg_prover: %zu commitments in one phase", count);
-    ZG_TRY(msm_batch4_dev(p->ctx, a, b2, split, scalars + p->shard_lo, stride, per, outer, count, p->shard_n, p->xyzz, run_mask,
-                          naf_width));
+    // The last kernel of the MSM writes its sums straight into the pinned host buffer the transcript reads (the memory is
+    // mapped into the device's address space): no copy command between the MSM and the host -- a command costs a lone
+    // proof its dispatch latency on top of its run time, ~9 us per commitment phase.  Only the in-library RCCL exchange
+    // keeps the sums on the device (all-gather and the additions follow on this stream) and copies the result out.
+    XYZZ* h_out = (XYZZ*)((char*)p->pinned_dev + p->pin_results);
+    ZG_TRY(msm_batch4_dev(p->ctx, a, b2, split, scalars + p->shard_lo, stride, per, outer, count, p->shard_n,
+                          p->rccl_comm ? p->xyzz : h_out, run_mask, naf_width));
     if (p->rccl_comm) {  // ONE all-gather of the phase's partial sums over xGMI, then the additions, all on this stream
         rccl_all_gather_fn gather = rccl_all_gather();
         ZG_REQUIRE(gather != nullptr, ZG_ERR_UNSUPPORTED, "zg_prover: librccl.so could not be loaded");
         const int st = gather(p->xyzz, p->gathered, count * sizeof(XYZZ), /* ncclUint8 */ 1, p->rccl_comm, p->ctx->stream);
         ZG_REQUIRE(st == 0, ZG_ERR_HIP, "zg_prover: ncclAllGather failed with %d", st);
         ZG_LAUNCH(p->ctx, "xyzz_sum_ranks", (double)p->world * count * sizeof(XYZZ), xyzz_sum_ranks_kernel,
-                  dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, p->gathered, p->world, (uint32_t)count, p->xyzz);
+                  dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, p->gathered, p->world, (uint32_t)count, h_out);
         ZG_HIP(hipGetLastError());
     }
-    ZG_HIP(hipMemcpyAsync((char*)p->pinned + p->pin_results, p->xyzz, count * sizeof(XYZZ), hipMemcpyDeviceToHost, p->ctx->stream));
     ZG_HIP(hipEventRecord(p->ev, p->ctx->stream));
     return ZG_OK;
 }
-// ... and waits for ONLY that copy; with a sharded SRS the partial commitments of all ranks are exchanged
+// ... and waits for ONLY that launch sequence; with a sharded SRS the partial commitments of all ranks are exchanged
 // (all-gather) and summed here -- EC addition is not a reduction operator of the collective library
 int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
     // (hipEventSynchronize already polls: the events are created without hipEventBlockingSync.  A hand-written
@@ -499,7 +504,6 @@ int alloc_slots_impl(zg_prover* p, uint32_t cap) {
     if (p->max_points > PC_MAX_POINTS) p->max_points = PC_MAX_POINTS;
     ZG_TRY(dalloc_into(own, &p->pw, c * p->max_points * n));
     p->max_evals = (uint32_t)(k.advice_queries.size() + k.fixed_queries.size()) + P + 3 * S + 5 * NL + 4;
-    ZG_TRY(dalloc_into(own, &p->evals, c * p->max_evals));
     ZG_TRY(dalloc_into(own, &p->wpoly, c * 2 * p->max_points * n));
     p->maxv = std::max<uint32_t>(std::max<uint32_t>(A, 2 * NL + 1), std::max<uint32_t>(S + NL + 1, std::max<uint32_t>(Q, p->max_points)));
     ZG_TRY(dalloc_into(own, &p->xyzz, c * p->maxv));
@@ -512,7 +516,8 @@ int alloc_slots_impl(zg_prover* p, uint32_t cap) {
     p->pin_evals = (c * p->maxv * sizeof(XYZZ) + 4095) & ~size_t(4095);
     p->pin_stage = p->pin_evals + ((c * p->max_evals * sizeof(Fe) + c * NL * 4 + 4095) & ~size_t(4095));
     p->pinned_cap = p->pin_stage + (1u << 20) + c * 16 * sizeof(ProofConst) + c * (size_t)k.I * 4096;
-    ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocDefault));
+    ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocMapped));
+    ZG_HIP(hipHostGetDevicePointer(&p->pinned_dev, p->pinned, 0));
     return ZG_OK;
 }
 
@@ -646,6 +651,7 @@ void zg_prover_destroy(zg_prover* p) {
         if (p->ev) (void)hipEventDestroy(p->ev);
         if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
         if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+        if (p->ev_err) (void)hipEventDestroy(p->ev_err);
         p->pk.reset();  // (the key's HBM goes with its last prover)
     }
     delete p;
@@ -671,6 +677,7 @@ static int prover_events(zg_prover* p) {
     ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    ZG_HIP(hipEventCreateWithFlags(&p->ev_err, hipEventDisableTiming));
     return ZG_OK;
 }
 
@@ -1097,6 +1104,26 @@ int zg_prover_set_shard_rccl(zg_prover* p, uint32_t rank, uint32_t world, size_t
 // challenges.  nb = 1 is the single-proof path (zg_prover_prove / _dev): there is no other.
 // advice_host / advice_dev: per proof, one of them may be given (host columns are uploaded, foreign device columns
 // copied into the proof's slot); both null = the slot already holds the columns (zg_prover_advice_slot).
+// Host-side timeline of a batch (development aid, compiled in with -DZG_TICKS: `make EXTRA=-DZG_TICKS`): every ZG_TICK
+// records a label and the time since the batch began; the list goes to stderr when the batch is done.
+#ifdef ZG_TICKS
+struct TickLog {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char*, double>> v;
+    void tick(const char* l) { v.emplace_back(l, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+    ~TickLog() {
+        double prev = 0;
+        for (auto& e : v) {
+            fprintf(stderr, "tick %9.1f us  +%7.1f  %s\n", e.second, e.second - prev, e.first);
+            prev = e.second;
+        }
+    }
+};
+#define ZG_TICK(l) ticks.tick(l)
+#else
+#define ZG_TICK(l) ((void)0)
+#endif
+
 static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advice_host, void* const* advice_dev,
                             const zg_fr* const* instance, size_t instance_len, const uint8_t* keys /* [count][32] */,
                             uint8_t* const* proofs, size_t proof_cap, size_t* proof_lens, int* statuses) {
@@ -1144,6 +1171,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     }
     p->in_flight = true;
     p->stage_off = p->pin_stage;
+#ifdef ZG_TICKS
+    TickLog ticks;
+#endif
     using clk = std::chrono::steady_clock;
     auto t_start = clk::now(), t_prev = t_start;
     auto lap = [&](int slot) {
@@ -1237,12 +1267,16 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         const Grouping g = grouping(A, adv_bs, pp_bs);
         ZG_TRY(ntt_batch_to_dev(sx, adv, pp_at(p->ix_adv), n, (size_t)nb * A, k, pk.omega_inv, &pk.ifft_div, &g));
         if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_adv, A));
+        ZG_TICK("advice: queued");
         ZG_TRY(wait_points(p, (size_t)nb * A, pts));
+        ZG_TICK("advice: points on the host");
         for (uint32_t b = 0; b < nb; b++)
             for (uint32_t c = 0; c < A; c++) tr[b].write_point(pts[(size_t)b * A + c]);
     }
     for (uint32_t b = 0; b < nb; b++) p->hpc[b].theta = tr[b].squeeze();
+    ZG_TICK("theta");
     ZG_TRY(upload_consts(p, nb));
+    ZG_TICK("theta uploaded");
     lap(0);
 
     Cols base_cols;
@@ -1270,19 +1304,23 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
                                     TAG_PERMUTED_TABLE));
         p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
         ZG_TRY(fork());
+        // the lookups' error words leave on the side stream, beside the commitments (an event of their own)
+        uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
+        ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ss));
+        ZG_HIP(hipEventRecord(p->ev_err, ss));
         // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
         const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);  // (both or neither)
         const uint64_t sorted_runs = cgl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
         ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs, naf_gl_width(p)));
-        uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
-        ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        ZG_HIP(hipEventRecord(p->ev, st));  // (wait_points waits for the error words too)
         {
             const Grouping g = grouping(2 * NL, perm_bs, pp_bs);
             ZG_TRY(ntt_batch_to_dev(sx, p->perm, pp_at(p->ix_perm), n, (size_t)nb * 2 * NL, k, pk.omega_inv, &pk.ifft_div, &g));
         }
         if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_perm, 2 * NL));
+        ZG_TICK("permuted: queued");
         ZG_TRY(wait_points(p, (size_t)nb * (2 * NL + 1), pts));
+        ZG_HIP(hipEventSynchronize(p->ev_err));
+        ZG_TICK("permuted: points on the host");
         for (uint32_t b = 0; b < nb; b++) {
             for (uint32_t l = 0; l < NL; l++)
                 if (h_err[b * NL + l] && status[b] == ZG_OK) {
@@ -1307,7 +1345,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         p->hpc[b].beta = tr[b].squeeze();
         p->hpc[b].gamma = tr[b].squeeze();
     }
+    ZG_TICK("beta, gamma");
     ZG_TRY(upload_consts(p, nb));
+    ZG_TICK("beta, gamma uploaded");
     lap(1);
 
     // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
@@ -1339,7 +1379,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
             ZG_TRY(ntt_batch_to_dev(sx, p->zs, pp_at(p->ix_pz), n, (size_t)nb * mb, k, pk.omega_inv, &pk.ifft_div, &g));
         }
         if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_pz, mb));
+        ZG_TICK("products: queued");
         ZG_TRY(wait_points(p, (size_t)nb * per, pts));
+        ZG_TICK("products: points on the host");
         for (uint32_t b = 0; b < nb; b++) {
             const Jac* q = &pts[(size_t)b * per];
             for (uint32_t i = 0; i < mb; i++) tr[b].write_point(q[i]);
@@ -1355,7 +1397,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     for (uint32_t b = 0; b < nb; b++) tr[b].write_point(random_commit[b]);
     ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
     for (uint32_t b = 0; b < nb; b++) evalh_consts(p->hpc[b], tr[b].squeeze(), hat, evalh_terms(pk));
+    ZG_TICK("y");
     ZG_TRY(upload_consts(p, nb));
+    ZG_TICK("y uploaded");
     lap(2);
 
     // (throughput configuration: nothing overlaps, so every witness polynomial goes to its cosets here, in one batch per
@@ -1391,7 +1435,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
     }
     ZG_TRY(commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0));
+    ZG_TICK("h: queued");
     ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
+    ZG_TICK("h: points on the host");
     for (uint32_t b = 0; b < nb; b++)
         for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
 
@@ -1441,7 +1487,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         c.xn = Fr::pow_u64(x, n);
         for (uint32_t i = 0; i < npoints; i++) c.points[i] = rotate_omega(pk, x, rots[i]);
     }
+    ZG_TICK("x");
     ZG_TRY(upload_consts(p, nb));
+    ZG_TICK("x uploaded");
     lap(3);
     // vanishing.evaluate: h(X) = sum_i xn^i h_i(X)
     uint32_t* d_hlist = p->d_idx + (size_t)4 * p->max_evals;
@@ -1458,10 +1506,13 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         idx[evq.size() + i] = evq[i].slot;
     }
     ZG_TRY(h2d_list(p, p->d_idx, idx));
-    ZG_TRY(poly_dot(ctx, polys, nb, n, p->d_idx, p->d_idx + evq.size(), p->pw, pw_bs, (uint32_t)evq.size(), p->evals, p->max_evals));
+    // (the evaluations too are written where the host reads them: no copy command behind the kernel)
+    ZG_TRY(poly_dot(ctx, polys, nb, n, p->d_idx, p->d_idx + evq.size(), p->pw, pw_bs, (uint32_t)evq.size(),
+                    reinterpret_cast<Fe*>((char*)p->pinned_dev + p->pin_evals), p->max_evals));
     const Fe* ev_all = reinterpret_cast<const Fe*>((char*)p->pinned + p->pin_evals);
-    ZG_HIP(hipMemcpyAsync((void*)ev_all, p->evals, ((size_t)(nb - 1) * p->max_evals + evq.size()) * sizeof(Fe), hipMemcpyDeviceToHost, st));
+    ZG_TICK("evals: queued");
     ZG_HIP(hipStreamSynchronize(st));
+    ZG_TICK("evals on the host");
 
     // ---- opening queries in create_proof's order: (poly, point slot, index of the evaluation)
     struct OQ { uint32_t poly, slot; size_t ev; };
@@ -1522,6 +1573,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         }
     }
     ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u opening points", nsets);
+    ZG_TICK("opening sets listed");
     for (uint32_t b = 0; b < nb; b++) {
         const Fe* ev = ev_all + (size_t)b * p->max_evals;
         for (size_t i = 0; i < e_written; i++) tr[b].write_scalar(ev[i]);
@@ -1533,7 +1585,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
             c.subs[s] = eval_batch;
         }
     }
+    ZG_TICK("v");
     ZG_TRY(upload_consts(p, nb));
+    ZG_TICK("v uploaded");
     lap(4);
     {
         // poly_batch of every point set in one launch: set s -> wpoly[2s]
@@ -1546,7 +1600,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
                                   wp_bs, p->ktmp, n));
         // the witness polynomials sit at odd slots: stride 2n
         ZG_TRY(commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0));
+        ZG_TICK("gwc: queued");
         ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
+        ZG_TICK("gwc: points on the host");
         for (uint32_t b = 0; b < nb; b++)
             for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
     }
@@ -1569,6 +1625,7 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         }
         if (statuses) statuses[b] = status[b];
     }
+    ZG_TICK("proof bytes out");
     lap(5);
     p->phase_ms[6] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
     p->in_flight = false;
