@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- create_proof of zero_g's WNN circuit on MI355X (BASELINE.json metric).
 
-A "step" is `--provers` (default 12) lock-step batches of `--batch` (default 16) full create_proofs each: every
+A "step" is `--provers` (default 12) lock-step batches of `--batch` (default 32) full create_proofs each: every
 prover works on its own HIP stream from its own host thread (while one batch waits for its transcript hashes on
 the host, the other keeps the GPU busy) and makes its B proofs with ONE launch sequence (zg_prover_prove_batch: the
 commitments of a phase are one MSM over B x columns vectors, evaluate_h one grid with a row of workgroups per
@@ -409,7 +409,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", choices=sorted(MODELS), default="tiny",
                     help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
-    ap.add_argument("--batch", type=int, default=16, help="proofs per lock-step batch (zg_prover_prove_batch)")
+    ap.add_argument("--batch", type=int, default=32, help="proofs per lock-step batch (zg_prover_prove_batch)")
     ap.add_argument("--provers", type=int, default=None,
                     help="proof streams per GPU (provers sharing one proving key): 12; 4 in shard-msm, where every prover "
                          "holds a communicator of its own")
@@ -511,6 +511,9 @@ def main():
         ms_per_proof = dt / (args.steps * proofs_per_step) * 1e3
         proofs_per_hour = n_proofs / dt * 3600.0
         pmc = load_pmc() if args.model == "tiny" and not sharded else None
+        # (the counter passes were taken at pmc["proofs_per_launch"] proofs per launch: every kernel of the path processes
+        #  the proofs of a batch side by side, so bytes per launch scale with the batch)
+        pmc_scale = batch / float(pmc.get("proofs_per_launch", batch)) if pmc else 1.0
         launches_per_proof = sum(v[0] for v in stats.values()) / max(1, args.steps * proofs_per_step)
         # per kernel and per family: device time, algorithmic bytes (DESIGN.md's per-unit figures x units per launch),
         # algorithmic GB/s against the HBM peak, counter bytes / algorithmic bytes
@@ -520,12 +523,12 @@ def main():
             kernels[name] = {"launches": l, "total_ms": round(ms, 3), "avg_launch_ms": ms / max(l, 1),
                              "algo_bytes_per_launch": by / max(l, 1),
                              "algo_GBps": (by / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
-                             "hbm_bytes_per_launch": k_pmc["hbm_bytes_per_launch"] if k_pmc else None}
+                             "hbm_bytes_per_launch": int(k_pmc["hbm_bytes_per_launch"] * pmc_scale) if k_pmc else None}
             f = fam.setdefault(family_of(name), {"total_ms": 0.0, "algo_bytes": 0.0, "hbm_bytes": 0.0, "hbm_known": True})
             f["total_ms"] += ms
             f["algo_bytes"] += by
             if k_pmc:
-                f["hbm_bytes"] += k_pmc["hbm_bytes_per_launch"] * l
+                f["hbm_bytes"] += k_pmc["hbm_bytes_per_launch"] * pmc_scale * l
             else:
                 f["hbm_known"] = False
         device_ms = sum(v[1] for v in stats.values())
@@ -645,7 +648,8 @@ def main():
         circuit.gl_bases.free()
         for m in ("small", "medium", "large"):
             c2 = Circuit(ctx0, m)
-            b2 = batch if m != "large" else max(1, batch // 2)
+            # (k = 15 slots are 0.34 GiB, k = 17 slots 1.4 GiB: batches of 16 and 8 keep 12 provers inside the 288 GB)
+            b2 = min(batch, 16) if m != "large" else min(batch, 8)
             np2 = min(nprov, 12)  # (a k = 17 slot is 1.4 GiB: 12 provers x 8 slots + workspaces = 175 GB of the 288)
             cx, st2, (lat, _) = make_streams(dev_index, c2, ctx0, np2, b2, rank, probe=latency_probe)
             dt2, _ = measure(st2, cx, 3, 1, barrier)

@@ -21,7 +21,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles", "r03")
 os.makedirs(dst, exist_ok=True)
-BATCH = 16
+BATCH = int(os.environ.get("BATCH", "32"))  # proofs per lock-step batch of the profiled runs (tools/profile_r03.sh)
 SIMDS = 256 * 4
 
 
@@ -102,7 +102,7 @@ GATHER_KERNELS = {"msm_accumulate": 1.0}
 
 fetch, nf, nbat = per_launch(one("pmc_FETCH_SIZE/*/*_counter_collection.csv"))
 write, _, _ = per_launch(one("pmc_WRITE_SIZE/*/*_counter_collection.csv"))
-out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of ONE prover making lock-step batches of 16 "
+out = {"_note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of ONE prover making lock-step batches of {BATCH} "
                 "(tools/profile_r03.sh: kernels serialised); counters are KB per dispatch; bytes per launch = "
                 "(fetch_correction * FETCH + WRITE) * 1024 averaged over the launches inside complete create_proof batches; "
                 "fetch_correction = 2 for kernels that stream 16 B per lane (the gfx950 halving, MI355X_MICROARCH.md), 1 for "
@@ -119,8 +119,8 @@ sq1, n1, nb1 = per_launch(one("pmc_sq1/*/*_counter_collection.csv"))
 sq2, n2, _ = per_launch(one("pmc_sq2/*/*_counter_collection.csv"))
 per = {k: sq1[k]["SQ_INSTS_VALU"] / (nb1 * BATCH) for k in sq1}
 total = sum(per.values())
-out["valu"] = {"_note": "VALU wave-instructions one create_proof issues in the benchmarked form (lock-step batch of 16, split "
-                        "extended domain): SQ_INSTS_VALU summed over the kernels of a batch / 16, averaged over the run's batches",
+out["valu"] = {"_note": f"VALU wave-instructions one create_proof issues in the benchmarked form (lock-step batch of {BATCH}, split "
+                        f"extended domain): SQ_INSTS_VALU summed over the kernels of a batch / {BATCH}, averaged over the run's batches",
                "source": f"profiles/r03/{tag}_valu_instructions_per_proof.txt", "batches": nb1,
                "wave_instructions_per_proof": total, "by_kernel": dict(sorted(per.items(), key=lambda kv: -kv[1]))}
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
@@ -132,7 +132,7 @@ with open(os.path.join(dst, f"{tag}_valu_instructions_per_proof.txt"), "w") as f
 # ---- issue saturation, kernel by kernel (each alone on the chip)
 issue = {"_note": "rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU "
                   "SQ_INSTS_VALU GRBM_GUI_ACTIVE and a second pass with SQ_INSTS_VALU_INT64/INT32, LDS and VMEM counters; ONE prover, "
-                  "batches of 16, kernels serialised.  SQ_* cycle counters are quad-cycles (MI355X_MICROARCH.md); clock = "
+                  f"batches of {BATCH}, kernels serialised.  SQ_* cycle counters are quad-cycles (MI355X_MICROARCH.md); clock = "
                   "GRBM_GUI_ACTIVE / 8 XCDs / duration; waves_per_simd = 4 * SQ_WAVE_CYCLES / (1024 SIMDs * cycles); active / "
                   "issue_stall / wait = SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY / SQ_WAIT_ANY over SQ_WAVE_CYCLES (they add up to 1); "
                   "valu_issue_util = 4 cycles * SQ_INSTS_VALU / (1024 SIMDs * cycles): the share of all SIMD issue cycles that a "
@@ -183,7 +183,7 @@ for b in tb:
         ser[n][0] += 1
         ser[n][1] += ns
 ser_total = sum(v[1] for v in ser.values())
-serial = {"_note": "rocprofv3 --kernel-trace of ONE prover making lock-step batches of 16 (one stream: every kernel alone on the chip); "
+serial = {"_note": f"rocprofv3 --kernel-trace of ONE prover making lock-step batches of {BATCH} (one stream: every kernel alone on the chip); "
                    "launches inside complete create_proof batches only", "batches": len(tb), "proofs_per_launch": BATCH,
           "device_us_per_proof": ser_total / (len(tb) * BATCH) / 1e3, "kernels": {}}
 for k in sorted(ser, key=lambda k: -ser[k][1]):

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round-3 profile on the GPU box:  ./tools/profile_r03.sh TAG     (outputs under gpurun_out/prof_TAG/)
-#   1. SERIALISED kernel stats: rocprofv3 --kernel-trace --stats of ONE prover making lock-step batches of 16 (one
+#   1. SERIALISED kernel stats: rocprofv3 --kernel-trace --stats of ONE prover making lock-step batches of $BATCH (default 32; one
 #      stream: every kernel alone on the chip) -- the per-kernel table of DESIGN.md section 4
 #   2. the same trace of the default bench command (12 provers sharing the chip): the roofline object's cross-check
-#   3. counter passes of ONE prover x 16 (kernels serialised under counter collection), separate passes, no tracing flags:
+#   3. counter passes of ONE prover x one batch (kernels serialised under counter collection), separate passes, no tracing flags:
 #        sq1: SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU
 #             SQ_INSTS_VALU + GRBM_GUI_ACTIVE      (issue saturation: active / wait split of the wave cycles, clock)
 #        sq2: SQ_INST_CYCLES_VALU SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS
@@ -13,11 +13,12 @@
 #   5. the bench line itself, without the profiler
 # tools/install_r03.py TAG copies the summaries into profiles/r03/.
 set -e
+[ -x tools/fetch_calib.bin ] || hipcc -O3 --offload-arch=gfx950 tools/fetch_calib.hip -o tools/fetch_calib.bin
 TAG=${1:-cur}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
-ONE="--steps 3 --warmup 1 --provers 1 --batch 16 --no-kernel-events --no-cpu-baseline --no-other-configs --no-verify --no-latency-probe --no-image-to-proof --no-serialised"
+ONE="--steps 3 --warmup 1 --provers 1 --batch ${BATCH:-32} --no-kernel-events --no-cpu-baseline --no-other-configs --no-verify --no-latency-probe --no-image-to-proof --no-serialised"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -- python3 $R/bench.py $ONE > $OUT/serial_bench.json 2> $OUT/serial.log
 echo "serial trace done"
