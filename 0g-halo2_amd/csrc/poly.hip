@@ -1097,10 +1097,11 @@ __device__ __forceinline__ const Fe* poly_of(const PolySet& ps, uint32_t ix, uin
     return ix < ps.nsh ? ps.sh + (size_t)ix * ps.n : ps.pp + (size_t)b * ps.pp_bs + (size_t)(ix - ps.nsh) * ps.n;
 }
 
-// pow[b][s][i] = x^i for x = pc[b].points[s]: lane computes x^(i0) by square-and-multiply, then a strip of 16 products
+// pow[b][s][i] = x^i for x = pc[b].points[s]: lane computes x^(i0) by square-and-multiply, then a strip of CH products
+// (16 in the throughput form; 4 for a lone proof, which waits for the dependent chain: 28 + 4 products instead of 28 + 16)
+template <uint32_t CH>
 __global__ __launch_bounds__(256) void powers_kernel(const ProofConst* __restrict__ pc, uint32_t n, Fe* __restrict__ pw,
                                                      size_t pw_bs) {
-    constexpr uint32_t CH = 16;
     uint32_t i0 = (blockIdx.x * blockDim.x + threadIdx.x) * CH;
     if (i0 >= n) return;
     const uint32_t sl = blockIdx.y, b = blockIdx.z;
@@ -1116,8 +1117,12 @@ __global__ __launch_bounds__(256) void powers_kernel(const ProofConst* __restric
 int poly_powers(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, uint32_t npoints, uint32_t n, Fe* d_pow, size_t pw_bs) {
     if (!npoints || !nb) return ZG_OK;
     ZG_REQUIRE(npoints <= PC_MAX_POINTS, ZG_ERR_UNSUPPORTED, "poly_powers: %u opening points (max %u)", npoints, PC_MAX_POINTS);
-    ZG_LAUNCH(ctx, "powers", (double)nb * npoints * n * 32, powers_kernel, dim3((n + 256 * 16 - 1) / (256 * 16), npoints, nb),
-              dim3(256), 0, pc, n, d_pow, pw_bs);
+    if (ctx->msm_pair)
+        ZG_LAUNCH(ctx, "powers", (double)nb * npoints * n * 32, powers_kernel<4>, dim3((n + 256 * 4 - 1) / (256 * 4), npoints, nb),
+                  dim3(256), 0, pc, n, d_pow, pw_bs);
+    else
+        ZG_LAUNCH(ctx, "powers", (double)nb * npoints * n * 32, powers_kernel<16>, dim3((n + 256 * 16 - 1) / (256 * 16), npoints, nb),
+                  dim3(256), 0, pc, n, d_pow, pw_bs);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -1421,7 +1426,7 @@ __global__ __launch_bounds__(1024) void kd_heads_kernel(const ProofConst* __rest
         w = Fr::sqr(w);
         __syncthreads();
     }
-    Fe carry = tid + 1 < 1024 ? sh[tid + 1] : fe_zero();
+    Fe carry = tid + 1 < span ? sh[tid + 1] : fe_zero();
     __syncthreads();
     if (tid < nblk) stg(hp + tid, carry);
 }
@@ -1463,7 +1468,10 @@ int poly_kate_division(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, const uin
         const double bytes = (double)m * n * 64;
         ZG_LAUNCH(ctx, "kate_local", bytes, kd_local_kernel, dim3(nblk, nsets, nb), dim3(KD_BLOCK), 0, pc, ks, a, a_stride, a_bs, loc,
                   heads, n, nblk);
-        ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(m), dim3(1024), 0, pc, ks, nsets, heads, nblk);
+        // (as many lanes as block heads, a power of two from 64: at n = 2^14 one wave, whose barriers cost nothing)
+        uint32_t hl = 64;
+        while (hl < nblk) hl <<= 1;
+        ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(m), dim3(hl), 0, pc, ks, nsets, heads, nblk);
         ZG_LAUNCH(ctx, "kate_apply", bytes, kd_apply_kernel, dim3(nblk, nsets, nb), dim3(KD_BLOCK), 0, pc, ks, loc, heads, q, q_stride,
                   q_bs, n, nblk);
         ZG_HIP(hipGetLastError());

@@ -45,7 +45,7 @@ def launch_name(kernel: str) -> str:
              "pp_flags": "permute_flags", "pp_scan": "permute_scan", "pp_scan_local": "permute_scan", "pp_scan_tiles": "permute_scan", "pp_leftover": "permute_leftover",
              "pp_build": "permute_build", "random_and_blind": "random_poly", "evaluate_h9": "evaluate_h",
              "horner_combine_sets": "horner_combine", "msm_digits_naf": "msm_digits", "sort_global_fused": "sort_global",
-             "gate_factor9": "gate_factor"}
+             "gate_factor9": "gate_factor", "combine9": "horner_combine", "dot9": "eval_dot", "msm_accumulate_full": "msm_accumulate_full"}
     return alias.get(k, k)
 
 
