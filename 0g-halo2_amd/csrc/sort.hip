@@ -39,7 +39,7 @@ __device__ __forceinline__ int key_cmp(const Fe& a, const Fe& b) {
 }
 
 constexpr uint32_t SORT_CH = 1024;  // keys per LDS chunk (32 KB)
-constexpr uint32_t SORT_NT = 256;
+constexpr uint32_t SORT_NT = 512;
 
 // keys[b][i] for i >= usable <- all-ones sentinel (sorts last; real keys are < r < 2^254)
 __global__ void sort_pad_kernel(Fe* keys, uint32_t n, uint32_t usable) {
