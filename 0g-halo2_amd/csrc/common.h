@@ -113,6 +113,7 @@ struct zg_ctx {
     zg_ctx* side = nullptr;  // optional second stream + workspace pool (created on demand, same device)
     // MSM bucket reduction with two lanes per EC addition (latency) or one (throughput); see msm.hip
     bool msm_pair = true;
+    bool msm_dense_hint = false;  // set by a caller around an MSM whose vectors are all random (latency form: one lane per task)
     uint32_t* msm_tickets = nullptr;  // last-workgroup-done counters of the MSM reduction (msm.hip), zero between launches
 };
 

@@ -984,14 +984,18 @@ __global__ __launch_bounds__(64) void msm_full_table_kernel(const Affine* __rest
 // the launch is as long as its longest pair -- and a wave's reads of the digit array are coalesced.  The table point of
 // the NEXT entry is requested before the current one is added: a gather from a 26 GB table (an HBM and a TLB miss) takes
 // as long as the addition it hides behind.
-template <bool FUSE>
-__global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
+template <bool FUSE, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 256 : 128) void msm_accumulate_full_kernel(
     const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table, uint32_t D,
     uint32_t windows, uint32_t n, const uint32_t* __restrict__ dig, uint32_t tasks, XYZZ9* __restrict__ partial,
     const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask, uint32_t per) {
+    // PAIR: a task's running sum lives half in each lane of a pair (five products per lane and point: the shorter chain a
+    // latency-bound launch wants); !PAIR: one lane per task (ten products, none of the pair's exchanges and selects -- ~15 %
+    // fewer instructions per addition: what a launch of all-random vectors wants, whose every entry is an addition and
+    // whose pairs fill the chip several times over).  128 tasks per workgroup either way.
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t t = lane >> 1;
-    const bool role_a = (lane & 1u) == 0;
+    const uint32_t t = PAIR ? lane >> 1 : lane;
+    const bool role_a = PAIR ? (lane & 1u) == 0 : true;
     const uint32_t b = blockIdx.y;
     // (pairs are never split: 2 * tasks lanes, even block size; a pair beyond the last task adds nothing and hands the
     //  workgroup's tree the identity)
@@ -1003,7 +1007,12 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
     const uint32_t step_w = tasks / n, step_i = tasks - step_w * n;  // one stride in (window, point) coordinates
     uint32_t e = t < tasks ? t : entries, w = t / n, i = t - w * n;
     PairAcc acc;
+    XYZZ9 acc1;
     bool inf = true;
+    auto add_point = [&](const F9& qx, const F9& qy) {
+        if constexpr (PAIR) xmadd_pair(acc, inf, qx, qy, role_a);
+        else xyzz9_madd(acc1, inf, qx, qy);
+    };
     // the point in hand (requested one non-zero entry ahead of its addition)
     uint32_t ent = 0;
     Fe px = fe_zero(), py = fe_zero();
@@ -1031,7 +1040,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
                     F9 qy = f9_unpack(py);
                     if (!(f9_limbs_zero(qx) && f9_limbs_zero(qy))) {  // (identity base point)
                         if (ent >> 31) qy = f9_neg(qy);
-                        xmadd_pair(acc, inf, qx, qy, role_a);
+                        add_point(qx, qy);
                     }
                 }
                 ent = cur;
@@ -1053,7 +1062,7 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
         F9 qy = f9_unpack(py);
         if (!(f9_limbs_zero(qx) && f9_limbs_zero(qy))) {
             if (ent >> 31) qy = f9_neg(qy);
-            xmadd_pair(acc, inf, qx, qy, role_a);
+            add_point(qx, qy);
         }
     }
     // FUSE: the workgroup's 128 partial sums are folded here, through LDS, by 64 four-lane groups (seven levels) -- one
@@ -1062,10 +1071,12 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
     // a launch of several rounds would wait seven additions at the end of EVERY round with most lanes idle, so those
     // write their partial sums and leave them to msm_tree_kernel (k = 15, same box: 3.64 ms fused everywhere against 3.72).
     __shared__ XYZZ9 sums[FUSE ? MSM_FULL_PAIRS : 1];
-    XYZZ9* dst = FUSE ? &sums[threadIdx.x >> 1] : partial + (size_t)b * tasks + t;
+    XYZZ9* dst = FUSE ? &sums[PAIR ? threadIdx.x >> 1 : threadIdx.x] : partial + (size_t)b * tasks + t;
     if (!FUSE && t >= tasks) return;
     if (inf) {
         if (role_a) st_xyzz9(dst, xyzz9_identity());
+    } else if (!PAIR) {
+        st_xyzz9(dst, acc1);
     } else if (role_a) {
         st_f9(&dst->x, acc.m);
         st_f9(&dst->zz, acc.z);
@@ -1075,9 +1086,9 @@ __global__ __launch_bounds__(256) void msm_accumulate_full_kernel(
     }
     if (!FUSE) return;
     __syncthreads();
-    const uint32_t q = threadIdx.x >> 2, role = threadIdx.x & 3u;
+    const uint32_t q0 = threadIdx.x >> 2, nq = blockDim.x >> 2, role = threadIdx.x & 3u;
     for (uint32_t o = MSM_FULL_PAIRS / 2; o > 0; o >>= 1) {
-        if (q < o) xstore<true>(&sums[q], xaddl<4>(&sums[q], &sums[q + o], role));
+        for (uint32_t q = q0; q < o; q += nq) xstore<true>(&sums[q], xaddl<4>(&sums[q], &sums[q + o], role));
         __syncthreads();
     }
     if (threadIdx.x == 0) st_xyzz9(partial + (size_t)b * gridDim.x + blockIdx.x, sums[0]);
@@ -1214,16 +1225,24 @@ static int msm_full_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* base
                  *rb = bases_b ? bases_b->full_run_table.load(std::memory_order_acquire) : ra;
     ZG_LAUNCH(ctx, "msm_digits", msm_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride, (uint32_t)per,
               outer, N, c, W, 0u, dig, run_mask);
+    // (the prover marks the launches whose vectors are all random -- the quotient pieces, the opening quotients: one lane
+    //  per task there, lane pairs everywhere else)
+    const bool single = ctx->msm_dense_hint && (uint64_t)B * tasks >= 65536;
+#define ZG_ACC_FULL(FUSE_, PAIR_, out_)                                                                                         \
+    ZG_LAUNCH(ctx, "msm_accumulate_full", msm_bytes, (msm_accumulate_full_kernel<FUSE_, PAIR_>), dim3(nwg, B),                   \
+              dim3((PAIR_ ? 2 : 1) * MSM_FULL_PAIRS), 0, ta, tb, (uint32_t)split, (uint32_t)bases->n, D, W, N, dig, tasks, out_, \
+              ra, rb, run_mask, (uint32_t)per)
     if (fuse) {
-        ZG_LAUNCH(ctx, "msm_accumulate_full", msm_bytes, msm_accumulate_full_kernel<true>, dim3(nwg, B), dim3(2 * MSM_FULL_PAIRS), 0, ta,
-                  tb, (uint32_t)split, (uint32_t)bases->n, D, W, N, dig, tasks, stage, ra, rb, run_mask, (uint32_t)per);
+        if (single) ZG_ACC_FULL(true, false, stage);
+        else ZG_ACC_FULL(true, true, stage);
     } else {
-        ZG_LAUNCH(ctx, "msm_accumulate_full", msm_bytes, msm_accumulate_full_kernel<false>, dim3(nwg, B), dim3(2 * MSM_FULL_PAIRS), 0, ta,
-                  tb, (uint32_t)split, (uint32_t)bases->n, D, W, N, dig, tasks, partial, ra, rb, run_mask, (uint32_t)per);
+        if (single) ZG_ACC_FULL(false, false, partial);
+        else ZG_ACC_FULL(false, true, partial);
         ZG_LAUNCH(ctx, "msm_tree", msm_bytes, msm_tree_kernel, dim3(n1, B), dim3(4 * MSM_TREE_GROUPS), 0, partial, tasks, G1, stage,
                   (XYZZ*)nullptr);
     }
     ZG_LAUNCH(ctx, "msm_tree", msm_bytes, msm_tree_kernel, dim3(1, B), dim3(4 * MSM_TREE_GROUPS), 0, stage, n1, G2, (XYZZ9*)nullptr, d_out);
+#undef ZG_ACC_FULL
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }

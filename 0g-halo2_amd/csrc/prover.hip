@@ -1434,7 +1434,10 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
         ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
     }
-    ZG_TRY(commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0));
+    ctx->msm_dense_hint = true;  // (the quotient pieces are random vectors: every digit of every window is an addition)
+    const int st_h = commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0);
+    ctx->msm_dense_hint = false;
+    ZG_TRY(st_h);
     ZG_TICK("h: queued");
     ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
     ZG_TICK("h: points on the host");
@@ -1599,7 +1602,10 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
                                   wp_bs, p->ktmp, n));
         // the witness polynomials sit at odd slots: stride 2n
-        ZG_TRY(commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0));
+        ctx->msm_dense_hint = true;  // (so are the opening quotients)
+        const int st_w = commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0);
+        ctx->msm_dense_hint = false;
+        ZG_TRY(st_w);
         ZG_TICK("gwc: queued");
         ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
         ZG_TICK("gwc: points on the host");
