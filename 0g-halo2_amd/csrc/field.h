@@ -333,6 +333,9 @@ struct Field {
                 if (geq(u, v)) { sub4(u, u, v); sub_mod(x1, x2); }
                 else { sub4(v, v, u); sub_mod(x2, x1); }
             }
+            // budget exhausted (a non-canonical multiple of p, a corrupted modulus): 0, as for a = 0 -- never a value that
+            // could pass for an inverse
+            if (!is_one(u) && !is_one(v)) return fe_zero();
             const uint64_t* res = is_one(u) ? x1 : x2;
             Fe r;
             for (int i = 0; i < 4; i++) {
@@ -406,6 +409,7 @@ struct Field {
             }
         }
         Fe r;
+        if (!is_one(u) && !is_one(v)) return fe_zero();  // (budget exhausted: 0, never a would-be inverse)
         const uint32_t* res = is_one(u) ? x1 : x2;
 #pragma unroll
         for (int i = 0; i < 8; i++) r.l[i] = res[i];

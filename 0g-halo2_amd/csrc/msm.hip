@@ -1123,21 +1123,22 @@ __global__ __launch_bounds__(4 * MSM_TREE_GROUPS) void msm_tree_kernel(const XYZ
 // window bits of a set's digit tables: the largest c whose three tables of a prover (g, g_lagrange, its running sums)
 // stay under 90 GB -- 11 at n = 2^14 (3 x 26 GB), 10 at 2^15 (3 x 28 GB) -- and none from n = 2^16 on, where
 // a lone proof is bound by its work and the windows' extra additions would cost more than the buckets they remove.
-static uint32_t default_full_bits(size_t n) {
+// `budget` = bytes the THREE tables of a prover may take together (0: the library's cap, 90 GB).
+uint32_t default_full_bits(size_t n, double budget) {
     const int env = knob(K_LAT_FULL_C);
     if (env == 0) return 0;
-    if (env >= (int)MSM_FULL_MIN_C && env <= (int)MSM_FULL_MAX_C) return (uint32_t)env;
+    if (budget <= 0.0) budget = 90e9;
+    auto bytes_at = [&](uint32_t c) { return 3.0 * (double)((255 + c - 1) / c) * (double)(1u << (c - 1)) * (double)n * sizeof(Affine); };
+    if (env >= (int)MSM_FULL_MIN_C && env <= (int)MSM_FULL_MAX_C) return bytes_at((uint32_t)env) <= budget ? (uint32_t)env : 0;
     if (n >= ((size_t)1 << 16)) return 0;
     uint32_t lg = 0;
     while (((size_t)2 << lg) <= n) lg++;
     // (small sets: windows of lg n - 3 bits keep the table at ~n^2 / 8 points; large ones: what the memory allows)
     uint32_t c = lg > MSM_FULL_MIN_C + 3 ? lg - 3 : MSM_FULL_MIN_C;
     if (c > MSM_FULL_MAX_C) c = MSM_FULL_MAX_C;
-    for (; c > MSM_FULL_MIN_C; c--) {
-        const double bytes = 3.0 * (double)((255 + c - 1) / c) * (double)(1u << (c - 1)) * (double)n * sizeof(Affine);
-        if (bytes <= 90e9) break;
-    }
-    return c;
+    for (; c > MSM_FULL_MIN_C; c--)
+        if (bytes_at(c) <= budget) break;
+    return bytes_at(c) <= budget ? c : 0;
 }
 
 static int build_full_table(zg_ctx* ctx, const Affine* table0_hat, size_t n, uint32_t c, Affine** out) {
@@ -1177,7 +1178,7 @@ static int build_full_table(zg_ctx* ctx, const Affine* table0_hat, size_t n, uin
 
 int bases_enable_full(zg_ctx* ctx, zg_bases* b, uint32_t window_bits, bool with_runs) {
     std::lock_guard<std::mutex> lock(b->mu);
-    uint32_t c = b->full_c ? b->full_c : window_bits ? window_bits : default_full_bits(b->n);
+    uint32_t c = b->full_c ? b->full_c : window_bits ? window_bits : default_full_bits(b->n, 0.0);
     if (c == 0) return ZG_OK;
     ZG_REQUIRE(c >= MSM_FULL_MIN_C && c <= MSM_FULL_MAX_C, ZG_ERR_INVALID_ARG, "bases_enable_full: window_bits %u not in [4,12]", c);
     ZG_REQUIRE(!b->full_c || !window_bits || window_bits == b->full_c, ZG_ERR_INVALID_ARG,

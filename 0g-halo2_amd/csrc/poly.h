@@ -236,6 +236,7 @@ int bases_register_dev(zg_ctx* ctx, const Affine* d_bases, size_t n, uint32_t wi
 // digit tables of the latency form (every multiple of every window; window_bits 0 = from n and the free memory, which may
 // decide on none); with_runs: for the running sums too (the set must have its running-sum table)
 int bases_enable_full(zg_ctx* ctx, zg_bases* b, uint32_t window_bits, bool with_runs);
+uint32_t default_full_bits(size_t n, double budget_bytes);  // 0 = no digit tables at this size / budget
 void xyzz_batch_normalise(const XYZZ* in, size_t count, zg_g1* out);
 
 }  // namespace zg

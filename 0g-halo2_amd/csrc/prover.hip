@@ -145,7 +145,6 @@ struct zg_prover {
     // what a LONE proof (latency form) borrows from the throughput form once the circuit is large enough for the work
     // to outweigh the launches (from k: K_LAT_SPLIT_K)
     bool lat_split = false;
-    bool full_tried = false;  // the latency form's digit tables were asked for (once per prover; bases_enable_full is idempotent)
     uint32_t naf_gl_w = 0;  // digit width of the run-form commitments' free-position form, 0 = windows (naf_gl_default)
     // point-range shard of the commitments (zg_prover_set_shard): this prover's base sets hold points
     // [shard_lo, shard_lo + shard_n) of the SRS; partial commitments of all ranks are exchanged and summed
@@ -1166,13 +1165,6 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         (void)hipStreamSynchronize(st);  // arena and slots are reused
         if (ctx->side) (void)hipStreamSynchronize(ctx->side->stream);
     }
-    if (p->use_side && !p->full_tried) {
-        // the latency form's digit tables (msm.hip: every multiple of every window -- no buckets), built once per base
-        // set the first time a proof runs in this form; no room or n too large: the bucket form stays
-        p->full_tried = true;
-        ZG_TRY(bases_enable_full(ctx, p->g, 0, false));
-        ZG_TRY(bases_enable_full(ctx, p->gl, 0, true));
-    }
     p->in_flight = true;
     p->stage_off = p->pin_stage;
 #ifdef ZG_TICKS
@@ -1683,6 +1675,36 @@ int zg_prover_set_overlap(zg_prover* p, int enable) {
     p->use_side = enable != 0;
     p->ctx->msm_pair = enable != 0;  // latency configuration: two lanes per addition in the MSM reduction
     p->lat_split = lone_split(p, enable != 0);
+    return ZG_OK;
+}
+
+// The latency form's digit tables (msm.hip: every multiple of every window -- no buckets) of this prover's base sets:
+// g, g_lagrange and the running sums of g_lagrange.  EXPLICIT since round 4: tens of GB and seconds of build
+// time are the caller's decision, never a side effect of the first proof.
+int zg_prover_enable_digit_tables(zg_prover* p, uint64_t max_bytes, uint64_t* bytes_built) {
+    ZG_REQUIRE(p, ZG_ERR_INVALID_ARG, "zg_prover_enable_digit_tables: null prover");
+    zg_ctx* ctx = p->ctx;
+    ZG_ENTER(ctx);
+    if (bytes_built) *bytes_built = 0;
+    ZG_REQUIRE(p->g->n == p->gl->n, ZG_ERR_INVALID_ARG, "zg_prover_enable_digit_tables: the base sets differ in length");
+    uint32_t c = p->g->full_c ? p->g->full_c : p->gl->full_c;
+    if (!c) {
+        size_t free_b = 0, total_b = 0;
+        ZG_HIP(hipMemGetInfo(&free_b, &total_b));
+        // the library's own cap: a third of the card (90 GB of the MI355X's 288), and never more than what is free now
+        // minus a reserve of 8 GiB per table build
+        double budget = max_bytes ? (double)max_bytes : (double)total_b / 3.0;
+        if (budget > 90e9 && !max_bytes) budget = 90e9;
+        if (budget + 3.0 * 8.0 * 1073741824.0 > (double)free_b) budget = (double)free_b - 3.0 * 8.0 * 1073741824.0;
+        c = budget > 0 ? default_full_bits(p->g->n, budget) : 0;
+    }
+    if (!c) return ZG_OK;  // (n too large, the knob says none, or no room inside the budget: the bucket form stays)
+    ZG_TRY(bases_enable_full(ctx, p->g, c, false));
+    ZG_TRY(bases_enable_full(ctx, p->gl, c, true));
+    if (bytes_built) {
+        const uint64_t one = (uint64_t)((255 + c - 1) / c) * (1ull << (c - 1)) * p->g->n * sizeof(Affine);
+        *bytes_built = (p->g->full_table.load() ? one : 0) + (p->gl->full_table.load() ? one : 0) + (p->gl->full_run_table.load() ? one : 0);
+    }
     return ZG_OK;
 }
 

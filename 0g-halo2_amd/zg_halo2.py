@@ -73,7 +73,7 @@ ABI_SYMBOLS = [
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
     "zg_witness_plan_create", "zg_witness_plan_destroy", "zg_witness_plan_image_bytes", "zg_witness_plan_instance_len",
     "zg_witness_run_dev", "zg_prover_prove_images", "zg_prover_set_shard_rccl", "zg_xyzz_sum_ranks_dev", "zg_bases_enable_bit_table",
-    "zg_tuning_set", "zg_tuning_get", "zg_tuning_names", "zg_bases_enable_digit_table",
+    "zg_tuning_set", "zg_tuning_get", "zg_tuning_names", "zg_bases_enable_digit_table", "zg_prover_enable_digit_tables",
 ]
 
 def tuning_names() -> list:
@@ -612,9 +612,22 @@ class Prover:
                                                  _ptr(_fr(y)), _ptr(out)))
         return out
 
-    def set_overlap(self, enable: bool):
-        """True (default): transforms on a side stream (latency); False: one stream per proof (throughput)."""
+    def set_overlap(self, enable, digit_tables: bool = False):
+        """True (default): transforms on a side stream (latency); False: one stream per proof (throughput).
+        enable == "tables" or digit_tables=True: the latency form AND its digit tables (enable_digit_tables) -- the
+        tables are never built implicitly."""
+        if enable == "tables":
+            enable, digit_tables = True, True
         _check(self.ctx.lib.zg_prover_set_overlap(self.h, ctypes.c_int(1 if enable else 0)))
+        if enable and digit_tables:
+            self.enable_digit_tables()
+
+    def enable_digit_tables(self, max_bytes: int = 0) -> int:
+        """zg_prover_enable_digit_tables: the lone-proof tables of the prover's three base sets (78 GB at k = 14), built NOW;
+        max_bytes 0 = the library's cap.  Returns the bytes resident afterwards (0: none fit / none at this size)."""
+        built = ctypes.c_uint64(0)
+        _check(self.ctx.lib.zg_prover_enable_digit_tables(self.h, ctypes.c_uint64(max_bytes), ctypes.byref(built)))
+        return built.value
 
     def phase_ms(self) -> list:
         out = (ctypes.c_double * 8)()

@@ -183,6 +183,8 @@ def run_steps(streams, steps):
         try:
             for _ in range(steps):
                 s.step()
+                if WATCHDOG:
+                    WATCHDOG.pat()
         except Exception as e:  # noqa: BLE001
             errors.append(e)
 
@@ -354,6 +356,8 @@ def image_to_proof(c: Circuit, streams, ctxs, barrier, threads: int, verify: boo
 
 
 def measure(streams, ctxs, steps, warmup, barrier, profile=False):
+    if WATCHDOG:
+        WATCHDOG.arm(True)
     run_steps(streams, max(warmup, 1))
     for x in ctxs:
         x.profile(profile)
@@ -362,6 +366,8 @@ def measure(streams, ctxs, steps, warmup, barrier, profile=False):
     run_steps(streams, steps)
     barrier()
     dt = time.perf_counter() - t0
+    if WATCHDOG:
+        WATCHDOG.arm(False)
     stats = {}
     for x in ctxs:
         if profile:
@@ -391,6 +397,8 @@ def latency_probe(stream: Stream):
     """One proof alone: transforms overlapped on a side stream, several lanes per EC addition (set_overlap(True))."""
     p, c = stream.prover, stream.c
     p.set_overlap(True)
+    # the lone-proof digit tables (78 GB at k = 14): an explicit call since round 4, here before the timed proofs
+    table_bytes = p.enable_digit_tables()
     for _ in range(2):
         p.prove_dev(p.advice_slot(0), c.instance, 1)
     t0 = time.perf_counter()
@@ -399,7 +407,87 @@ def latency_probe(stream: Stream):
     latency_s = (time.perf_counter() - t0) / 3
     phases = p.phase_ms()
     p.set_overlap(False)
-    return latency_s, phases
+    return latency_s, phases, table_bytes
+
+
+def launcher_command(argv, gpus: int, env) -> "list[str] | None":
+    """What `python bench.py --gpus N ...` has to START, decided before anything touches the GPU (the harness being
+    mirrored, /root/reference/benches/bench.rs:47-76, is one process per measurement; the contract here is one process
+    per GPU).  Returns None when THIS process is a rank (WORLD_SIZE set by torch.distributed.run, or N = 1), else the
+    command of the child that brings up N ranks: this process then only relays the child's JSON line and exit code.
+    A WORLD_SIZE that contradicts --gpus is an error (a one-GPU number must never be printed as an N-GPU line)."""
+    if "WORLD_SIZE" in env:
+        world = int(env["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"bench.py: --gpus {gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus {gpus}` "
+                             f"(it launches its own ranks) or give torch.distributed.run --nproc-per-node {gpus}")
+        return None
+    if gpus <= 1:
+        return None
+    port = env.get("ZG_BENCH_PORT") or str(free_port())
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", port, os.path.abspath(__file__)] + list(argv)
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def relay(cmd) -> int:
+    """Run the ranks as a CHILD process (never os.exec*: this process may not be replaced once a GPU runtime could be
+    loaded), pass its stderr through, print the one JSON line of its rank 0 and return its exit code."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL between processes needs dmabuf IPC on this pool)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in child.stdout:
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        elif ln:
+            print(ln, file=sys.stderr)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks exited 0 without a JSON line", file=sys.stderr)
+        rc = 4
+    return rc
+
+
+class Watchdog:
+    """A stuck collective must end the run non-zero, not hang it: every rank pats the dog when a step of any
+    of its provers completes; ZG_BENCH_STALL_S seconds (default 300) without progress inside a timed or warm-up region
+    -> stacks to stderr, exit code 3."""
+
+    def __init__(self, seconds: float):
+        self.seconds, self.last, self.armed = seconds, time.monotonic(), False
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def pat(self):
+        self.last = time.monotonic()
+
+    def arm(self, on: bool):
+        self.last, self.armed = time.monotonic(), on
+
+    def _run(self):
+        import faulthandler
+
+        while True:
+            time.sleep(1.0)
+            if self.armed and time.monotonic() - self.last > self.seconds:
+                print(f"bench.py: no prover finished a step for {self.seconds:.0f} s (stuck collective?): giving up", file=sys.stderr)
+                faulthandler.dump_traceback(file=sys.stderr)
+                os._exit(3)
+
+
+WATCHDOG = None
 
 
 def main():
@@ -430,8 +518,13 @@ def main():
     ap.add_argument("--no-image-to-proof", action="store_true", help="skip the run with a different image per proof (device witness)")
     args = ap.parse_args()
 
-    global HOST_ADVICE
+    global HOST_ADVICE, WATCHDOG
     HOST_ADVICE = args.host_advice
+    # --gpus N > 1 outside torch.distributed.run: start the N ranks as a child and relay its line -- decided BEFORE the
+    # first GPU call of this process (torch.cuda.is_available() below initialises the runtime)
+    cmd = launcher_command(sys.argv[1:], args.gpus, os.environ)
+    if cmd is not None:
+        raise SystemExit(relay(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -443,7 +536,7 @@ def main():
     backend = os.environ.get("ZG_BENCH_BACKEND", "nccl")
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    dist = None
+    dist, collective_ranks = None, 1
     if world > 1 or os.environ.get("ZG_BENCH_FORCE_DIST") == "1":  # (the env knob rehearses the RCCL path on one GPU)
         import torch.distributed as dist_mod
 
@@ -455,20 +548,36 @@ def main():
                 dist.init_process_group(backend)
             dist.barrier()
             torch.cuda.synchronize()
+            # what the collective backend itself saw: an all-reduce of ones over the default group (RCCL when every rank
+            # owns a GPU) -- the N of an N-GPU line is this number, not an argument echoed back
+            ones = torch.ones(1, dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(ones)
+            collective_ranks = int(ones.item())
+        if collective_ranks != world:
+            raise SystemExit(f"bench.py: the {backend} group counts {collective_ranks} ranks, WORLD_SIZE says {world}")
+        WATCHDOG = Watchdog(float(os.environ.get("ZG_BENCH_STALL_S", "300")))
 
     sharded = args.mode == "shard-msm" and world > 1
     shard = (rank, world) if sharded else (0, 1)
-    nprov = max(1, args.provers if args.provers else (4 if sharded else 12))
+    # every rank on a GPU of its own (the driver's launch): RCCL; ranks sharing a card (rehearsal): host callback
+    own_gpu = backend == "nccl" and "ZG_BENCH_DEVICE" not in os.environ
+    exchange_kind = (args.exchange or ("rccl" if own_gpu else "host")) if sharded else None
+    # shard-msm over raw RCCL communicators: ONE prover per rank unless --provers says otherwise.  Several provers of a
+    # process would issue ncclAllGather on several communicators from several threads, in an order that differs from rank
+    # to rank -- the classic NCCL/RCCL deadlock once the collectives' kernels cannot all be resident -- and no
+    # world > 1 run has ever validated it; the host exchange (gloo / torch.distributed groups, one per prover) has no
+    # device-side spinning and keeps 4.
+    nprov = max(1, args.provers if args.provers else (12 if not sharded else 1 if exchange_kind == "rccl" else 4))
     batch = max(1, args.batch)
     if args.model == "large":
         batch = min(batch, 8)  # (a k = 17 proof slot is 1.4 GiB; 8 provers x 8 slots + workspaces stay well inside 288 GB)
-    exchanges, rccl_ranks, exchange_kind = None, None, None
+    exchanges = None
+    # rccl_ranks: the ranks RCCL itself counted -- the all-reduce above when the default group is RCCL (replicas and the
+    # host exchange), ncclCommCount of the prover's communicator in shard-msm's in-library exchange; null under gloo
+    rccl_ranks = collective_ranks if (dist is not None and backend == "nccl") else None
     if sharded:
         import multi_gpu
 
-        # every rank on a GPU of its own (the driver's launch): RCCL; ranks sharing a card (rehearsal): host callback
-        own_gpu = backend == "nccl" and "ZG_BENCH_DEVICE" not in os.environ
-        exchange_kind = args.exchange or ("rccl" if own_gpu else "host")
         # ONE exchange PER PROVER (prover i of every rank forms a group with prover i of the others): the provers of a
         # rank work through their phases independently, each on its own stream / host thread
         with stdout_to_stderr():
@@ -494,7 +603,7 @@ def main():
         for x in ctxs:
             x.sync()
 
-    latency_s, phases = probed if probed else (None, [0.0] * 8)
+    latency_s, phases, table_bytes = probed if probed else (None, [0.0] * 8, 0)
     # timed region: every launch carries its own start / stop event (hipExtLaunchKernelGGL on the prover's stream): a
     # lock-step batch is ~100 launches for `batch` proofs, so timing them all costs nothing measurable
     dt, stats = measure(streams, ctxs, args.steps, args.warmup, barrier, profile=not args.no_kernel_events)
@@ -598,10 +707,13 @@ def main():
                                        f"{world} GPU(s) x {nprov} prover stream(s) x lock-step batches of {batch} proofs")},
             "mode": args.mode if world > 1 else "single-gpu",
             "exchange": exchange_kind, "rccl_ranks": rccl_ranks,
+            "collective": {"backend": ("rccl" if backend == "nccl" else backend) if dist is not None else None,
+                           "ranks_seen": collective_ranks if dist is not None else None,
+                           "how": "all-reduce of ones over the default process group before the timed region"},
             "ranks_share_a_device": bool(world > 1 and "ZG_BENCH_DEVICE" in os.environ),
             "inputs": "host memory, uploaded per proof" if HOST_ADVICE else "resident in HBM",
             "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
-            "create_proof_wall_s": latency_s, "provers_per_gpu": nprov, "batch": batch,
+            "create_proof_wall_s": latency_s, "lone_proof_digit_table_bytes": table_bytes, "provers_per_gpu": nprov, "batch": batch,
             "launches_per_proof": launches_per_proof,
             "algorithmic_GBps": algorithmic_bytes_per_proof(cs) / (ms_per_proof * 1e-3) / 1e9,
             "device_ms_per_proof": device_ms / max(1, args.steps * proofs_per_step),
@@ -651,10 +763,10 @@ def main():
             # (k = 15 slots are 0.34 GiB, k = 17 slots 1.4 GiB: batches of 16 and 8 keep 12 provers inside the 288 GB)
             b2 = min(batch, 16) if m != "large" else min(batch, 8)
             np2 = min(nprov, 12)  # (a k = 17 slot is 1.4 GiB: 12 provers x 8 slots + workspaces = 175 GB of the 288)
-            cx, st2, (lat, _) = make_streams(dev_index, c2, ctx0, np2, b2, rank, probe=latency_probe)
+            cx, st2, (lat, _, tb2) = make_streams(dev_index, c2, ctx0, np2, b2, rank, probe=latency_probe)
             dt2, _ = measure(st2, cx, 3, 1, barrier)
             others[m] = {"model": c2.model_name, "k": c2.k, "ms_per_proof": dt2 / (3 * np2 * b2) * 1e3,
-                         "create_proof_wall_s": lat, "batch": b2, "provers": np2,
+                         "create_proof_wall_s": lat, "lone_proof_digit_table_bytes": tb2, "batch": b2, "provers": np2,
                          "proofs_per_hour": 3 * np2 * b2 / dt2 * 3600.0}
             if m != "large" and not args.no_image_to_proof:  # (the stand-in's program: 360 000 operations, 5 s to record)
                 i2p = image_to_proof(c2, st2, cx, barrier, host_cores(), not args.no_verify, steps=2, checks=1)

@@ -67,7 +67,7 @@ const char *zg_version(void);
  * result: every form computes the same group elements and field elements, bit for bit (tests/test_gpu_knobs.py walks
  * them all against the oracle).  Knobs that shape resident data are read when that object is built (ZG_MSM_C: a base
  * set registered with window_bits = 0; ZG_MSM_NAF, ZG_MSM_NAF_GL, ZG_MSM_RUNS, ZG_EVALH9, ZG_EVALH_GROUPED,
- * ZG_SPLIT_DOMAIN: zg_prover_create*; ZG_LAT_SPLIT_K: zg_prover_create* and zg_prover_set_overlap; ZG_LAT_FULL_C: the first latency-form proof), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
+ * ZG_SPLIT_DOMAIN: zg_prover_create*; ZG_LAT_SPLIT_K: zg_prover_create* and zg_prover_set_overlap; ZG_LAT_FULL_C: zg_prover_enable_digit_tables), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
  * ZG_MSM_STRIP, ZG_LAT_FULL_K, ZG_LAZY_DOT).
  *   ZG_MSM_C          window bits of the MSM tables, 2..16 (default from n: k - 2)
  *   ZG_MSM_K          points per bucket-accumulation task in the throughput form, 4..120 (48)
@@ -143,7 +143,7 @@ int zg_bases_enable_bit_table(zg_ctx *ctx, zg_bases *bases, uint32_t digit_width
  * c = 11).  A signed digit then names its summand and the MSM is a flat sum of gathered points folded by a tree: no digit
  * sort, no buckets, no bucket reduction -- the latency of a lone commitment phase drops by about half.  window_bits 0 = chosen
  * from n and the free memory (none from n = 2^16 on, or when the card has no room: not an error); 4..12 otherwise.
- * zg_prover_prove* enables them by itself for a prover in its latency form (ZG_LAT_FULL_C = 0 to keep it from doing so).
+ * Never built implicitly: this call for a lone base set, zg_prover_enable_digit_tables for a prover's three.
  * Same results, bit for bit. */
 int zg_bases_enable_digit_table(zg_ctx *ctx, zg_bases *bases, uint32_t window_bits);
 size_t zg_bases_len(const zg_bases *b);
@@ -377,6 +377,18 @@ int zg_prover_phase_ms(const zg_prover *p, double *out, size_t cap);
  * polynomial h from fewer evaluations) and the MSM reductions spend one lane per EC addition.  Proof bytes do
  * not depend on it. */
 int zg_prover_set_overlap(zg_prover *p, int enable);
+/* Builds the digit tables (zg_bases_enable_digit_table) of the prover's three base sets -- ParamsKZG::g, ::g_lagrange and
+ * the running sums of g_lagrange -- which a LONE proof (zg_prover_set_overlap(p, 1)) then uses instead of Pippenger buckets:
+ * 2.9 -> 2.2 ms per create_proof at k = 14.  Footprint: 3 x ceil(255 / c) * 2^(c-1) * n * 64 B -- 78 GB at n = 2^14 (c = 11),
+ * 84 GB at n = 2^15 (c = 10) -- and ~1 s of build time per table, which is why it is an explicit call (round 3 built them
+ * inside the first latency-form proof).  max_bytes = what the three tables may take together; 0 = the library's cap (a third
+ * of the card's memory, at most 90 GB) -- window bits shrink until they fit; nothing is built (not an error) when no width
+ * fits, when n >= 2^16, when ZG_LAT_FULL_C = 0 or when the card has not that much free memory plus a reserve.
+ * *bytes_built (may be NULL) = what is resident afterwards.  The tables belong to the base sets (shared by every prover on
+ * them, freed with zg_bases_free); the throughput form never reads them.  Idempotent.  Proof bytes do not depend on it.
+ * halo2 has no counterpart (ParamsKZG holds the bases only); the call site served is one synchronous proof,
+ * /root/reference/src/wnn.rs:242-259. */
+int zg_prover_enable_digit_tables(zg_prover *p, uint64_t max_bytes, uint64_t *bytes_built);
 
 /* Stand-alone building blocks of the above. */
 /* Evaluator::evaluate_h (halo2_proofs src/plonk/evaluation.rs) followed by the division by X^n - 1 of

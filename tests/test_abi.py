@@ -193,3 +193,14 @@ def test_plain_c_driver_builds_against_the_library(tmp_path):
     if not torch.cuda.is_available():
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+def test_field_inv_returns_zero_when_its_budget_runs_out_host_path():
+    """ADVICE r3: Field::inv on a non-canonical multiple of the modulus must terminate AND return 0, not a would-be inverse
+    (tests/abi/field_probe.hip, built by the package Makefile; the device path runs in tests/test_gpu_msm.py)."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "tests", "abi", "field_probe")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, "host"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

@@ -44,3 +44,60 @@ def test_bench_touches_the_oracle_only_as_checker_and_cpu_baseline():
         fn = re.findall(r"^def (\w+)\(", head, re.M)[-1]
         assert fn in ("cpu_baseline", "verify_last_step", "image_to_proof", "verify_proofs"), fn
     assert "import orc" not in src.split("def measure(")[1].split("\ndef ")[0]  # (the timed region itself)
+
+
+def _bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("zg_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_gpus_n_starts_n_ranks_as_a_child():
+    """`python bench.py --gpus N` (the driver's command shape) must measure N GPUs: argv + environment
+    in, the child's command out -- decided before any GPU call."""
+    import pytest
+
+    b = _bench()
+    argv = ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+    cmd = b.launcher_command(argv, 4, {"ZG_BENCH_PORT": "29999"})
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench.py") and cmd[-len(argv):] == argv  # (same arguments, --gpus included)
+    # no port given: a free one is drawn
+    port = int(b.launcher_command(argv, 4, {})[b.launcher_command(argv, 4, {}).index("--master-port") + 1])
+    assert 1024 < port < 65536
+    # a rank started by torch.distributed.run runs the bench itself ...
+    assert b.launcher_command(argv, 4, {"WORLD_SIZE": "4", "RANK": "1"}) is None
+    # ... one GPU needs no launcher ...
+    assert b.launcher_command(["--steps", "5"], 1, {}) is None
+    assert b.launcher_command(["--gpus", "1"], 1, {"WORLD_SIZE": "1"}) is None
+    # ... and a world that contradicts --gpus is refused, never printed as an N-GPU line
+    with pytest.raises(SystemExit):
+        b.launcher_command(argv, 4, {"WORLD_SIZE": "2"})
+    with pytest.raises(SystemExit):
+        b.launcher_command(["--gpus", "1"], 1, {"WORLD_SIZE": "8"})
+
+
+def test_launcher_is_decided_before_the_first_gpu_call_and_never_execs():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src.split("def main():")[1]
+    assert main.index("launcher_command(") < main.index("if not torch.cuda.is_available()") < main.index("torch.cuda.set_device")
+    assert "os.exec" not in src.replace("never os.exec*", "")
+
+
+def test_relay_passes_the_json_line_and_the_exit_code(capfd):
+    import sys
+
+    b = _bench()
+    rc = b.relay([sys.executable, "-c", "import sys; print('banner'); print('{\"metric\": \"m\", \"n_gpus\": 2}'); sys.exit(0)"])
+    out, err = capfd.readouterr()
+    assert rc == 0 and out.strip() == '{"metric": "m", "n_gpus": 2}' and "banner" in err
+    rc = b.relay([sys.executable, "-c", "import sys; sys.exit(7)"])
+    assert rc == 7
+    rc = b.relay([sys.executable, "-c", "print('no line')"])
+    assert rc != 0  # (ranks that exit 0 without a line did not measure anything)
+    capfd.readouterr()

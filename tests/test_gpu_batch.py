@@ -270,7 +270,7 @@ def test_batch_of_circuit_variants(ctx, zg, orc, kind):
         st, proof, _ = orc.create_proof(pk, adv, inst, s)
         assert st == 0
         want.append(proof)
-    for overlap in (True, False):
+    for overlap in (True, "tables", False):
         prover.set_overlap(overlap)
         got, sts = prover.prove_batch([adv] * 3, [inst] * 3, seeds)
         assert sts == [0, 0, 0] and got == want, (kind, overlap)

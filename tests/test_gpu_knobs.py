@@ -114,6 +114,8 @@ def test_knob_settings_give_the_oracles_bytes(ctx, zg, orc, workloads, case):
             prover = zg.Prover(ctx, w["img"], w["fixed"], w["sigma"], w["g"], w["gl"], w["vk_repr"])
             prover.set_overlap(True)    # latency form: side stream, single coset, several lanes per EC addition
             assert prover.prove(w["adv"], w["inst"], 1) == w["want"][1], (case, w["name"], "latency form")
+            prover.set_overlap("tables")  # ... and over its digit tables (ZG_LAT_FULL_C / _K act here; explicit since round 4)
+            assert prover.prove(w["adv"], w["inst"], 1) == w["want"][1], (case, w["name"], "latency form, digit tables")
             prover.set_overlap(False)   # throughput form: split domain, strip reduction, free-position digits
             assert prover.prove(w["adv"], w["inst"], 2) == w["want"][2], (case, w["name"], "throughput form")
             prover.set_batch(3)

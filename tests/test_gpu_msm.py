@@ -207,3 +207,15 @@ def test_digit_tables_give_the_same_points(ctx, zg, orc, srs, c):
     r = ctx.msm(bases, np.zeros((0, 4), np.uint64))
     assert not r[:4].any() and not r[8:].any()
     bases.free()
+
+
+@pytest.mark.gpu
+def test_field_inv_returns_zero_when_its_budget_runs_out_device_path():
+    """Field::inv of a multiple of the modulus on the DEVICE: the loop ends (iteration budget) and the result is 0
+    (tests/abi/field_probe.hip; one run, its own process)."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "abi", "field_probe")
+    r = subprocess.run([exe, "device"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr

@@ -61,7 +61,7 @@ def test_single_stream_schedule_gives_the_same_bytes(ctx, zg, orc):
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
     st, want, _ = orc.create_proof(pk, adv, inst, 5)
     assert st == 0
-    for overlap in (False, True, False):
+    for overlap in (False, True, "tables", False):  # ("tables": the latency form over its digit tables, built here)
         prover.set_overlap(overlap)
         assert prover.prove(adv, inst, 5) == want
     prover.close()
@@ -75,7 +75,7 @@ def test_split_extended_domain_gives_the_same_bytes(ctx, zg, orc, force_degree, 
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
     st, want, _ = orc.create_proof(pk, adv, inst, 11)
     assert st == 0
-    for overlap in (False, True):
+    for overlap in (False, True, "tables"):
         prover.set_overlap(overlap)
         assert prover.prove(adv, inst, 11) == want, parts
     assert orc.verify_proof_pairing(pk, inst, want) == 1
@@ -264,7 +264,8 @@ def test_real_wnn_circuit_tiny_proof_bytes_match_oracle(ctx, zg, orc):
     adv, inst = asg.advice_values(), asg.instance_values(ilen)
     # both configurations: overlap on = one 8n-point coset, two lanes per EC addition; overlap off (the bench's
     # throughput form) = the split 4n + n extended domain, one lane per addition
-    for seed, overlap in ((1, True), (99, False), (7, True)):
+    # ("tables": zg_prover_enable_digit_tables first -- 78 GB at k = 14 -- then the lone proof as a flat sum of table points)
+    for seed, overlap in ((1, True), (99, False), (7, "tables")):
         prover.set_overlap(overlap)
         got = prover.prove(adv, inst, seed)
         st, want, _ = orc.create_proof(pk, adv, inst, seed)
@@ -305,6 +306,8 @@ def test_real_wnn_circuit_medium_k15_verifies(ctx, zg, orc):
     prover.set_overlap(False)
     assert prover.prove(adv, inst, 11) == want
     prover.set_overlap(True)
+    assert prover.prove(adv, inst, 11) == want
+    prover.set_overlap("tables")  # (k = 15: c = 10, 84 GB)
     assert prover.prove(adv, inst, 11) == want
     assert orc.verify_proof_pairing(pk, inst, want) == 1
     prover.close()

@@ -14,7 +14,7 @@ ctx = zg.Ctx(0)
 c = bench.Circuit(ctx, sys.argv[1] if len(sys.argv) > 1 else "tiny")
 which = sys.argv[2] if len(sys.argv) > 2 else "both"
 p = zg.Prover(ctx, c.img, c.fixed, c.sigma, c.g_bases, c.gl_bases, c.vk_repr)
-for form, overlap in (("latency", True), ("throughput", False)):
+for form, overlap in (("latency", "tables"), ("throughput", False)):  # (ZG_LAT_FULL_C=0: the bucket form)
     if which not in (form, "both"):
         continue
     p.set_overlap(overlap)
