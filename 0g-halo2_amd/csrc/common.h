@@ -106,13 +106,17 @@ struct zg_ctx {
     struct ProfRec {
         const char* name;
         hipEvent_t e0, e1;
-        double bytes;
+        double bytes;       // what THIS kernel's algorithm streams: every distinct input once, every output once
+        double unit_bytes;  // SURVEY.md 8d's figure of the unit of work (one MSM, one transform, ...), charged ONCE per unit:
+                            // on the kernel that carries the unit; 0 on the other kernels of its launch sequence
     };
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> event_pool;  // recycled by zg_ctx_profile_collect
     zg_ctx* side = nullptr;  // optional second stream + workspace pool (created on demand, same device)
     // MSM bucket reduction with two lanes per EC addition (latency) or one (throughput); see msm.hip
     bool msm_pair = true;
+    // SURVEY-unit bytes of the NEXT transform plan run on this context (-1: the plan's own in + out; ntt.hip consumes it)
+    double unit_next = -1.0;
     bool msm_dense_hint = false;  // set by a caller around an MSM whose vectors are all random (latency form: one lane per task)
     uint32_t* msm_tickets = nullptr;  // last-workgroup-done counters of the MSM reduction (msm.hip), zero between launches
 };
@@ -179,15 +183,19 @@ int pinned_reserve(zg_ctx* ctx, size_t bytes);
 // (hipExtLaunchKernelGGL: the timestamps are the kernel's begin and end, as rocprofv3 reports them -- events
 // recorded around the launch would add the queueing time of a busy stream) and `algo_bytes` (the
 // ALGORITHMIC bytes this launch is charged with) is recorded beside them.
-zg_ctx::ProfRec* prof_slot(zg_ctx* ctx, const char* name, double algo_bytes);  // nullptr: filtered out
-#define ZG_LAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...)                                       \
+zg_ctx::ProfRec* prof_slot(zg_ctx* ctx, const char* name, double algo_bytes, double unit_bytes);  // nullptr: filtered out
+// ZG_LAUNCH_U: a kernel with its own streamed bytes AND the SURVEY-unit bytes it carries (0: a stage kernel of a
+// multi-kernel unit, or a kernel SURVEY.md 8d names no unit for); ZG_LAUNCH: a stage / unit-less kernel (unit bytes 0).
+#define ZG_LAUNCH_U(ctx, name, bytes, unit, kernel, grid, block, lds, ...)                               \
     do {                                                                                                 \
-        zg_ctx::ProfRec* _zg_r = (ctx)->profiling ? ::zg::prof_slot((ctx), (name), (double)(bytes)) : nullptr; \
+        zg_ctx::ProfRec* _zg_r = (ctx)->profiling ? ::zg::prof_slot((ctx), (name), (double)(bytes), (double)(unit)) : nullptr; \
         if (_zg_r)                                                                                       \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, _zg_r->e0, _zg_r->e1, 0, __VA_ARGS__); \
         else                                                                                             \
             hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);                    \
     } while (0)
+#define ZG_LAUNCH(ctx, name, bytes, kernel, grid, block, lds, ...) \
+    ZG_LAUNCH_U(ctx, name, bytes, 0.0, kernel, grid, block, lds, __VA_ARGS__)
 
 // twiddle table for (log_n, omega), created on first use
 int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out);

@@ -92,11 +92,12 @@ static hipEvent_t pool_event(zg_ctx* ctx) {
     return e;
 }
 
-zg_ctx::ProfRec* prof_slot(zg_ctx* ctx, const char* name, double algo_bytes) {
+zg_ctx::ProfRec* prof_slot(zg_ctx* ctx, const char* name, double algo_bytes, double unit_bytes) {
     if (!ctx->prof_filter.empty() && ctx->prof_filter != name) return nullptr;
     zg_ctx::ProfRec r;
     r.name = name;
     r.bytes = algo_bytes;
+    r.unit_bytes = unit_bytes;
     r.e0 = pool_event(ctx);
     r.e1 = pool_event(ctx);
     ctx->prof.push_back(r);
@@ -262,6 +263,7 @@ int zg_ctx_profile_collect(zg_ctx* ctx, zg_kernel_stat* out, size_t cap, size_t*
         s->launches += 1;
         s->total_ms += ms;
         s->algo_bytes += r.bytes;
+        s->unit_bytes += r.unit_bytes;
     }
     ctx->prof.clear();
     *count = acc.size();

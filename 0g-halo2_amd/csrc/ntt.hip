@@ -361,8 +361,14 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
     a.zin0 = p.zin0; a.zin1 = p.zin1; a.zin2 = p.zin2; a.zout1 = p.zout1; a.zout2 = p.zout2; a.scale = p.scale;
     const uint32_t N = 1u << p.log_n;
     const uint32_t gper = p.grp.per ? p.grp.per : 0xffffffffu;
-    // algorithmic bytes of a transform: input entries read + output entries written
+    // algorithmic bytes.  The UNIT is one transform: input entries read + output entries written -- or what
+    // the caller says this plan stands for (zg_ctx::unit_next: the split extended domain computes EvaluationDomain's n -> 8n
+    // transform as n -> 4n and n -> n), carried by the LAST pass.  Each pass is charged what it streams itself: the first
+    // reads the input and writes the N-point workspace, the second reads that and writes the output.
     const double pass_bytes = (double)p.batch * ((double)p.in_len + (double)p.out_len) * 32.0;
+    const double unit_bytes = ctx->unit_next >= 0.0 ? ctx->unit_next : pass_bytes;
+    ctx->unit_next = -1.0;
+    const double pts = (double)p.batch * (double)(1u << p.log_n) * 32.0;
     dim3 block(T / 4);
     const bool single = p.log_n <= (uint32_t)LOG_T;
     if (single) {
@@ -373,7 +379,7 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.out = p.out; a.out_stride = p.out_stride;
         a.in_per = a.out_per = gper; a.in_outer = p.grp.in_outer; a.out_outer = p.grp.out_outer;
         size_t lds = (size_t)(T + N / 2) * ELEM;
-        ZG_LAUNCH(ctx, "ntt_single", pass_bytes, (ntt_pass_kernel<LOG_T, false, true>),
+        ZG_LAUNCH_U(ctx, "ntt_single", pass_bytes, unit_bytes, (ntt_pass_kernel<LOG_T, false, true>),
                   dim3(1, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
@@ -388,7 +394,7 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.out_per = 0xffffffffu; a.out_outer = 0;
         uint32_t cnt = T / N1;
         size_t lds = (size_t)(T + N1 / 2) * ELEM;
-        ZG_LAUNCH(ctx, "ntt_cols", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, true, true>),
+        ZG_LAUNCH(ctx, "ntt_cols", (double)p.batch * (double)p.in_len * 32.0 + pts, (ntt_pass_kernel<LOG_T, true, true>),
                   dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }
@@ -400,7 +406,7 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         uint32_t cnt = T / N2;
         if (cnt > N1) cnt = N1;
         size_t lds = (size_t)(T + N2 / 2) * ELEM;
-        ZG_LAUNCH(ctx, "ntt_rows", pass_bytes * 0.5, (ntt_pass_kernel<LOG_T, false, false>),
+        ZG_LAUNCH_U(ctx, "ntt_rows", pts + (double)p.batch * (double)p.out_len * 32.0, unit_bytes, (ntt_pass_kernel<LOG_T, false, false>),
                   dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }

@@ -148,7 +148,9 @@ int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Pr
 size_t poly_grand_product_tmp_elems(uint32_t n, uint32_t batch);
 int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
                        uint32_t batch, uint32_t chain, uint32_t last, uint32_t per = 0, size_t z_outer = 0);
-int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en, uint32_t nb);
+// n_columns = advice + instance + fixed columns of the circuit, unit_share = the rows of EvaluationDomain's extended domain
+// this launch stands for (both only shape the profile's byte charges)
+int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en, uint32_t nb, uint32_t n_columns, double unit_share);
 // out[i] = U(col[(i + rot_off) mod en]),  U(x) = sum_{k=1..count} coef[k-1] x^k; everything in the 2^261 form
 int poly_gate_factor(zg_ctx* ctx, const Fe* col, uint32_t rot_off, uint32_t en, const Fe* coef, uint32_t count, Fe* out);
 // Coefficient-form polynomials a kernel may be asked for by index: indices below nsh name the proving key's
@@ -164,7 +166,8 @@ struct PolySet {
 int poly_powers(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, uint32_t npoints, uint32_t n, Fe* d_pow, size_t pw_bs);
 // out[b * out_bs + j] = <poly poly_idx[j] of proof b, powers row point_idx[j] of proof b>
 int poly_dot(zg_ctx* ctx, const PolySet& polys, uint32_t nb, uint32_t n, const uint32_t* d_poly_idx,
-             const uint32_t* d_point_idx, const Fe* d_pow, size_t pw_bs, uint32_t count, Fe* d_out, size_t out_bs);
+             const uint32_t* d_point_idx, const Fe* d_pow, size_t pw_bs, uint32_t count, Fe* d_out, size_t out_bs,
+             uint32_t distinct_polys = 0, uint32_t distinct_points = 0);  // (distinct counts: the profile's byte charge only)
 // out[b][i] = Horner in pc[b].xn over the polys listed (first listed = highest power)
 int poly_horner_combine_xn(zg_ctx* ctx, const PolySet& polys, const ProofConst* pc, uint32_t nb, const uint32_t* d_list,
                            uint32_t count, Fe* out, size_t out_bs, uint32_t n);

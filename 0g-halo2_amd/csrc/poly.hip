@@ -621,12 +621,14 @@ static int grand_product_blocks(zg_ctx* ctx, const Fe* num, const Fe* den, const
     Fe* totd = totn + (size_t)batch * nblk;
     Fe* tinv = totd + (size_t)batch * nblk;
     Fe* zlast = tinv + batch;
+    // the UNIT: one running product = num, den in, z out = 3 n * 32 B, carried by the apply kernel; each
+    // kernel's own streams beside it (the block-local products cross HBM between the launches)
     const double bytes = (double)batch * n * 96;
-    ZG_LAUNCH(ctx, "grand_product_local", bytes, gp_local_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, num, den, locn,
+    ZG_LAUNCH(ctx, "grand_product_local", (double)batch * n * 128, gp_local_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, num, den, locn,
               locd, totn, totd, n, nblk);
     // latency configuration: the host inverts the totals (one shared inversion) between the two launches
     const bool host_inv = ctx->msm_pair && batch <= FESET_MAX && batch == per;
-    ZG_LAUNCH(ctx, "grand_product_totals", bytes, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
+    ZG_LAUNCH(ctx, "grand_product_totals", (double)batch * nblk * 128, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
               tinv, zlast, n, nblk, last, host_inv ? 1u : 0u);
     FeSet inv_set;
     memset(&inv_set, 0, sizeof(inv_set));
@@ -651,7 +653,7 @@ static int grand_product_blocks(zg_ctx* ctx, const Fe* num, const Fe* den, const
             acc = Fr::mul(acc, h[b]);
         }
     }
-    ZG_LAUNCH(ctx, "grand_product_apply", bytes, gp_apply_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, locn, locd, totn,
+    ZG_LAUNCH_U(ctx, "grand_product_apply", bytes, bytes, gp_apply_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, locn, locd, totn,
               totd, tinv, zlast, d_z0, z, n, nblk, chain, inv_set, host_inv ? 1u : 0u, per, z_outer);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -702,7 +704,7 @@ int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0
             acc = Fr::mul(acc, h[b]);
         }
     }
-    ZG_LAUNCH(ctx, "grand_product_apply", bytes, gp_strip_apply_kernel, dim3((lanes + 255) / 256, batch), dim3(256), 0, num, den,
+    ZG_LAUNCH_U(ctx, "grand_product_apply", (double)batch * n * 128, bytes, gp_strip_apply_kernel, dim3((lanes + 255) / 256, batch), dim3(256), 0, num, den,
               locd, aux, tinv, zlast, d_z0, z, n, lanes, strip, chain, inv_set, host_inv ? 1u : 0u, per, z_outer);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -1072,22 +1074,26 @@ __global__ __launch_bounds__(256) void evaluate_h9_kernel(EvalHArgs a, uint32_t 
     stg(pr.h + idx, f9_reduce_pack<Fr9Params>(value));
 }
 
-int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en, uint32_t nb) {
+int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en, uint32_t nb, uint32_t n_columns, double unit_share) {
     if (!nb) return ZG_OK;
     ZG_REQUIRE(a.pc != nullptr && (a.zpow == 1 || a.zpow == 2), ZG_ERR_INVALID_ARG, "evaluate_h: per-proof scalars missing");
-    // algorithmic bytes: every input coset read once + h written
+    // algorithmic bytes: every input coset read once + h written, as SURVEY.md 8d counts them -- `n_columns` advice,
+    // instance and fixed columns, 3 l-polynomials, sigma, the permutation products, 3 polynomials per lookup, h: ONE count
+    // (round 3 charged 26 arrays here while bench.py counted 49).  own = over the `en` rows of this launch; unit = over the
+    // 2^ext_k rows of EvaluationDomain's extended domain, of which this launch stands for `unit_share`.
     const DevCircuit& c = a.c;
-    double arrays = 3.0 + c.n_perm + c.n_sets + 3.0 * c.n_lookups + 1.0;  // l-polys, sigma, z's, lookup polys, h
+    const double arrays = (double)n_columns + 3.0 + c.n_perm + c.n_sets + 3.0 * c.n_lookups + 1.0;
+    const double unit = nb * arrays * unit_share * 32.0;
     ZG_REQUIRE(!a.hat || a.monos_hat != nullptr || (c.n_gates == 0 && c.n_lookups == 0), ZG_ERR_INVALID_ARG,
                "evaluate_h: the 2^261-form monomial table is missing");
     ZG_REQUIRE(!a.hat || c.n_gates == 0 || (a.gates_hat != nullptr && a.gate_common != nullptr && a.gate_uni != nullptr && a.uni_coef != nullptr && a.gate_slab != nullptr && a.gate_slabs != nullptr), ZG_ERR_INVALID_ARG,
                "evaluate_h: the factored gate table is missing");
     if (a.hat && a.n_terms)
-        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h9_kernel<true>, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
+        ZG_LAUNCH_U(ctx, "evaluate_h", nb * arrays * en * 32.0, unit, evaluate_h9_kernel<true>, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
     else if (a.hat)
-        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h9_kernel<false>, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
+        ZG_LAUNCH_U(ctx, "evaluate_h", nb * arrays * en * 32.0, unit, evaluate_h9_kernel<false>, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
     else
-        ZG_LAUNCH(ctx, "evaluate_h", nb * arrays * en * 32.0, evaluate_h_kernel, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
+        ZG_LAUNCH_U(ctx, "evaluate_h", nb * arrays * en * 32.0, unit, evaluate_h_kernel, dim3((en + 255) / 256, nb), dim3(256), 0, a, en);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
 }
@@ -1191,17 +1197,21 @@ __global__ __launch_bounds__(DOT_NT) void dot9_kernel(PolySet ps, uint32_t n, co
 }
 
 int poly_dot(zg_ctx* ctx, const PolySet& polys, uint32_t nb, uint32_t n, const uint32_t* d_poly_idx,
-             const uint32_t* d_point_idx, const Fe* d_pow, size_t pw_bs, uint32_t count, Fe* d_out, size_t out_bs) {
+             const uint32_t* d_point_idx, const Fe* d_pow, size_t pw_bs, uint32_t count, Fe* d_out, size_t out_bs,
+             uint32_t distinct_polys, uint32_t distinct_points) {
     if (!count || !nb) return ZG_OK;
+    // algorithmic bytes: a polynomial opened at several points is READ ONCE, and so is each point's power table (round 3
+    // charged count * n * 64: more than the kernel moves -- its figure came out above the HBM peak)
+    const double dot_bytes = (double)nb * ((double)(distinct_polys ? distinct_polys : count) + (distinct_points ? distinct_points : count)) * n * 32.0;
     // (a lane sums n / 256 terms at most: 2^12 at n = 2^20, inside Dot9's bound of 2^13 terms)
     if (knob(K_LAZY_DOT) != 0 && n <= (1u << 20) && ctx->msm_pair)
-        ZG_LAUNCH(ctx, "eval_dot", (double)nb * count * n * 64, dot9_kernel<1024>, dim3(count, nb), dim3(1024), 0, polys, n, d_poly_idx,
+        ZG_LAUNCH(ctx, "eval_dot", dot_bytes, dot9_kernel<1024>, dim3(count, nb), dim3(1024), 0, polys, n, d_poly_idx,
                   d_point_idx, d_pow, pw_bs, d_out, out_bs);
     else if (knob(K_LAZY_DOT) != 0 && n <= (1u << 20))
-        ZG_LAUNCH(ctx, "eval_dot", (double)nb * count * n * 64, dot9_kernel<256>, dim3(count, nb), dim3(256), 0, polys, n, d_poly_idx,
+        ZG_LAUNCH(ctx, "eval_dot", dot_bytes, dot9_kernel<256>, dim3(count, nb), dim3(256), 0, polys, n, d_poly_idx,
                   d_point_idx, d_pow, pw_bs, d_out, out_bs);
     else
-    ZG_LAUNCH(ctx, "eval_dot", (double)nb * count * n * 64, dot_kernel, dim3(count, nb), dim3(DOT_NT), 0, polys, n, d_poly_idx,
+    ZG_LAUNCH(ctx, "eval_dot", dot_bytes, dot_kernel, dim3(count, nb), dim3(DOT_NT), 0, polys, n, d_poly_idx,
               d_point_idx, d_pow, pw_bs, d_out, out_bs);
     ZG_HIP(hipGetLastError());
     return ZG_OK;
@@ -1471,7 +1481,7 @@ int poly_kate_division(zg_ctx* ctx, const ProofConst* pc, uint32_t nb, const uin
         // (as many lanes as block heads, a power of two from 64: at n = 2^14 one wave, whose barriers cost nothing)
         uint32_t hl = 64;
         while (hl < nblk) hl <<= 1;
-        ZG_LAUNCH(ctx, "kate_heads", bytes, kd_heads_kernel, dim3(m), dim3(hl), 0, pc, ks, nsets, heads, nblk);
+        ZG_LAUNCH(ctx, "kate_heads", (double)m * nblk * 64, kd_heads_kernel, dim3(m), dim3(hl), 0, pc, ks, nsets, heads, nblk);
         ZG_LAUNCH(ctx, "kate_apply", bytes, kd_apply_kernel, dim3(nblk, nsets, nb), dim3(KD_BLOCK), 0, pc, ks, loc, heads, q, q_stride,
                   q_bs, n, nblk);
         ZG_HIP(hipGetLastError());

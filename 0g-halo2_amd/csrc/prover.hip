@@ -1203,10 +1203,15 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         return g;
     };
     // coefficient forms (ix0 .. ix0 + per) of every proof -> their slabs on each part of the extended domain
+    // (profile charges: SURVEY.md 8d counts one coeff_to_extended as (n + 2^ext_k) * 32 B whatever parts it is computed on)
+    double parts_en = 0.0;
+    for (uint32_t di = dlo; di < dhi; di++) parts_en += (double)pk.dom[di].en;
+    const double ext_unit = ((double)n + (double)((size_t)1 << ek)) * 32.0;
     auto to_cosets = [&](zg_ctx* c, uint32_t ix0, uint32_t per) -> int {
         for (uint32_t di = dlo; di < dhi; di++) {
             const PkDev::Dom& d = pk.dom[di];
             const Grouping g = grouping(per, pp_bs, (size_t)p->ncos * d.en);
+            c->unit_next = (double)nb * per * ext_unit * ((double)d.en / parts_en);
             ZG_TRY(coeff_to_coset_dev(c, pp_at(ix0), n, n, p->dbuf[di].cos + (size_t)(ix0 - p->ix_adv) * d.en, d.en, (size_t)nb * per,
                                       d.ek, hat, d.zpow, &g));
         }
@@ -1404,12 +1409,14 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
     for (uint32_t di = dlo; di < dhi; di++) {
         const EvalHArgs a = evalh_args(p, di);
-        ZG_TRY(poly_evaluate_h(ctx, a, pk.dom[di].en, nb));
+        ZG_TRY(poly_evaluate_h(ctx, a, pk.dom[di].en, nb, A + I + pk.F, (double)((size_t)1 << ek) * ((double)pk.dom[di].en / parts_en)));
     }
     p->have_last = true;
     p->last_split = split;
     p->last_nb = nb;
+    const double ext_inv_unit = (double)nb * 2.0 * (double)((size_t)1 << ek) * 32.0;  // (ext -> coeff, 2 * 8n * 32 B)
     if (!split) {
+        ctx->unit_next = ext_inv_unit;
         ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[0].h, ek, (size_t)Q * n, pp_at(p->ix_hpiece), hat, 1, nb, pk.dom[0].en, pp_bs));
     } else {
         // h = A + (X^L1 - c1) B:  A (degree < L1) from the first coset, where X^L1 = c1 = shift1^L1;  B (degree < L2)
@@ -1422,11 +1429,14 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
         Fe* hp = pp_at(p->ix_hpiece);
         const size_t tb = (size_t)3 * L2;
         Fe *fold = p->split_tmp, *a2 = fold + L2, *bc = a2 + L2;
+        ctx->unit_next = ext_inv_unit;  // (the three transforms of the split form stand for ONE extended_to_coeff)
         ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[1].h, d1.ek, L1, hp, hat, 1, nb, L1, pp_bs));  // A, in place of the low pieces
         ZG_TRY(poly_fold(ctx, nb, hp, pp_bs, L2, L1 / L2, e, fold, tb));                       // A mod (X^L2 - e)
+        ctx->unit_next = 0.0;
         ZG_TRY(coeff_to_coset_dev(ctx, fold, tb, L2, a2, tb, nb, d2.ek, false, 2));            // A on the second coset
         const Fe unhat = hat ? Fr::inv(Fr::from_u64(32)) : Fr::one();
         ZG_TRY(poly_diff_scale(ctx, nb, p->dbuf[2].h, L2, unhat, a2, tb, Fr::inv(Fr::sub(c2, c1)), a2, tb, L2));  // B on the second coset
+        ctx->unit_next = 0.0;
         ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
         ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
     }
@@ -1506,8 +1516,14 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     }
     ZG_TRY(h2d_list(p, p->d_idx, idx));
     // (the evaluations too are written where the host reads them: no copy command behind the kernel)
+    uint32_t distinct_polys = 0;
+    {
+        std::vector<uint32_t> seen(idx.begin(), idx.begin() + evq.size());
+        std::sort(seen.begin(), seen.end());
+        distinct_polys = (uint32_t)(std::unique(seen.begin(), seen.end()) - seen.begin());
+    }
     ZG_TRY(poly_dot(ctx, polys, nb, n, p->d_idx, p->d_idx + evq.size(), p->pw, pw_bs, (uint32_t)evq.size(),
-                    reinterpret_cast<Fe*>((char*)p->pinned_dev + p->pin_evals), p->max_evals));
+                    reinterpret_cast<Fe*>((char*)p->pinned_dev + p->pin_evals), p->max_evals, distinct_polys, npoints));
     const Fe* ev_all = reinterpret_cast<const Fe*>((char*)p->pinned + p->pin_evals);
     ZG_TICK("evals: queued");
     ZG_HIP(hipStreamSynchronize(st));
@@ -1802,7 +1818,7 @@ int zg_prover_evaluate_h(zg_prover* p, const zg_fr* advice_polys, const zg_fr* i
     const PkDev::Dom& d = pk.dom[0];
     ZG_TRY(coeff_to_coset_dev(ctx, p->pp + (size_t)(p->ix_adv - p->nsh) * n, n, n, p->dbuf[0].cos, d.en, p->ncos, d.ek, pk.hat, d.zpow));
     const EvalHArgs a = evalh_args(p, 0);
-    ZG_TRY(poly_evaluate_h(ctx, a, d.en, 1));
+    ZG_TRY(poly_evaluate_h(ctx, a, d.en, 1, pk.A + pk.I + pk.F, (double)d.en));
     WsScope ws(ctx);
     Fe* tmp = ws.get<Fe>(d.en);
     if (!tmp) return ZG_ERR_OOM;

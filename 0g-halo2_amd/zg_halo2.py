@@ -111,7 +111,7 @@ def rng_key(seed) -> bytes:
 
 class KernelStat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_uint64), ("total_ms", ctypes.c_double),
-                ("algo_bytes", ctypes.c_double)]
+                ("algo_bytes", ctypes.c_double), ("unit_bytes", ctypes.c_double)]
 
 
 def _check(status: int) -> None:
@@ -240,12 +240,13 @@ class Ctx:
         _check(self.lib.zg_ctx_profile_filter(self.h, kernel_name.encode() if kernel_name else None))
 
     def profile_collect(self) -> dict:
-        """{kernel: (launches, total_ms, algo_bytes)} since the last collect; synchronises."""
+        """{kernel: (launches, total_ms, algo_bytes, unit_bytes)} since the last collect; synchronises.  algo_bytes = what
+        the kernel itself streams, unit_bytes = SURVEY 8d's figure of the units it carries (include/zg_halo2.h)."""
         cap = 64
         arr = (KernelStat * cap)()
         cnt = c_size_t(0)
         _check(self.lib.zg_ctx_profile_collect(self.h, arr, c_size_t(cap), ctypes.byref(cnt)))
-        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms), float(arr[i].algo_bytes))
+        return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms), float(arr[i].algo_bytes), float(arr[i].unit_bytes))
                 for i in range(min(cap, cnt.value))}
 
     # ---- SRS ----

@@ -49,7 +49,7 @@ import zg_halo2 as zg
 
 R = zg.FR_MODULUS
 MONT = (1 << 256) % R
-PROFILES = os.path.join(ROOT, "profiles", "r03")
+PROFILES = os.path.join(ROOT, "profiles", os.environ.get("ZG_BENCH_PROFILES", "r04"))  # the counter files the line reads
 # the four configurations of BASELINE.json: (k, model); "large" is a seeded stand-in of the same shape
 # because model_49input_8192entry_4hash_6bpi.hdf5 is not in the reference checkout (.MISSING_LARGE_BLOBS)
 MODELS = {"tiny": wnn_model.MNIST_TINY, "small": wnn_model.MNIST_SMALL, "medium": wnn_model.MNIST_MEDIUM,
@@ -227,12 +227,68 @@ def family_of(kernel: str) -> str:
 
 
 def load_pmc():
-    """Counter figures of the same configuration (rocprofv3 --pmc passes, tools/profile_r03.sh + tools/install_r03.py;
-    committed under profiles/r03): HBM bytes per launch per kernel and VALU wave-instructions per proof."""
-    try:
-        return json.load(open(os.path.join(PROFILES, "pmc_traffic.json")))
-    except (OSError, ValueError):
-        return None
+    """Counter figures of the same configuration (rocprofv3 --pmc passes, tools/profile.sh + tools/install_profile.py;
+    committed under profiles/rNN): HBM bytes per launch per kernel and VALU wave-instructions per proof."""
+    return load_json("pmc_traffic.json")
+
+
+def load_json(name: str):
+    """a counter file of this round's profile set, else of the newest earlier round that has it (`_from` says which)"""
+    rounds = [PROFILES] + sorted((os.path.join(ROOT, "profiles", d) for d in os.listdir(os.path.join(ROOT, "profiles"))
+                                  if d.startswith("r") and os.path.join(ROOT, "profiles", d) < PROFILES), reverse=True)
+    for d in rounds:
+        try:
+            out = json.load(open(os.path.join(d, name)))
+            out["_from"] = os.path.relpath(os.path.join(d, name), ROOT)
+            return out
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+# kernel families whose unit of work SURVEY.md 8d defines (its per-proof figure is their sum); the others are charged what
+# their kernels stream
+UNIT_FAMILIES = ("msm", "ntt", "evaluate_h", "products")
+
+
+def roofline_tables(stats: dict, pmc, pmc_scale: float):
+    """Per kernel and per family from the per-launch HIP events of one measured region.
+    stats[kernel] = (launches, device ms, streamed bytes, unit bytes) as the library charges every launch (include/zg_halo2.h,
+    zg_kernel_stat): `streamed` = what the kernel's own algorithm moves (each distinct input once, each output once), `unit` =
+    SURVEY.md 8d's figure for the unit of work, charged ONCE per unit on the kernel that carries it (an MSM's n * 96 + 96 on
+    msm_accumulate, not on each of its eight kernels).  A kernel's GB/s is its own streamed bytes over its own time; a family's
+    is its units' bytes (where SURVEY defines the unit, else its kernels' streams) over the family's time, and its counter
+    traffic is the SUM over its kernels -- the MSM's eight kernels together against ONE n * 96 + 96."""
+    kernels, fam = {}, {}
+    for name, (l, ms, by, ub) in stats.items():
+        k_pmc = (pmc or {}).get("kernels", {}).get(name)
+        gbps = (by / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
+        kernels[name] = {"launches": l, "total_ms": round(ms, 3), "avg_launch_ms": ms / max(l, 1),
+                         "algo_bytes_per_launch": by / max(l, 1), "unit_bytes_per_launch": ub / max(l, 1),
+                         "algo_GBps": gbps,
+                         "hbm_bytes_per_launch": int(k_pmc["hbm_bytes_per_launch"] * pmc_scale) if k_pmc else None}
+        f = fam.setdefault(family_of(name), {"total_ms": 0.0, "streamed": 0.0, "unit": 0.0, "hbm_bytes": 0.0, "hbm_known": True})
+        f["total_ms"] += ms
+        f["streamed"] += by
+        f["unit"] += ub
+        if k_pmc:
+            f["hbm_bytes"] += k_pmc["hbm_bytes_per_launch"] * pmc_scale * l
+        else:
+            f["hbm_known"] = False
+    device_ms = sum(v[1] for v in stats.values())
+    families = {}
+    for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["total_ms"]):
+        unit_basis = name in UNIT_FAMILIES and f["unit"] > 0
+        algo = f["unit"] if unit_basis else f["streamed"]
+        gbps = algo / (f["total_ms"] * 1e-3) / 1e9 if f["total_ms"] > 0 else 0.0
+        families[name] = {"share_of_device_time": f["total_ms"] / device_ms if device_ms else 0.0,
+                          "algorithmic_bytes": algo, "basis": "SURVEY 8d units, each charged once" if unit_basis else "what the kernels stream",
+                          "streamed_bytes_of_its_kernels": f["streamed"],
+                          "algo_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+                          "counter_bytes": f["hbm_bytes"] if f["hbm_known"] else None,
+                          "counter_over_algorithmic_bytes": (f["hbm_bytes"] / algo) if f["hbm_known"] and algo else None}
+    charged_unit_bytes = sum(f["unit"] for f in fam.values())
+    return kernels, families, device_ms, charged_unit_bytes
 
 
 def cpu_baseline(c: Circuit, proof_len: int, threads: int, repeats: int = 7):
@@ -265,7 +321,10 @@ def cpu_baseline(c: Circuit, proof_len: int, threads: int, repeats: int = 7):
     return {
         "value": 3600.0 / dt, "unit": "proofs/hour", "cores": threads, "kind": "port",
         "sample": f"median of {repeats} full create_proofs of the same k={c.k} circuit (after 1 warm-up): {dt:.3f} s each; "
-                  f"oracle/prover.c (plain-C restatement of halo2 create_proof, OpenMP {threads} threads)",
+                  f"oracle/prover.c (plain-C restatement of halo2 create_proof, OpenMP {threads} threads); its evaluate_h "
+                  f"INTERPRETS the gate monomials row by row where halo2's GraphEvaluator runs a compiled graph (the `h` phase is "
+                  f"~3/4 of this proof), on {threads} of the machine's {os.cpu_count()} cores: expected SLOWER than real halo2 on the "
+                  f"same cores -- a baseline to be read with that, never a speed-up claim",
         "wall_s": dt, "samples_s": [round(x, 4) for x in samples], "min_s": min(samples), "max_s": max(samples),
         "openmp": {"threads": threads, "OMP_NUM_THREADS": os.environ.get("OMP_NUM_THREADS"), "OMP_PROC_BIND": os.environ.get("OMP_PROC_BIND"),
                    "cores_in_affinity_mask": affinity, "machine_cores": os.cpu_count()},
@@ -322,8 +381,8 @@ def image_to_proof(c: Circuit, streams, ctxs, barrier, threads: int, verify: boo
         s.enable_images(arrays, pool)
     dt, stats = measure(streams, ctxs, steps, 1, barrier, profile=True)
     n = steps * sum(s.batch for s in streams)
-    wit_ms = sum(stats.get(k_, (0, 0.0, 0.0))[1] for k_ in ("witness_run", "witness_finish"))
-    wit_launches = stats.get("witness_run", (0, 0.0, 0.0))[0]
+    wit_ms = sum(stats.get(k_, (0, 0.0, 0.0, 0.0))[1] for k_ in ("witness_run", "witness_finish"))
+    wit_launches = stats.get("witness_run", (0, 0.0, 0.0, 0.0))[0]
     out = {"ms_per_proof": dt / n * 1e3, "proofs_per_hour": n / dt * 3600.0, "images": len(pool),
            "witness_program": {"operations": int(arrays["ops"].shape[0]), "levels": int(arrays["level_start"].shape[0] - 1),
                                "assigned_cells": len(prog.cells), "recorded_in_s": round(trace_s, 2)},
@@ -371,9 +430,9 @@ def measure(streams, ctxs, steps, warmup, barrier, profile=False):
     stats = {}
     for x in ctxs:
         if profile:
-            for name, (l, ms, by) in x.profile_collect().items():
-                a = stats.get(name, (0, 0.0, 0.0))
-                stats[name] = (a[0] + l, a[1] + ms, a[2] + by)
+            for name, (l, ms, by, ub) in x.profile_collect().items():
+                a = stats.get(name, (0, 0.0, 0.0, 0.0))
+                stats[name] = (a[0] + l, a[1] + ms, a[2] + by, a[3] + ub)
         x.profile(False)
     return dt, stats
 
@@ -624,65 +683,80 @@ def main():
         #  the proofs of a batch side by side, so bytes per launch scale with the batch)
         pmc_scale = batch / float(pmc.get("proofs_per_launch", batch)) if pmc else 1.0
         launches_per_proof = sum(v[0] for v in stats.values()) / max(1, args.steps * proofs_per_step)
-        # per kernel and per family: device time, algorithmic bytes (DESIGN.md's per-unit figures x units per launch),
-        # algorithmic GB/s against the HBM peak, counter bytes / algorithmic bytes
-        kernels, fam = {}, {}
-        for name, (l, ms, by) in stats.items():
-            k_pmc = (pmc or {}).get("kernels", {}).get(name)
-            kernels[name] = {"launches": l, "total_ms": round(ms, 3), "avg_launch_ms": ms / max(l, 1),
-                             "algo_bytes_per_launch": by / max(l, 1),
-                             "algo_GBps": (by / (ms * 1e-3) / 1e9) if ms > 0 else 0.0,
-                             "hbm_bytes_per_launch": int(k_pmc["hbm_bytes_per_launch"] * pmc_scale) if k_pmc else None}
-            f = fam.setdefault(family_of(name), {"total_ms": 0.0, "algo_bytes": 0.0, "hbm_bytes": 0.0, "hbm_known": True})
-            f["total_ms"] += ms
-            f["algo_bytes"] += by
-            if k_pmc:
-                f["hbm_bytes"] += k_pmc["hbm_bytes_per_launch"] * pmc_scale * l
-            else:
-                f["hbm_known"] = False
-        device_ms = sum(v[1] for v in stats.values())
-        families = {}
-        for name, f in sorted(fam.items(), key=lambda kv: -kv[1]["total_ms"]):
-            gbps = f["algo_bytes"] / (f["total_ms"] * 1e-3) / 1e9 if f["total_ms"] > 0 else 0.0
-            families[name] = {"share_of_device_time": f["total_ms"] / device_ms if device_ms else 0.0,
-                              "algo_GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
-                              "counter_over_algorithmic_bytes": (f["hbm_bytes"] / f["algo_bytes"]) if f["hbm_known"] and f["algo_bytes"] else None}
+        kernels, families, device_ms, charged_unit_bytes = roofline_tables(stats, pmc, pmc_scale)
+        # ONE prover stepping, same lock-step batches, every launch bracketed by its own events -- one stream, so the kernels
+        # run one at a time: what a kernel costs ALONE on the chip.  The timed region's durations are shared-chip durations
+        # (eleven other provers run beside every launch) and flip from box to box; the dominant kernel is picked HERE.
+        serial = None
+        if stats and not args.no_serialised and not sharded and world == 1:
+            dt1, st1 = measure(streams[:1], ctxs[:1], 3, 1, barrier, profile=True)
+            k1, f1, dev1, _ = roofline_tables(st1, pmc, pmc_scale)
+            serial = {"note": "one prover alone on the chip (one stream: kernels run one at a time), same batches of "
+                              f"{batch}; per-launch HIP events; algorithmic bytes / launch duration against the HBM peak",
+                      "ms_per_proof": dt1 / (3 * batch) * 1e3, "device_ms_per_proof": dev1 / (3 * batch),
+                      "kernels": {k_: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "share_of_device_time": round(v["total_ms"] / dev1, 4) if dev1 else 0.0,
+                                       "algo_GBps": round(v["algo_GBps"], 1), "frac_of_hbm_peak": round(v["algo_GBps"] / HBM_PEAK_GBPS, 5)}
+                                  for k_, v in sorted(k1.items(), key=lambda kv: -kv[1]["total_ms"])},
+                      "families": f1}
         roofline = None
         if stats:
-            # the dominant kernel = the one with the largest device time in THIS run's timed region
-            name = max(stats.items(), key=lambda kv: kv[1][1])[0]
+            # the dominant kernel: the largest share of the SERIALISED pass; without one (N > 1, --no-serialised) the largest
+            # share of the proof's VALU instructions (counter file), else of this run's shared-chip time
+            by_valu = (pmc or {}).get("valu", {}).get("by_kernel") or {}
+            if serial:
+                name, picked_by = next(iter(serial["kernels"])), "largest device time in the serialised pass (one prover alone on the chip)"
+            elif by_valu:
+                name, picked_by = max((k_ for k_ in by_valu if k_ in kernels), key=lambda k_: by_valu[k_]), "largest share of SQ_INSTS_VALU per proof"
+            else:
+                name, picked_by = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0], "largest shared-chip device time of this run"
             kd = kernels[name]
-            achieved = kd["algo_bytes_per_launch"] / (kd["avg_launch_ms"] * 1e-3) / 1e9 if kd["avg_launch_ms"] > 0 else 0.0
+            per_launch = kd["unit_bytes_per_launch"] or kd["algo_bytes_per_launch"]  # (the unit's bytes where the kernel carries one)
+            achieved = per_launch / (kd["avg_launch_ms"] * 1e-3) / 1e9 if kd["avg_launch_ms"] > 0 else 0.0
             roofline = {
-                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": name, "kernel_picked_by": picked_by, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": kd["hbm_bytes_per_launch"],
-                "avg_launch_ms": kd["avg_launch_ms"], "algo_bytes_per_launch": kd["algo_bytes_per_launch"],
+                "avg_launch_ms": kd["avg_launch_ms"], "algo_bytes_per_launch": per_launch,
                 "share_of_device_time": kd["total_ms"] / device_ms if device_ms else 0.0,
                 "launches_per_proof": kd["launches"] / (args.steps * proofs_per_step),
                 "proofs_per_launch": batch,
+                "durations": "timed region: twelve provers share the chip (shared-chip durations are not additive); `serialised` = alone on the chip",
                 "families": families,
                 "note": "BASELINE asks for the HBM roofline; the kernels are integer-ALU bound "
                         "(254-bit Montgomery products), see DESIGN.md and `valu`",
             }
+            if serial:
+                sk = serial["kernels"][name]
+                ach1 = per_launch / (sk["avg_launch_ms"] * 1e-3) / 1e9 if sk["avg_launch_ms"] > 0 else 0.0
+                serial.update({"kernel": name, "achieved": ach1, "frac": ach1 / HBM_PEAK_GBPS, "avg_launch_ms": sk["avg_launch_ms"]})
+                roofline["serialised"] = serial
         valu = None
         if pmc and "valu" in pmc:
             per_proof = float(pmc["valu"]["wave_instructions_per_proof"])
             ach = per_proof / (ms_per_proof * 1e-3)
             # three yardsticks: the architectural issue peak (one wave64 instruction per SIMD every 2 cycles: only
             # v_mov-class instructions reach it), the 4-cycle rate the SQ counters price a VALU instruction at
-            # (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles; 2.1 GHz under this load), and the rate a pure stream of
-            # nine-limb Montgomery products sustains (tools/fp64_probe.hip: 173.9 G products/s x 236 instructions)
-            four_cycle = 256 * 4 * 2.1e9 / 4
+            # (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU quad-cycles) at the clock the counter passes measured under this load,
+            # and the rate a pure stream of nine-limb Montgomery products sustains (tools/fp64_probe.hip: 173.9 G products/s
+            # x 236 instructions)
+            sq = load_json("sq_issue.json") or {}
+            alone = sq.get("kernels", {})
+            # (the timed region's clock: the VALU-bound kernels' -- the time-weighted mean of the counter passes' per-kernel
+            #  clocks reads high because the short latency-bound launches do)
+            heavy = [v for k_, v in alone.items() if v.get("valu_issue_util", 0) >= 0.7 and v.get("clock_GHz")]
+            clock = (sum(v["clock_GHz"] * v["us_per_proof"] for v in heavy) / sum(v["us_per_proof"] for v in heavy)) if heavy else 2.1
+            four_cycle = 256 * 4 * clock * 1e9 / 4
             product_loop = 173.9e9 * 236 / 64
             valu = {"wave_instructions_per_proof": per_proof, "achieved_wave_instr_per_s": ach,
                     "issue_peak_wave_instr_per_s": VALU_ISSUE_PEAK, "frac": ach / VALU_ISSUE_PEAK,
                     "peak_note": "one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32), 256 CUs x 4 SIMDs x 2.4 GHz",
+                    "clock_GHz_under_load": round(clock, 3),
+                    "clock_source": f"{os.path.relpath(PROFILES, ROOT)}/sq_issue.json: GRBM_GUI_ACTIVE / duration of the kernels at >= 0.7 issue utilisation, time-weighted",
                     "four_cycle_issue_rate_wave_instr_per_s": four_cycle, "frac_of_four_cycle_issue_rate": ach / four_cycle,
                     "nine_limb_product_loop_rate_wave_instr_per_s": product_loop,
                     "frac_of_nine_limb_product_loop_rate": ach / product_loop,
-                    "per_kernel_alone": "profiles/r03/sq_issue.json (ntt 0.93-0.98, evaluate_h 0.74, msm_accumulate 0.66 of the "
-                                        "4-cycle rate when alone on the chip; the reductions 0.03-0.12)",
-                    "source": pmc["valu"].get("source")}
+                    "per_kernel_alone": {k_: round(v["valu_issue_util"], 3) for k_, v in alone.items() if "valu_issue_util" in v},
+                    "per_kernel_alone_note": "VALU issue utilisation (4-cycle rate) of each kernel ALONE on the chip, from the counter passes",
+                    "source": pmc["valu"].get("source"), "counter_files": [pmc.get("_from"), sq.get("_from")]}
         cs = circuit.cs
         out = {
             "metric": f"create_proof proofs/hour, {circuit.model_name}",
@@ -715,35 +789,22 @@ def main():
             "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
             "create_proof_wall_s": latency_s, "lone_proof_digit_table_bytes": table_bytes, "provers_per_gpu": nprov, "batch": batch,
             "launches_per_proof": launches_per_proof,
+            # SURVEY.md 8d's per-proof figure, twice: from its formula and as the library charged it launch by launch
+            # (the units of the msm / ntt / evaluate_h / products families, each once) -- the two must agree
+            "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof(cs),
+            "algorithmic_bytes_per_proof_charged": charged_unit_bytes / max(1, args.steps * proofs_per_step) if stats else None,
             "algorithmic_GBps": algorithmic_bytes_per_proof(cs) / (ms_per_proof * 1e-3) / 1e9,
             "device_ms_per_proof": device_ms / max(1, args.steps * proofs_per_step),
             "roofline": roofline, "valu": valu,
             "kernels": {k_: {"avg_launch_ms": round(v["avg_launch_ms"], 4), "share": round(v["total_ms"] / device_ms, 4) if device_ms else 0,
-                             "algo_GBps": round(v["algo_GBps"], 1), "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
+                             "algo_GBps": round(v["algo_GBps"], 1), "frac_of_hbm_peak": round(v["algo_GBps"] / HBM_PEAK_GBPS, 5),
+                             "hbm_bytes_per_launch": v["hbm_bytes_per_launch"]}
                         for k_, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])},
             "single_proof_phase_ms": dict(zip(["advice", "lookups_permuted", "products", "h", "evals", "gwc",
                                                "total", "host_sort"], [round(x, 3) for x in phases])),
         }
         if not args.no_verify:
             out.update(verify_last_step(circuit, streams, host_cores()))  # (a sharded rank holds whole proofs: same check)
-    if rank == 0 and out.get("roofline") and not args.no_serialised and not sharded and world == 1:
-        # The timed region's durations are SHARED-chip durations (eleven other provers run beside every launch).  Per-kernel
-        # cost is what a kernel takes alone: ONE prover stepping, same lock-step batches, every launch bracketed by its own
-        # events -- one stream, so the kernels run one at a time.
-        dt1, st1 = measure(streams[:1], ctxs[:1], 3, 1, barrier, profile=True)
-        dev1 = sum(v[1] for v in st1.values())
-        ser = {}
-        for name, (l, ms, by) in sorted(st1.items(), key=lambda kv: -kv[1][1]):
-            gbps = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-            ser[name] = {"avg_launch_ms": round(ms / max(l, 1), 4), "share_of_device_time": round(ms / dev1, 4) if dev1 else 0.0,
-                         "algo_GBps": round(gbps, 1), "frac_of_hbm_peak": round(gbps / HBM_PEAK_GBPS, 5)}
-        dom = out["roofline"]["kernel"]
-        out["roofline"]["serialised"] = {
-            "note": "one prover alone on the chip (one stream: kernels run one at a time), same batches of "
-                    f"{batch}; per-launch HIP events; algorithmic bytes / launch duration against the HBM peak",
-            "ms_per_proof": dt1 / (3 * batch) * 1e3, "device_ms_per_proof": dev1 / (3 * batch),
-            "kernel": dom, "achieved": ser.get(dom, {}).get("algo_GBps"), "frac": ser.get(dom, {}).get("frac_of_hbm_peak"),
-            "avg_launch_ms": ser.get(dom, {}).get("avg_launch_ms"), "kernels": ser}
     if rank == 0 and not args.no_image_to_proof and not sharded and args.model == "tiny" and world == 1 and not HOST_ADVICE:
         out["image_to_proof"] = image_to_proof(circuit, streams, ctxs, barrier, host_cores(), not args.no_verify)
     # the other three models of BASELINE.json: a few steps each, same driver (after the headline's timed region)

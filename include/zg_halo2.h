@@ -102,13 +102,18 @@ int zg_ctx_sync(zg_ctx *ctx);
 void *zg_ctx_stream(zg_ctx *ctx);
 
 /* Per-kernel timing with HIP events recorded on the context stream around every launch (used by
- * bench.py for the roofline line; off by default).  algo_bytes is the ALGORITHMIC byte count the
- * launches were charged with (DESIGN.md lists the per-unit figures), not measured HBM traffic. */
+ * bench.py for the roofline line; off by default).  Two ALGORITHMIC byte counts, neither measured HBM traffic:
+ * algo_bytes = what the kernel's own algorithm streams (every distinct input once, every output once);
+ * unit_bytes = SURVEY.md 8d's figure for the unit of work (one MSM: n * 96 + 96; one transform: (in + out) * 32; one
+ * grand product: 3 n * 32; evaluate_h: (inputs + 1) * 8n * 32), charged ONCE per unit -- on the one kernel of a
+ * multi-kernel launch sequence that carries the unit (msm_accumulate for an MSM), 0 on its stage kernels and on
+ * kernels SURVEY names no unit for.  Summed over a proof's launches unit_bytes is SURVEY's per-proof figure. */
 typedef struct {
     char name[48];
     uint64_t launches;
     double total_ms;
     double algo_bytes;
+    double unit_bytes;
 } zg_kernel_stat;
 int zg_ctx_profile_enable(zg_ctx *ctx, int on);
 /* Time only launches of the named kernel (NULL or "" = every kernel).  A timed launch carries its own start and

@@ -49,11 +49,11 @@ int main(int argc, char** argv) {
     if (device) {
         Case* d = nullptr;
         if (hipMalloc(&d, sizeof(cs)) != hipSuccess) { printf("FAIL hipMalloc\n"); return 2; }
-        hipMemcpy(d, cs, sizeof(cs), hipMemcpyHostToDevice);
+        (void)hipMemcpy(d, cs, sizeof(cs), hipMemcpyHostToDevice);
         hipLaunchKernelGGL(inv_kernel, dim3(1), dim3(64), 0, 0, d, n);
         if (hipDeviceSynchronize() != hipSuccess) { printf("FAIL kernel\n"); return 2; }
-        hipMemcpy(cs, d, sizeof(cs), hipMemcpyDeviceToHost);
-        hipFree(d);
+        (void)hipMemcpy(cs, d, sizeof(cs), hipMemcpyDeviceToHost);
+        (void)hipFree(d);
     } else {
         for (int i = 0; i < n; i++) {
             cs[i].out_fr = Fr::inv(cs[i].in);

@@ -27,7 +27,7 @@ STATIC_ASSERT(circuit, sizeof(zg_circuit) == 136 && offsetof(zg_circuit, n_queri
                            offsetof(zg_circuit, n_advice_queries) == 104 && offsetof(zg_circuit, advice_queries) == 112 &&
                            offsetof(zg_circuit, n_fixed_queries) == 120 && offsetof(zg_circuit, fixed_queries) == 128);
 STATIC_ASSERT(witness_op, sizeof(zg_witness_op) == 32 && offsetof(zg_witness_op, imm) == 24);
-STATIC_ASSERT(kernel_stat, sizeof(zg_kernel_stat) == 72 && offsetof(zg_kernel_stat, launches) == 48 &&
+STATIC_ASSERT(kernel_stat, sizeof(zg_kernel_stat) == 80 && offsetof(zg_kernel_stat, unit_bytes) == 72 && offsetof(zg_kernel_stat, launches) == 48 &&
                                offsetof(zg_kernel_stat, total_ms) == 56 && offsetof(zg_kernel_stat, algo_bytes) == 64);
 STATIC_ASSERT(status_codes, ZG_OK == 0 && ZG_ERR_INVALID_ARG == -1 && ZG_ERR_NO_DEVICE == -2 && ZG_ERR_HIP == -3 &&
                                 ZG_ERR_UNSUPPORTED == -4 && ZG_ERR_CONSTRAINT == -5 && ZG_ERR_OOM == -6);
@@ -54,7 +54,7 @@ int main(void) {
     END();
     BEGIN(zg_witness_op); FIELD(zg_witness_op, op); FIELD(zg_witness_op, a); FIELD(zg_witness_op, b); FIELD(zg_witness_op, imm); END();
     BEGIN(zg_kernel_stat); FIELD(zg_kernel_stat, name); FIELD(zg_kernel_stat, launches); FIELD(zg_kernel_stat, total_ms);
-    FIELD(zg_kernel_stat, algo_bytes); END();
+    FIELD(zg_kernel_stat, algo_bytes); FIELD(zg_kernel_stat, unit_bytes); END();
     printf("\n}\n");
     return 0;
 }
