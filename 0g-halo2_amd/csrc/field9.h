@@ -45,6 +45,10 @@ struct Fq9Params {
     static ZG_HD Fe c261_fe() {
         return Fe{{0x157ccc21u, 0x4e8384ebu, 0x0ce148c3u, 0xfb90a602u, 0x819caa36u, 0x5301fa84u, 0x563d4475u, 0x0dc83629u}};
     }
+    // 2^271 mod p: Fq::inv of the packed form of x * 2^261 returns x^-1 * 2^251; mul9(that, k271) = x^-1 * 2^261
+    static __device__ __forceinline__ F9 k271() {
+        return F9{{0x1d1c9c4b, 0x08a372ee, 0x1273abad, 0x17c9d397, 0x1698b0a7, 0x09c89e50, 0x177e12ab, 0x185f3518, 0x001ed378}};
+    }
 };
 
 struct Fr9Params {

@@ -42,6 +42,7 @@ constexpr uint32_t MSM_K_THROUGHPUT = 48, MSM_K_LATENCY = 16;
 constexpr uint32_t MSM_MAX_C = 16;
 constexpr uint32_t MSM_LEN_BINS = 128;  // task-length classes of the accumulate launch (lengths <= task size + 1 < 128)
 constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
+constexpr uint32_t MSM_AFFINE_ROUNDS = 0;  // batched-affine rounds before the XYZZ chains, throughput form (ZG_MSM_AFFINE)
 constexpr uint32_t MSM_MAX_BATCH = 4096;  // vectors per batched MSM call
 
 __device__ __forceinline__ Fe ld_fe_g(const Fe* p) {
@@ -306,7 +307,8 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ ttotal, uint32_t* __restrict__ hmap,
                                                         uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
                                                         uint32_t max_heavy, uint32_t* __restrict__ off, uint32_t MSM_K,
-                                                        uint32_t* __restrict__ stoff, uint32_t* __restrict__ sbucket) {
+                                                        uint32_t* __restrict__ stoff, uint32_t* __restrict__ sbucket,
+                                                        uint32_t R, uint32_t* __restrict__ sorted, size_t cap) {
     extern __shared__ uint32_t scan_smem[];  // [nb+2] bucket totals -> entry offsets
     __shared__ uint32_t se[1024], st[1024];
     __shared__ uint32_t hcount;
@@ -330,10 +332,14 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     uint32_t lo = tid * per, hi = lo + per;
     if (lo > nb + 1) lo = nb + 1;
     if (hi > nb + 1) hi = nb + 1;
+    // R > 0 (batched-affine pre-reduction, below): a bucket's entry range is PADDED to a multiple of 2^R with null entries,
+    // so that R rounds of pairwise additions never pair entries of two buckets; the accumulation's tasks are then cut from
+    // the bucket's v' = ceil(v / 2^R) points that are left.  R = 0: v' = v, nothing changes.
+    const uint32_t padm = (1u << R) - 1u;
     uint32_t es = 0, ts = 0;
     for (uint32_t k = lo; k < hi; k++) {
-        uint32_t v = le[k];
-        es += v;
+        uint32_t v = (le[k] + padm) >> R;
+        es += v << R;
         const uint32_t nt = (v + MSM_K - 1) / MSM_K;
         ts += nt;
         atomicAdd(&bins[nt ? v / nt : 0u], 1u);  // (a bucket's tasks hold v / nt or one more entries: its length class)
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     __syncthreads();
     for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t v = le[k];
+        const uint32_t v = (le[k] + padm) >> R;
         const uint32_t nt = (v + MSM_K - 1) / MSM_K;
         const uint32_t pos = atomicAdd(&bcur[nt ? v / nt : 0u], 1u);
         sbk[pos] = k;
@@ -403,10 +409,12 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
     uint32_t eb = se[tid] - es, tb = st[tid] - ts;
     for (uint32_t k = lo; k < hi; k++) {
-        const uint32_t v = le[k];
+        const uint32_t raw = le[k];
+        const uint32_t v = (raw + padm) >> R;
         le[k] = eb;
         to[k] = tb;  // write-only: no dependent HBM reads in this strip loop
-        eb += v;
+        for (uint32_t q = raw; q < (v << R); q++) sorted[(size_t)b * cap + eb + q] = 0xffffffffu;  // (R > 0: the pad slots; k = 0 holds nothing)
+        eb += v << R;
         const uint32_t nt = (v + MSM_K - 1) / MSM_K;
         tb += nt;
         // hot bucket (repeated or tiny scalars): merged by its own workgroup in msm_heavy_kernel
@@ -439,12 +447,21 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
 }
 
 // Write (point, window, sign) into bucket order: position = cell offset + slot inside the cell.
+// Every entry is ONE scattered 4-byte store: a vector's bucket-ordered array (~1 MB) fits an XCD's 4 MB L2, so the stores
+// of a vector combine into whole lines there -- IF they all go through the same L2.  Workgroups are dealt round-robin
+// over the 8 XCDs (blocks b and b + 8 share one), so the flat grid is laid out XCD by XCD: block L works for the XCD
+// L % 8, which takes the vectors xcd, xcd + 8, ... one after the other; with the (chunk, window, vector) grid of round 3 a
+// vector's stores reached HBM as partial lines from eight L2s (1.12 GB of write traffic per launch for 0.2 GB of entries).
 __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __restrict__ dig, uint32_t n, uint32_t c,
                                                           uint32_t windows, const uint32_t* __restrict__ off,
                                                           const uint32_t* __restrict__ slot,
-                                                          uint32_t* __restrict__ sorted, uint32_t naf) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t w = blockIdx.y, b = blockIdx.z;
+                                                          uint32_t* __restrict__ sorted, uint32_t naf, size_t cap, uint32_t B,
+                                                          uint32_t chunks) {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per_vec = chunks * windows;
+    const uint32_t b = xcd + 8u * (j / per_vec);
+    if (b >= B) return;
+    const uint32_t r = j % per_vec, w = r / chunks;
+    const uint32_t i = (r % chunks) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
     const size_t cell = ((size_t)b * windows + w);
@@ -454,7 +471,259 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __rest
     uint32_t pos = off[cell * (nb + 1) + k] + slot[cell * n + i];
     // entry = point (23 bits) | table row (8 bits: the window, or the bit position of a free-position digit) | sign
     const uint32_t row = naf ? (d >> 16) & 0xffu : w;
-    sorted[(size_t)b * windows * n + pos] = i | (row << 23) | (d & 0x80000000u);
+    sorted[(size_t)b * cap + pos] = i | (row << 23) | (d & 0x80000000u);
+}
+
+// ---------------------------------------------------------------- batched-affine pre-reduction (throughput form)
+// An XYZZ mixed addition costs ten products; the affine chord  l = (y2 - y1) / (x2 - x1), x3 = l^2 - x1 - x2,
+// y3 = l (x1 - x3) - y1  costs three and one INVERSION -- which Montgomery's trick shares among any number of independent
+// additions at three more products each.  Inside one task of one lane there are no independent additions, and a workgroup's
+// worth (a few thousand) does not pay for an inversion (~20 000 wave-instructions whoever runs it, an addition ~25 per
+// lane); but a lock-step batch brings 10^7 of them per LAUNCH: the entries of every bucket of every vector, paired up
+// (2p, 2p + 1).  So the inversion is shared by the whole launch, through HBM:
+//   aff_prefix   lane l of vector b takes the pairs p = l + s L (s < AFF_A): denominators d_s (x2 - x1; 2 y for a doubling;
+//                one where there is nothing to add), their running product before each pair -> pre[], the lane's total -> val[]
+//   aff_inv_up   a lane folds AFF_S lane totals the same way (prefix -> pfx[], total -> val2[])
+//   aff_inv_top  ONE workgroup: strips of val2[], a prefix and a suffix product scan over its 1024 lanes through LDS, ONE
+//                inversion (binary Euclid, lane 0), and back down its strips: val2[] := the inverses
+//   aff_inv_down back down the AFF_S-strips: val[] := the inverse of every lane total
+//   aff_apply    the lane walks its pairs backwards: 1 / d_s = u * pre_s, u *= d_s; the chord; the sum as a canonical
+//                packed affine point (x * 2^261 form, like the table rows) -> pts[p]
+// 6 + 3 / AFF_A + ... products per addition instead of 10, paid for with ~390 B of HBM traffic per addition (both gathers
+// of the operands, the prefix, the sum).  R such rounds halve the summands R times; buckets are padded to multiples of
+// 2^R (msm_scan_kernel) so a pair never straddles two buckets, and msm_accumulate_kernel<false, true> chains what is left.
+// Same group element as the XYZZ chain, so the same bytes.  Knob ZG_MSM_AFFINE = R.
+constexpr uint32_t AFF_A = 8;       // pairs per lane and round
+constexpr uint32_t AFF_S = 256;     // lane totals per lane of aff_inv_up / aff_inv_down
+constexpr uint32_t AFF_TOP = 1024;  // lanes of aff_inv_top
+constexpr uint32_t AFF_NULL = 0xffffffffu;
+
+// F9 values in HBM, limb-major: limb j of element e at base[j * stride + e] (a wave's accesses are nine coalesced rows)
+__device__ __forceinline__ F9 ld_f9_soa(const int32_t* __restrict__ base, size_t stride, size_t e) {
+    F9 r;
+#pragma unroll
+    for (int j = 0; j < 9; j++) r.l[j] = base[(size_t)j * stride + e];
+    return r;
+}
+__device__ __forceinline__ void st_f9_soa(int32_t* __restrict__ base, size_t stride, size_t e, const F9& v) {
+#pragma unroll
+    for (int j = 0; j < 9; j++) base[(size_t)j * stride + e] = v.l[j];
+}
+
+enum AffKind : uint32_t { AFF_ADD = 0, AFF_DBL = 1, AFF_COPY1 = 2, AFF_COPY2 = 3, AFF_ZERO = 4 };
+
+// The operands of pair p of this round: FIRST = entries (point | table row | sign) of the padded bucket order, against the
+// vector's table; later rounds = the previous round's points.  nullptr = nothing there (a pad entry).
+template <bool FIRST>
+__device__ __forceinline__ const Affine* aff_operand(const uint32_t* __restrict__ so, const Affine* __restrict__ table,
+                                                     uint32_t n_table, const Affine* __restrict__ prev, uint32_t idx,
+                                                     uint32_t& neg) {
+    neg = 0;
+    if constexpr (FIRST) {
+        const uint32_t ent = so[idx];
+        if (ent == AFF_NULL) return nullptr;
+        neg = ent >> 31;
+        return table + (size_t)((ent >> 23) & 0xffu) * n_table + (ent & 0x7fffffu);
+    } else {
+        return prev + idx;
+    }
+}
+
+// Kind of the pair and its denominator.  x = 0 marks the identity (no point of y^2 = x^3 + 3 over Fq has x = 0: 3 is a
+// non-residue).  Equal x: the same point (doubling, denominator 2 y) or opposite points (the sum is the identity).
+__device__ __forceinline__ uint32_t aff_classify(const Affine* p1, const Affine* p2, uint32_t n1, uint32_t n2, const Fe& x1,
+                                                 const Fe& x2, F9& d) {
+    const bool z1 = p1 == nullptr || fe_is_zero(x1), z2 = p2 == nullptr || fe_is_zero(x2);
+    d = Fq9Params::one();
+    if (z1 || z2) return z1 ? (z2 ? AFF_ZERO : AFF_COPY2) : AFF_COPY1;
+    if (__builtin_expect(fe_eq(x1, x2), 0)) {
+        const Fe y1 = ld_fe_g(&p1->y), y2 = ld_fe_g(&p2->y);
+        if (fe_eq(y1, y2) != (n1 == n2)) return AFF_ZERO;  // y2 = -y1 (y != 0 on this curve)
+        F9 y = f9_unpack(y1);
+        if (n1) y = f9_neg(y);
+        d = f9_norm(f9_add(y, y));
+        return AFF_DBL;
+    }
+    d = f9_sub(f9_unpack(x2), f9_unpack(x1));
+    return AFF_ADD;
+}
+
+struct AffArgs {
+    const Affine* table_a; const Affine* table_b; const Affine* run_a; const Affine* run_b;
+    uint32_t split, n_table, per, nb;
+    uint64_t run_mask;
+    const uint32_t* tot;     // [B][nb + 2] padded entry offsets; tot[nb + 1] = the vector's padded total
+    const uint32_t* sorted;  // [B][cap]
+    const Affine* prev;      // [B][cap >> (r - 1)] the previous round's points (r > 1)
+    Affine* out;             // [B][cap >> r]
+    size_t cap;
+    uint32_t r;              // this round, 1-based
+    uint32_t lanes;          // lanes per vector (a multiple of the block size)
+    int32_t* pre;            // [9][AFF_A * B * lanes]
+    int32_t* val;            // [9][B * lanes] lane totals, then their inverses
+};
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void aff_prefix_kernel(AffArgs a) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const uint32_t pairs = a.tot[(size_t)b * (a.nb + 2) + a.nb + 1] >> a.r;
+    const uint32_t vj = b % a.per;
+    const bool runs = vj < 64 && ((a.run_mask >> vj) & 1ull);
+    const Affine* table = vj < a.split ? (runs ? a.run_a : a.table_a) : (runs ? a.run_b : a.table_b);
+    const uint32_t* so = a.sorted + (size_t)b * a.cap;
+    const Affine* prev = a.prev + (size_t)b * (a.cap >> (a.r - 1));
+    const size_t nl = (size_t)gridDim.y * a.lanes, fl = (size_t)b * a.lanes + l;
+    F9 acc = Fq9Params::one();
+#pragma unroll 1
+    for (uint32_t s = 0; s < AFF_A; s++) {
+        const uint32_t p = l + s * a.lanes;
+        if (p >= pairs) break;
+        uint32_t n1, n2;
+        const Affine* p1 = aff_operand<FIRST>(so, table, a.n_table, prev, 2 * p, n1);
+        const Affine* p2 = aff_operand<FIRST>(so, table, a.n_table, prev, 2 * p + 1, n2);
+        const Fe x1 = p1 ? ld_fe_g(&p1->x) : fe_zero(), x2 = p2 ? ld_fe_g(&p2->x) : fe_zero();
+        F9 d;
+        const uint32_t kind = aff_classify(p1, p2, n1, n2, x1, x2, d);
+        st_f9_soa(a.pre, (size_t)AFF_A * nl, (size_t)s * nl + fl, acc);
+        if (kind <= AFF_DBL) acc = Fq9::mul(acc, d);
+    }
+    st_f9_soa(a.val, nl, fl, acc);
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void aff_apply_kernel(AffArgs a) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+    const uint32_t pairs = a.tot[(size_t)b * (a.nb + 2) + a.nb + 1] >> a.r;
+    if (l >= pairs) return;
+    const uint32_t vj = b % a.per;
+    const bool runs = vj < 64 && ((a.run_mask >> vj) & 1ull);
+    const Affine* table = vj < a.split ? (runs ? a.run_a : a.table_a) : (runs ? a.run_b : a.table_b);
+    const uint32_t* so = a.sorted + (size_t)b * a.cap;
+    const Affine* prev = a.prev + (size_t)b * (a.cap >> (a.r - 1));
+    Affine* out = a.out + (size_t)b * (a.cap >> a.r);
+    const size_t nl = (size_t)gridDim.y * a.lanes, fl = (size_t)b * a.lanes + l;
+    F9 u = ld_f9_soa(a.val, nl, fl);  // 1 / (product of this lane's denominators)
+    uint32_t last = (pairs - 1 - l) / a.lanes;  // the lane's last pair is l + last * lanes
+    if (last >= AFF_A) last = AFF_A - 1;
+#pragma unroll 1
+    for (uint32_t s = last + 1; s-- > 0;) {
+        const uint32_t p = l + s * a.lanes;
+        uint32_t n1, n2;
+        const Affine* p1 = aff_operand<FIRST>(so, table, a.n_table, prev, 2 * p, n1);
+        const Affine* p2 = aff_operand<FIRST>(so, table, a.n_table, prev, 2 * p + 1, n2);
+        const Fe x1 = p1 ? ld_fe_g(&p1->x) : fe_zero(), x2 = p2 ? ld_fe_g(&p2->x) : fe_zero();
+        F9 d;
+        const uint32_t kind = aff_classify(p1, p2, n1, n2, x1, x2, d);
+        Fe ox = fe_zero(), oy = fe_zero();
+        if (kind <= AFF_DBL) {
+            const F9 inv = Fq9::mul(u, ld_f9_soa(a.pre, (size_t)AFF_A * nl, (size_t)s * nl + fl));  // 1 / d
+            u = Fq9::mul(u, d);
+            const F9 fx1 = f9_unpack(x1), fx2 = f9_unpack(x2);
+            F9 fy1 = f9_unpack(ld_fe_g(&p1->y));
+            if (n1) fy1 = f9_neg(fy1);
+            F9 num;
+            if (__builtin_expect(kind == AFF_DBL, 0)) {
+                const F9 xx = Fq9::sqr(fx1);
+                num = f9_norm(f9_add(f9_add(xx, xx), xx));
+            } else {
+                F9 fy2 = f9_unpack(ld_fe_g(&p2->y));
+                if (n2) fy2 = f9_neg(fy2);
+                num = f9_sub(fy2, fy1);  // (limb magnitudes < 2^30: allowed on one side of a product)
+            }
+            const F9 lam = Fq9::mul(inv, num);
+            const F9 x3 = f9_norm(f9_sub(f9_sub(Fq9::sqr(lam), fx1), fx2));
+            const F9 y3 = f9_norm(f9_sub(Fq9::mul(lam, f9_sub(fx1, x3)), fy1));
+            ox = f9_reduce_pack<Fq9Params>(x3);
+            oy = f9_reduce_pack<Fq9Params>(y3);
+        } else if (kind == AFF_COPY1 || kind == AFF_COPY2) {
+            const Affine* src = kind == AFF_COPY1 ? p1 : p2;
+            const uint32_t neg = kind == AFF_COPY1 ? n1 : n2;
+            ox = kind == AFF_COPY1 ? x1 : x2;
+            oy = ld_fe_g(&src->y);
+            if (neg) oy = f9_reduce_pack<Fq9Params>(f9_neg(f9_unpack(oy)));  // (q - y; y != 0)
+        }
+        st_fe_g(&out[p].x, ox);
+        st_fe_g(&out[p].y, oy);
+    }
+}
+
+// lane j folds the lane totals j, j + n2, j + 2 n2, ... (coalesced): prefix before each -> pfx[], strip total -> val2[]
+__global__ __launch_bounds__(256) void aff_inv_up_kernel(const int32_t* __restrict__ val, int32_t* __restrict__ pfx, size_t n1,
+                                                         int32_t* __restrict__ val2, size_t n2) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n2) return;
+    F9 acc = Fq9Params::one();
+#pragma unroll 1
+    for (size_t e = j; e < n1; e += n2) {
+        st_f9_soa(pfx, n1, e, acc);
+        acc = Fq9::mul(acc, ld_f9_soa(val, n1, e));
+    }
+    st_f9_soa(val2, n2, j, acc);
+}
+// ... and back: val2[j] holds 1 / (strip total); val[e] := 1 / val[e]
+__global__ __launch_bounds__(256) void aff_inv_down_kernel(int32_t* __restrict__ val, const int32_t* __restrict__ pfx, size_t n1,
+                                                           const int32_t* __restrict__ val2, size_t n2) {
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n2) return;
+    F9 u = ld_f9_soa(val2, n2, j);
+    if (j >= n1) return;
+    size_t e = j + ((n1 - 1 - j) / n2) * n2;  // the strip's last element
+#pragma unroll 1
+    for (;; e -= n2) {
+        const F9 v = ld_f9_soa(val, n1, e);
+        st_f9_soa(val, n1, e, Fq9::mul(u, ld_f9_soa(pfx, n1, e)));
+        u = Fq9::mul(u, v);
+        if (e < n2) break;
+    }
+}
+
+// ONE workgroup: val2[0 .. n2) := their inverses.  Lane t folds the strip t, t + 1024, ...; the lane totals are scanned
+// both ways through LDS (Hillis-Steele, ten steps each); lane 0 inverts the grand total; every lane gets
+// 1 / total_t = (1 / T) * (product of the lanes before) * (product of the lanes after), and walks its strip back.
+__global__ __launch_bounds__(AFF_TOP) void aff_inv_top_kernel(int32_t* __restrict__ val2, int32_t* __restrict__ pfx2, size_t n2) {
+    __shared__ F9 sh[AFF_TOP];
+    __shared__ F9 tinv;
+    const uint32_t t = threadIdx.x;
+    F9 acc = Fq9Params::one();
+#pragma unroll 1
+    for (size_t e = t; e < n2; e += AFF_TOP) {
+        st_f9_soa(pfx2, n2, e, acc);
+        acc = Fq9::mul(acc, ld_f9_soa(val2, n2, e));
+    }
+    auto scan = [&](bool up) {  // inclusive product scan over the lanes, towards higher (up) or lower lane numbers
+        sh[t] = acc;
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t o = 1; o < AFF_TOP; o <<= 1) {
+            const bool has = up ? t >= o : t + o < AFF_TOP;
+            F9 v;
+            if (has) v = sh[up ? t - o : t + o];
+            __syncthreads();
+            if (has) sh[t] = Fq9::mul(sh[t], v);
+            __syncthreads();
+        }
+    };
+    scan(true);
+    const F9 before = t ? sh[t - 1] : Fq9Params::one();
+    if (t == AFF_TOP - 1) {
+        // T is x * 2^261; Fq::inv of its packed form is x^-1 * 2^251 (it reads a Montgomery-2^256 residue); k271 puts
+        // the 2^261 back.  (No denominator is 0 mod q, so T is not.)
+        const Fe inv8 = Fq::inv(f9_reduce_pack<Fq9Params>(sh[t]));
+        tinv = Fq9::mul(f9_unpack(inv8), Fq9Params::k271());
+    }
+    __syncthreads();
+    scan(false);
+    const F9 after = t + 1 < AFF_TOP ? sh[t + 1] : Fq9Params::one();
+    F9 u = Fq9::mul(Fq9::mul(tinv, before), after);  // 1 / (this lane's strip total)
+    if (t >= n2) return;
+    size_t e = t + ((n2 - 1 - t) / AFF_TOP) * AFF_TOP;
+#pragma unroll 1
+    for (;; e -= AFF_TOP) {
+        const F9 v = ld_f9_soa(val2, n2, e);
+        st_f9_soa(val2, n2, e, Fq9::mul(u, ld_f9_soa(pfx2, n2, e)));
+        u = Fq9::mul(u, v);
+        if (e < AFF_TOP) break;
+    }
 }
 
 // One lane per task: at most K points of one bucket, mixed adds in XYZZ on nine 29-bit limbs (field9.h:
@@ -463,14 +732,17 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __rest
 // PAIR (the latency configuration): two lanes per task, the running sum split between them (field9.h
 // `xmadd_pair`): half the dependent products per point, for a launch that does not fill the chip alone.
 // (132 VGPRs: three waves per SIMD; forced to 128 for four -- 20 B of scratch -- it measured the same, 0.751 ms/proof)
-template <bool PAIR>
+// AFF (throughput form after R rounds of batched-affine pre-reduction, below): a task's summands are the affine points the
+// last round left -- bucket k's at [tot[k] >> R, tot[k + 1] >> R) of `pts` -- read in sequence, not gathered.
+template <bool PAIR, bool AFF = false>
 __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     const Affine* __restrict__ table_a, const Affine* __restrict__ table_b, uint32_t split, uint32_t n_table,
     uint32_t c, uint32_t windows, uint32_t n,
     const uint32_t* __restrict__ tot, const uint32_t* __restrict__ toff, const uint32_t* __restrict__ ttotal,
     const uint32_t* __restrict__ sorted, uint32_t max_tasks, XYZZ9* __restrict__ partial,
     const Affine* __restrict__ run_a, const Affine* __restrict__ run_b, uint64_t run_mask, uint32_t per,
-    const uint32_t* __restrict__ stoff, const uint32_t* __restrict__ sbucket) {
+    const uint32_t* __restrict__ stoff, const uint32_t* __restrict__ sbucket, size_t cap, uint32_t R,
+    const Affine* __restrict__ pts) {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t t = PAIR ? lane >> 1 : lane;
     const bool role_a = !PAIR || (lane & 1u) == 0;
@@ -497,13 +769,13 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
     // bucket k's entries are contiguous: [tot[k], tot[k+1])  (exclusive entry offsets); its nt = ceil(total / K)
     // tasks share them EVENLY (sizes differ by one at most): a wave's lanes then run nearly the same number of
     // additions, where a full / full / ... / remainder split leaves the remainder's lane idle for most of the loop
-    const uint32_t first = tot[(size_t)b * (nb + 2) + k];
-    const uint32_t total = tot[(size_t)b * (nb + 2) + k + 1] - first;
+    const uint32_t first = tot[(size_t)b * (nb + 2) + k] >> R;
+    const uint32_t total = (tot[(size_t)b * (nb + 2) + k + 1] >> R) - first;
     const uint32_t nt = to[k + 1] - to[k];
     const uint32_t share = total / nt, extra = total % nt;
     const uint32_t start = first + j * share + (j < extra ? j : extra);
     const uint32_t len = share + (j < extra ? 1u : 0u);
-    const uint32_t* so = sorted + (size_t)b * windows * n + start;
+    const uint32_t* so = sorted + (size_t)b * cap + start;
     XYZZ9* dst = partial + (size_t)b * max_tasks + to[k] + j;  // (the bucket-order slot the reduction reads)
     bool inf = true;
     if constexpr (PAIR) {
@@ -527,6 +799,16 @@ __global__ __launch_bounds__(256) void msm_accumulate_kernel(
             st_f9(&dst->y, acc.m);
             st_f9(&dst->zzz, acc.z);
         }
+    } else if constexpr (AFF) {
+        XYZZ9 acc;
+        const Affine* src = pts + (size_t)b * (cap >> R) + start;
+        for (uint32_t e = 0; e < len; e++) {
+            const F9 qx = f9_unpack(ld_fe_g(&src[e].x));
+            const F9 qy = f9_unpack(ld_fe_g(&src[e].y));
+            if (f9_limbs_zero(qx) && f9_limbs_zero(qy)) continue;  // (a pad pair, or a pair that cancelled)
+            xyzz9_madd(acc, inf, qx, qy);
+        }
+        st_xyzz9(dst, inf ? xyzz9_identity() : acc);
     } else {
         XYZZ9 acc;
         for (uint32_t e = 0; e < len; e++) {
@@ -1352,7 +1634,15 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
                                          : (k_env >= 4 && k_env <= 120 ? (uint32_t)k_env : MSM_K_THROUGHPUT);
     const uint64_t entries = (uint64_t)N * W;
     ZG_REQUIRE(entries < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
-    uint64_t mt = entries / MSM_K + (entries < nb ? entries : nb) + 1;
+    // R rounds of batched-affine pre-reduction before the XYZZ chains (throughput form only; ZG_MSM_AFFINE): every bucket's
+    // entry range is padded to a multiple of 2^R, `cap` entries per vector at most, cap >> R points left for the tasks
+    const int aff_env = knob(K_MSM_AFFINE);
+    const uint32_t R = ctx->msm_pair ? 0u : aff_env >= 0 && aff_env <= 4 ? (uint32_t)aff_env : MSM_AFFINE_ROUNDS;
+    const uint64_t padm = (1ull << R) - 1ull;
+    const size_t cap = (size_t)((entries + (uint64_t)nb * padm + padm) & ~padm);
+    ZG_REQUIRE(cap < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: n*windows too large");
+    const uint64_t left = cap >> R;  // summands per vector after the rounds, at most
+    uint64_t mt = left / MSM_K + (left < nb ? left : nb) + 1;
     const uint32_t max_tasks = (uint32_t)mt;
     // buckets per reduction block: 256 in the throughput configuration; the latency configuration spreads
     // the same buckets over more, smaller workgroups (one wave per SIMD, shorter scans) while the block
@@ -1390,8 +1680,18 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     uint32_t* ttotal = ws.get<uint32_t>(B);
     uint32_t* stoff = ws.get<uint32_t>((size_t)B * (nb + 2));
     uint32_t* sbucket = ws.get<uint32_t>((size_t)B * (nb + 1));
-    uint32_t* sorted = ws.get<uint32_t>((size_t)B * entries);
+    uint32_t* sorted = ws.get<uint32_t>((size_t)B * cap);
     XYZZ9* partial = ws.get<XYZZ9>((size_t)B * max_tasks);
+    // batched-affine rounds: points of the odd rounds, of the even rounds, the per-pair prefixes, the two levels of totals
+    const uint32_t aff_lanes = R ? (uint32_t)((((cap >> 1) + AFF_A - 1) / AFF_A + 255) / 256 * 256) : 0u;  // round 1: the widest
+    const size_t aff_n1 = (size_t)B * aff_lanes, aff_n2 = (aff_n1 + AFF_S - 1) / AFF_S;
+    Affine* pts_odd = R >= 1 ? ws.get<Affine>((size_t)B * (cap >> 1)) : nullptr;
+    Affine* pts_even = R >= 2 ? ws.get<Affine>((size_t)B * (cap >> 2)) : nullptr;
+    int32_t* aff_pre = R ? ws.get<int32_t>((size_t)9 * AFF_A * aff_n1) : nullptr;
+    int32_t* aff_val = R ? ws.get<int32_t>((size_t)9 * aff_n1) : nullptr;
+    int32_t* aff_pfx = R ? ws.get<int32_t>((size_t)9 * aff_n1) : nullptr;
+    int32_t* aff_val2 = R ? ws.get<int32_t>((size_t)9 * aff_n2) : nullptr;
+    int32_t* aff_pfx2 = R ? ws.get<int32_t>((size_t)9 * aff_n2) : nullptr;
     XYZZ9* blk_w = ws.get<XYZZ9>((size_t)B * nblk);
     XYZZ9* tsum = ws.get<XYZZ9>(B);  // (odd-digit buckets: the vectors' plain bucket sums, msm_bucket_sum_kernel)
     XYZZ9* blk_p = ws.get<XYZZ9>((size_t)B * nblk);
@@ -1441,19 +1741,54 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_LAUNCH(ctx, "msm_hist", hist_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", scan_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
-              ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket);
-    ZG_LAUNCH(ctx, "msm_scatter", scat_bytes, msm_scatter_kernel, dim3((N + 255) / 256, W, B), dim3(256), 0, dig, N, c, W,
-              off, slot, sorted, naf);
+              ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket, R, sorted, cap);
+    {
+        const uint32_t chunks = (N + 255) / 256;
+        const uint64_t blocks = 8ull * ((B + 7) / 8) * chunks * W;
+        ZG_REQUIRE(blocks < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: scatter grid of %llu blocks", (unsigned long long)blocks);
+        ZG_LAUNCH(ctx, "msm_scatter", scat_bytes, msm_scatter_kernel, dim3((uint32_t)blocks), dim3(256), 0, dig, N, c, W, off, slot,
+                  sorted, naf, cap, B, chunks);
+    }
+    const Affine* aff_pts = nullptr;
+    for (uint32_t r = 1; r <= R; r++) {
+        const size_t pairs = cap >> r;  // per vector, at most (the kernels read the vector's own count)
+        AffArgs a;
+        a.table_a = bases->table; a.table_b = bases_b ? bases_b->table : bases->table; a.run_a = run_a; a.run_b = run_b;
+        a.split = (uint32_t)split; a.n_table = (uint32_t)bases->n; a.per = (uint32_t)per; a.nb = nb; a.run_mask = run_mask;
+        a.tot = tot; a.sorted = sorted; a.prev = aff_pts; a.out = (r & 1u) ? pts_odd : pts_even; a.cap = cap; a.r = r;
+        a.lanes = (uint32_t)(((pairs + AFF_A - 1) / AFF_A + 255) / 256 * 256);
+        a.pre = aff_pre; a.val = aff_val;
+        const size_t n1 = (size_t)B * a.lanes, n2 = (n1 + AFF_S - 1) / AFF_S;
+        const double pr = (double)B * (double)pairs;
+        const dim3 g(a.lanes / 256, B);
+        if (r == 1) ZG_LAUNCH(ctx, "msm_aff_prefix", pr * (8.0 + 64.0 + 36.0), aff_prefix_kernel<true>, g, dim3(256), 0, a);
+        else ZG_LAUNCH(ctx, "msm_aff_prefix", pr * (64.0 + 36.0), aff_prefix_kernel<false>, g, dim3(256), 0, a);
+        ZG_LAUNCH(ctx, "msm_aff_invert", (double)n1 * 72.0, aff_inv_up_kernel, dim3((uint32_t)((n2 + 255) / 256)), dim3(256), 0, aff_val,
+                  aff_pfx, n1, aff_val2, n2);
+        ZG_LAUNCH(ctx, "msm_aff_invert", (double)n2 * 108.0, aff_inv_top_kernel, dim3(1), dim3(AFF_TOP), 0, aff_val2, aff_pfx2, n2);
+        ZG_LAUNCH(ctx, "msm_aff_invert", (double)n1 * 108.0, aff_inv_down_kernel, dim3((uint32_t)((n2 + 255) / 256)), dim3(256), 0, aff_val,
+                  aff_pfx, n1, aff_val2, n2);
+        if (r == 1) ZG_LAUNCH(ctx, "msm_aff_apply", pr * (8.0 + 128.0 + 36.0 + 64.0), aff_apply_kernel<true>, g, dim3(256), 0, a);
+        else ZG_LAUNCH(ctx, "msm_aff_apply", pr * (128.0 + 36.0 + 64.0), aff_apply_kernel<false>, g, dim3(256), 0, a);
+        aff_pts = a.out;
+    }
     // (lane pairs per task -- half the dependent products per point -- while the launch is latency-bound; from n = 2^16
     //  on it fills the chip several times over and the pair form's exchanges are pure cost)
     if (ctx->msm_pair && N < (1u << 16)) {
         ZG_LAUNCH_U(ctx, "msm_accumulate", msm_bytes, msm_bytes, msm_accumulate_kernel<true>, dim3((2 * max_tasks + 255) / 256, B), dim3(256),
                   0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket, cap, 0u,
+                  (const Affine*)nullptr);
+    } else if (R) {
+        ZG_LAUNCH_U(ctx, "msm_accumulate", msm_bytes, msm_bytes, (msm_accumulate_kernel<false, true>), dim3((max_tasks + 255) / 256, B),
+                    dim3(256), 0, bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N,
+                    tot, toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket, cap, R,
+                    aff_pts);
     } else {
         ZG_LAUNCH_U(ctx, "msm_accumulate", msm_bytes, msm_bytes, msm_accumulate_kernel<false>, dim3((max_tasks + 255) / 256, B), dim3(256), 0,
                   bases->table, bases_b ? bases_b->table : bases->table, (uint32_t)split, (uint32_t)bases->n, c, W, N, tot,
-                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket);
+                  toff, ttotal, sorted, max_tasks, partial, run_a, run_b, run_mask, (uint32_t)per, stoff, sbucket, cap, 0u,
+                  (const Affine*)nullptr);
     }
     // hot buckets are few (repeated or tiny scalars put one or two per window at most): a flat grid strides over the
     // launch's (vector, hot bucket) pairs and leaves at once when there are none

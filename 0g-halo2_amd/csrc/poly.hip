@@ -628,14 +628,20 @@ static int grand_product_blocks(zg_ctx* ctx, const Fe* num, const Fe* den, const
               locd, totn, totd, n, nblk);
     // latency configuration: the host inverts the totals (one shared inversion) between the two launches
     const bool host_inv = ctx->msm_pair && batch <= FESET_MAX && batch == per;
+    // (... which the totals kernel writes straight into the context's pinned, mapped host buffer: no copy command between
+    //  the kernel and the host's wait)
+    Fe* h = nullptr;
+    void* h_dev = nullptr;
+    if (host_inv) {
+        ZG_TRY(pinned_reserve(ctx, 4096));
+        h = reinterpret_cast<Fe*>(ctx->pinned);
+        ZG_HIP(hipHostGetDevicePointer(&h_dev, ctx->pinned, 0));
+    }
     ZG_LAUNCH(ctx, "grand_product_totals", (double)batch * nblk * 128, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
-              tinv, zlast, n, nblk, last, host_inv ? 1u : 0u);
+              host_inv ? reinterpret_cast<Fe*>(h_dev) : tinv, zlast, n, nblk, last, host_inv ? 1u : 0u);
     FeSet inv_set;
     memset(&inv_set, 0, sizeof(inv_set));
     if (host_inv) {
-        ZG_TRY(pinned_reserve(ctx, 4096));
-        Fe* h = reinterpret_cast<Fe*>(ctx->pinned);
-        ZG_HIP(hipMemcpyAsync(h, tinv, batch * sizeof(Fe), hipMemcpyDeviceToHost, ctx->stream));
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         // Montgomery's trick: prefix products, one inversion, walk back (a zero total inverts to zero, as Fr::inv does)
         Fe pre[FESET_MAX], acc = Fr::one();

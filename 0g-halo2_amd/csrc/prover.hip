@@ -230,6 +230,7 @@ Fe rotate_omega(const PkDev& k, const Fe& x, int32_t rot) {
     return Fr::mul(x, w);
 }
 
+constexpr int LAT_PULL_DEFAULT = 1;  // (ZG_LAT_PULL: a lone proof's small uploads by a one-wave kernel instead of a copy command)
 // Small host->device transfers go through a pinned staging arena: hipMemcpyAsync from pageable memory
 // blocks the calling thread until the stream has drained up to the copy, which serialises host and
 // GPU inside a proof and throttles concurrent proof streams.  The arena is a bump allocator reset at
@@ -253,8 +254,20 @@ int h2d_list(zg_prover* p, uint32_t* d_dst, const std::vector<uint32_t>& list) {
     held = list;
     return ZG_OK;
 }
+// (a lone proof's version of a small upload: ONE wave reads the staged bytes through the device's view of the pinned arena
+//  and writes them where they go -- a kernel dispatch instead of a copy command behind every transcript step)
+__global__ void pull_kernel(const uint4* __restrict__ src_mapped, uint4* __restrict__ dst, uint32_t n16) {
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src_mapped[i];
+}
 int h2d(zg_prover* p, void* d_dst, const void* src, size_t bytes) {
     const void* s = stage(p, src, bytes);
+    const int pull = knob(K_LAT_PULL);
+    if (s && p->use_side && (pull < 0 ? LAT_PULL_DEFAULT : pull) != 0 && bytes % 16 == 0 && bytes <= (1u << 16) && ((uintptr_t)d_dst & 15u) == 0) {
+        const uint4* dev_view = reinterpret_cast<const uint4*>((const char*)p->pinned_dev + ((const char*)s - (const char*)p->pinned));
+        ZG_LAUNCH(p->ctx, "pull", (double)bytes * 2, pull_kernel, dim3(1), dim3(256), 0, dev_view, (uint4*)d_dst, (uint32_t)(bytes / 16));
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
     ZG_HIP(hipMemcpyAsync(d_dst, s ? s : src, bytes, hipMemcpyHostToDevice, p->ctx->stream));
     if (!s) ZG_HIP(hipStreamSynchronize(p->ctx->stream));
     return ZG_OK;
@@ -1127,6 +1140,613 @@ struct TickLog {
 #define ZG_TICK(l) ((void)0)
 #endif
 
+// One lock-step batch of create_proofs (upstream plonk/prover.rs, `create_proof`): the state its phases share, and ONE member
+// function per phase -- round 3 had all of it in a single 510-line function.  A phase queues its kernels
+// on the prover's stream(s), waits for what the transcript needs (commitments as points, evaluations), feeds every proof's
+// EvmTranscript and leaves the next challenges in p->hpc[] / on the device (upload_consts).  Order and contents of the phases
+// are upstream's:
+//   load_inputs        instance + advice columns in place, blinding rows, the vanishing argument's random polynomial
+//   commit_advice      advice commitments                                   -> theta
+//   commit_permuted    lookup::commit_permuted (+ the random polynomial)    -> beta, gamma
+//   commit_products    permutation::commit, lookup::commit_product          -> y
+//   quotient           evaluate_h, h(X) in pieces, their commitments        -> x
+//   evaluations        eval_polynomial at x omega^rot                       -> v
+//   openings           ProverGWC::create_proof
+//   finish             proof bytes and statuses out
+// A nonzero return leaves p->in_flight set: the next batch drains the streams before it reuses the slots.
+struct ProveBatch {
+    using clk = std::chrono::steady_clock;
+    // ---- the call
+    zg_prover* p;
+    const zg_fr* const* advice_host;
+    void* const* advice_dev;
+    const zg_fr* const* instance;
+    size_t instance_len;
+    const uint8_t* keys;
+    uint8_t* const* proofs;
+    size_t proof_cap;
+    size_t* proof_lens;
+    int* statuses;
+    // ---- shapes
+    const PkDev& pk;
+    zg_ctx* ctx;
+    hipStream_t st;
+    uint32_t nb, n, k, ek, bf, usable, A, I, P, NL, S, Q;
+    bool hat;
+    bool split;         // extended-domain parts of this proof: the split pair in the throughput configuration, the single coset otherwise
+    bool phase_cosets;  // the coset forms of a phase's columns: on the side stream while that phase's commitments run (latency
+                        // form), or all at once before evaluate_h (throughput form)
+    uint32_t dlo, dhi;
+    size_t pp_bs, adv_bs, inst_bs, perm_bs, zs_bs, pw_bs, wp_bs;  // strides between consecutive proofs
+    // side stream: coefficient / coset forms of committed columns are computed there while the main stream runs the
+    // commitment MSM (p->use_side == false: everything stays on the main stream -- the throughput configuration, where other
+    // proofs in flight fill the gaps and every extra HIP stream costs a hardware queue)
+    zg_ctx* sx;
+    hipStream_t ss;
+    double parts_en, ext_unit;  // (profile charges: SURVEY.md 8d counts one coeff_to_extended as (n + 2^ext_k) * 32 B whatever parts it is computed on)
+    // ---- state carried from phase to phase
+    PolySet polys;
+    std::vector<EvmTranscript> tr;
+    std::vector<int> status;
+    std::vector<Jac> pts;
+    Fe* random_row = nullptr;  // (proof 0's; proof b's is perm_bs further)
+    Fe* adv = nullptr;
+    Cols base_cols;
+    std::vector<Jac> random_commit;
+    bool have_random = false;
+    struct Q1 { uint32_t poly, slot; };
+    std::vector<int32_t> rots;  // distinct opening points, in any order (the powers table is indexed by slot)
+    std::vector<Q1> evq;
+    size_t e_fixed = 0, e_random = 0, e_sigma = 0, e_pz = 0, e_lk = 0, e_written = 0, e_h = 0;
+    uint32_t npoints = 0;
+    uint32_t* d_hlist = nullptr;
+    const Fe* ev_all = nullptr;
+    clk::time_point t_start, t_prev;
+#ifdef ZG_TICKS
+    TickLog ticks;
+#endif
+
+    ProveBatch(zg_prover* p_, size_t count, const zg_fr* const* advice_host_, void* const* advice_dev_, const zg_fr* const* instance_,
+               size_t instance_len_, const uint8_t* keys_, uint8_t* const* proofs_, size_t proof_cap_, size_t* proof_lens_, int* statuses_)
+        : p(p_), advice_host(advice_host_), advice_dev(advice_dev_), instance(instance_), instance_len(instance_len_), keys(keys_),
+          proofs(proofs_), proof_cap(proof_cap_), proof_lens(proof_lens_), statuses(statuses_), pk(*p_->pk), ctx(p_->ctx),
+          st(p_->ctx->stream), nb((uint32_t)count), tr(count), status(count, ZG_OK) {
+        n = pk.n; k = pk.k; ek = pk.ext_k; bf = pk.bf; usable = pk.usable;
+        A = pk.A; I = pk.I; P = pk.P; NL = pk.NL; S = pk.sets; Q = pk.qpd;
+        hat = pk.hat;
+        split = pk.nparts == 3 && (!p->use_side || p->lat_split);
+        phase_cosets = p->use_side || !split;
+        dlo = split ? 1u : 0u;
+        dhi = split ? 3u : 1u;
+        pp_bs = (size_t)p->npp * n; adv_bs = (size_t)A * n; inst_bs = (size_t)I * n; perm_bs = (size_t)(2 * NL + 1) * n;
+        zs_bs = (size_t)(S + NL + 1) * n; pw_bs = (size_t)p->max_points * n; wp_bs = (size_t)2 * p->max_points * n;
+        polys.sh = pk.sh_polys; polys.pp = p->pp; polys.nsh = p->nsh; polys.n = n; polys.pp_bs = pp_bs;
+        sx = p->use_side ? ctx->side : ctx;
+        ss = sx->stream;
+        parts_en = 0.0;
+        for (uint32_t di = dlo; di < dhi; di++) parts_en += (double)pk.dom[di].en;
+        ext_unit = ((double)n + (double)((size_t)1 << ek)) * 32.0;
+        t_start = t_prev = clk::now();
+    }
+
+    Fe* pp_at(uint32_t ix) const { return p->pp + (size_t)(ix - p->nsh) * n; }  // proof 0's polynomial ix (>= nsh)
+    void lap(int slot) {
+        auto now = clk::now();
+        p->phase_ms[slot] = std::chrono::duration<double, std::milli>(now - t_prev).count();
+        t_prev = now;
+    }
+    int fork() {  // side stream continues after everything queued on the main stream so far
+        if (!p->use_side) return ZG_OK;
+        ZG_HIP(hipEventRecord(p->ev_fork, st));
+        ZG_HIP(hipStreamWaitEvent(ss, p->ev_fork, 0));
+        return ZG_OK;
+    }
+    int join() {  // main stream continues after everything queued on the side stream so far
+        if (!p->use_side) return ZG_OK;
+        ZG_HIP(hipEventRecord(p->ev_join, ss));
+        ZG_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
+        return ZG_OK;
+    }
+    // two-level layouts of the transforms: `per` arrays per proof
+    static Grouping grouping(uint32_t per, size_t in_outer, size_t out_outer) {
+        Grouping g;
+        g.per = per; g.in_outer = in_outer; g.out_outer = out_outer;
+        return g;
+    }
+    // coefficient forms (ix0 .. ix0 + per) of every proof -> their slabs on each part of the extended domain
+    int to_cosets(zg_ctx* c, uint32_t ix0, uint32_t per) {
+        for (uint32_t di = dlo; di < dhi; di++) {
+            const PkDev::Dom& d = pk.dom[di];
+            const Grouping g = grouping(per, pp_bs, (size_t)p->ncos * d.en);
+            c->unit_next = (double)nb * per * ext_unit * ((double)d.en / parts_en);
+            ZG_TRY(coeff_to_coset_dev(c, pp_at(ix0), n, n, p->dbuf[di].cos + (size_t)(ix0 - p->ix_adv) * d.en, d.en, (size_t)nb * per,
+                                      d.ek, hat, d.zpow, &g));
+        }
+        return ZG_OK;
+    }
+
+    int run() {
+        begin();
+        ZG_TRY(load_inputs());
+        ZG_TRY(commit_advice());
+        ZG_TRY(commit_permuted());
+        ZG_TRY(commit_products());
+        ZG_TRY(quotient());
+        ZG_TRY(evaluations());
+        ZG_TRY(openings());
+        return finish();
+    }
+
+    void begin() {
+        p->have_last = false;
+        if (p->in_flight) {  // the previous batch left through an error return: drain what it queued before its staging
+            (void)hipStreamSynchronize(st);  // arena and slots are reused
+            if (ctx->side) (void)hipStreamSynchronize(ctx->side->stream);
+        }
+        p->in_flight = true;
+        p->stage_off = p->pin_stage;
+    }
+
+    int load_inputs() {
+        // ---- advice columns into their slots
+        for (uint32_t b = 0; b < nb; b++) {
+            Fe* slot = p->adv_val + b * adv_bs;
+            if (!A) break;
+            if (advice_host && advice_host[b]) {
+                ZG_HIP(hipMemcpyAsync(slot, advice_host[b], adv_bs * 32, hipMemcpyHostToDevice, st));
+            } else if (advice_dev && advice_dev[b] && advice_dev[b] != (void*)slot) {
+                ZG_HIP(hipMemcpyAsync(slot, advice_dev[b], adv_bs * 32, hipMemcpyDeviceToDevice, st));
+            }
+        }
+
+        // ---- vk + instance values into the transcripts; instance polynomials
+        for (uint32_t b = 0; b < nb; b++) {
+            memset(&p->hpc[b], 0, sizeof(ProofConst));
+            memcpy(p->hpc[b].key, keys + 32 * (size_t)b, 32);
+            tr[b].common_scalar(pk.vk_repr);
+        }
+        ZG_TRY(upload_consts(p, nb));
+        // vanishing::Argument::commit's random polynomial depends on no challenge: generate it now and
+        // commit it inside the permuted-lookup batch (coefficient basis `g` next to `g_lagrange` vectors)
+        random_row = p->perm + (size_t)(2 * NL) * n;  // (proof 0's; proof b's is perm_bs further)
+        // (the same launch draws the blinding rows of the advice columns: commit_lagrange's input below)
+        adv = p->adv_val;
+        ZG_TRY(poly_random_and_blind(ctx, p->d_pc, nb, random_row, perm_bs, pp_at(p->ix_random), pp_bs, n, TAG_RANDOM_POLY, adv, adv_bs,
+                                     n, A, usable, bf + 1, TAG_ADVICE_BLIND));
+        if (I) {
+            for (uint32_t b = 0; b < nb; b++) {
+                Fe* iv = p->inst_val + b * inst_bs;
+                if (p->inst_filled[b] > instance_len) ZG_HIP(hipMemsetAsync(iv, 0, inst_bs * 32, st));  // (zeroed at create)
+                p->inst_filled[b] = instance_len;
+                for (uint32_t c = 0; c < I; c++) {
+                    const zg_fr* src = instance_len ? instance[b] + (size_t)c * instance_len : nullptr;
+                    for (size_t i = 0; i < instance_len; i++) tr[b].common_scalar(to_fe(&src[i]));
+                    if (instance_len) ZG_TRY(h2d(p, iv + (size_t)c * n, src, instance_len * 32));
+                }
+            }
+        }
+
+        return ZG_OK;
+    }
+
+    int commit_advice() {
+        // ---- advice: commit (Lagrange basis)
+        ZG_TRY(fork());
+        if (I) {
+            const Grouping g = grouping(I, inst_bs, pp_bs);
+            ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, pp_at(p->ix_inst), n, (size_t)nb * I, k, pk.omega_inv, &pk.ifft_div, &g));
+            if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_inst, I));
+        }
+        if (A) {
+            ZG_TRY(commit(p, p->gl, nullptr, A, adv, n, A, adv_bs, (size_t)nb * A, 0));
+            const Grouping g = grouping(A, adv_bs, pp_bs);
+            ZG_TRY(ntt_batch_to_dev(sx, adv, pp_at(p->ix_adv), n, (size_t)nb * A, k, pk.omega_inv, &pk.ifft_div, &g));
+            if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_adv, A));
+            ZG_TICK("advice: queued");
+            ZG_TRY(wait_points(p, (size_t)nb * A, pts));
+            ZG_TICK("advice: points on the host");
+            for (uint32_t b = 0; b < nb; b++)
+                for (uint32_t c = 0; c < A; c++) tr[b].write_point(pts[(size_t)b * A + c]);
+        }
+        for (uint32_t b = 0; b < nb; b++) p->hpc[b].theta = tr[b].squeeze();
+        ZG_TICK("theta");
+        ZG_TRY(upload_consts(p, nb));
+        ZG_TICK("theta uploaded");
+        lap(0);
+
+        base_cols.fixed = pk.fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
+        base_cols.log_size = k; base_cols.rot_scale = 1;
+        base_cols.adv_bs = adv_bs; base_cols.inst_bs = inst_bs;
+
+        return ZG_OK;
+    }
+
+    int commit_permuted() {
+        // ---- lookups: commit_permuted (+ the random polynomial's commitment)
+        random_commit.resize(nb);
+        have_random = false;
+        if (NL) {
+            // permute_expression_pair on the device: canonical keys (written by the compression kernel itself, with
+            // the sentinel padding), bitonic sort of inputs and tables, scan-based construction of s' (sort.hip).
+            // raw rows [0, m) = inputs -> a', [m, 2m) = tables, m = nb * NL, row b * NL + l = lookup l of proof b.
+            const uint32_t m = nb * NL;
+            Fe *raw_in = p->raw, *raw_tab = p->raw + (size_t)m * n;
+            uint32_t* d_err = p->sort_u32 + (size_t)2 * m * n + 2 * m;  // behind permute_pairs' scratch: zeroed by the same fill
+            ZG_TRY(poly_lookup_compress(ctx, pk.dc, base_cols, p->d_pc, nb, p->cin, p->ctab, n, raw_in, raw_tab, usable));
+            auto t_sort = clk::now();
+            ZG_TRY(poly_sort_keys(ctx, p->raw, n, 2 * m));
+            ZG_TRY(poly_permute_pairs(ctx, raw_in, raw_tab, p->sraw, n, usable, m, p->sort_u32, p->sort_fe, d_err));
+            // perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form) on the usable rows, then the blinding tail
+            // (blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j)
+            ZG_TRY(poly_permuted_finish(ctx, p->d_pc, nb, raw_in, p->sraw, p->perm, perm_bs, n, usable, bf + 1, NL, TAG_PERMUTED_INPUT,
+                                        TAG_PERMUTED_TABLE));
+            p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
+            ZG_TRY(fork());
+            // the lookups' error words leave on the side stream, beside the commitments (an event of their own)
+            uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
+            ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ss));
+            ZG_HIP(hipEventRecord(p->ev_err, ss));
+            // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
+            const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);  // (both or neither)
+            const uint64_t sorted_runs = cgl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
+            ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs, naf_gl_width(p)));
+            {
+                const Grouping g = grouping(2 * NL, perm_bs, pp_bs);
+                ZG_TRY(ntt_batch_to_dev(sx, p->perm, pp_at(p->ix_perm), n, (size_t)nb * 2 * NL, k, pk.omega_inv, &pk.ifft_div, &g));
+            }
+            if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_perm, 2 * NL));
+            ZG_TICK("permuted: queued");
+            ZG_TRY(wait_points(p, (size_t)nb * (2 * NL + 1), pts));
+            ZG_HIP(hipEventSynchronize(p->ev_err));
+            ZG_TICK("permuted: points on the host");
+            for (uint32_t b = 0; b < nb; b++) {
+                for (uint32_t l = 0; l < NL; l++)
+                    if (h_err[b * NL + l] && status[b] == ZG_OK) {
+                        set_error("zg_prover_prove: lookup %u of proof %u has an input outside its table (ConstraintSystemFailure)", l, b);
+                        status[b] = ZG_ERR_CONSTRAINT;
+                    }
+                const Jac* q = &pts[(size_t)b * (2 * NL + 1)];
+                for (uint32_t i = 0; i < 2 * NL; i++) tr[b].write_point(q[i]);
+                random_commit[b] = q[2 * NL];
+            }
+            have_random = true;
+            if (nb == 1 && status[0] != ZG_OK) {  // a lone proof stops here, as upstream's `?` does
+                (void)hipStreamSynchronize(ss);
+                (void)hipStreamSynchronize(st);
+                if (statuses) statuses[0] = status[0];
+                proof_lens[0] = 0;
+                p->in_flight = false;
+                return status[0];
+            }
+        }
+        for (uint32_t b = 0; b < nb; b++) {
+            p->hpc[b].beta = tr[b].squeeze();
+            p->hpc[b].gamma = tr[b].squeeze();
+        }
+        ZG_TICK("beta, gamma");
+        ZG_TRY(upload_consts(p, nb));
+        ZG_TICK("beta, gamma uploaded");
+        lap(1);
+
+        return ZG_OK;
+    }
+
+    int commit_products() {
+        // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
+        const uint32_t mb = S + NL;
+        if (S) ZG_TRY(poly_perm_terms(ctx, pk.dc, base_cols, p->d_pc, nb, pk.sigma_val, pk.omega_tw, p->num, p->den, mb, n));
+        // (a'_l / s'_l are interleaved in `perm`: two views with a stride of two columns)
+        ZG_TRY(poly_lookup_terms(ctx, p->d_pc, nb, p->cin, p->ctab, p->perm, p->perm + n, (size_t)2 * n, perm_bs, p->num, p->den, mb, S, n, NL));
+        if (mb) {
+            // all running products of the batch in one scan sequence; per proof the S permutation sets are chained
+            // through row n - bf - 1, the lookup products start from one
+            ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, nb * mb, S, n - bf - 1, mb, zs_bs));
+            ZG_TRY(poly_blind_rows2(ctx, p->d_pc, nb, p->zs, zs_bs, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf));  // (lz follows pz)
+            // The products stay constant wherever a row changes nothing (every padding row of the circuit): they are
+            // committed in the run form, sum_i (z_i - z_{i+1}) Q_i over the running sums Q of g_lagrange.
+            const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);
+            const uint64_t z_runs = cgl->run_table && mb < 64 ? (1ull << mb) - 1ull : 0ull;
+            ZG_TRY(fork());
+            uint32_t per = mb;
+            if (have_random) {
+                ZG_TRY(commit(p, cgl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs, naf_gl_width(p)));
+            } else {  // no lookups: the random polynomial rides here instead (row mb of zs)
+                for (uint32_t b = 0; b < nb; b++)
+                    ZG_HIP(hipMemcpyAsync(p->zs + b * zs_bs + (size_t)mb * n, random_row + b * perm_bs, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
+                per = mb + 1;
+                ZG_TRY(commit(p, cgl, cg, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs, naf_gl_width(p)));
+            }
+            {
+                const Grouping g = grouping(mb, zs_bs, pp_bs);
+                ZG_TRY(ntt_batch_to_dev(sx, p->zs, pp_at(p->ix_pz), n, (size_t)nb * mb, k, pk.omega_inv, &pk.ifft_div, &g));
+            }
+            if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_pz, mb));
+            ZG_TICK("products: queued");
+            ZG_TRY(wait_points(p, (size_t)nb * per, pts));
+            ZG_TICK("products: points on the host");
+            for (uint32_t b = 0; b < nb; b++) {
+                const Jac* q = &pts[(size_t)b * per];
+                for (uint32_t i = 0; i < mb; i++) tr[b].write_point(q[i]);
+                if (!have_random) random_commit[b] = q[mb];
+            }
+            have_random = true;
+        }
+        if (!have_random) {  // neither lookups nor permutation: commit the random polynomial on its own
+            ZG_TRY(commit(p, p->g, nullptr, 1, random_row, n, 1, perm_bs, nb, 0));
+            ZG_TRY(wait_points(p, nb, pts));
+            for (uint32_t b = 0; b < nb; b++) random_commit[b] = pts[b];
+        }
+        for (uint32_t b = 0; b < nb; b++) tr[b].write_point(random_commit[b]);
+        ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
+        for (uint32_t b = 0; b < nb; b++) evalh_consts(p->hpc[b], tr[b].squeeze(), hat, evalh_terms(pk));
+        ZG_TICK("y");
+        ZG_TRY(upload_consts(p, nb));
+        ZG_TICK("y uploaded");
+        lap(2);
+
+        return ZG_OK;
+    }
+
+    int quotient() {
+        // (throughput configuration: nothing overlaps, so every witness polynomial goes to its cosets here, in one batch per
+        //  coset, instead of phase by phase)
+        if (!phase_cosets) ZG_TRY(to_cosets(ctx, p->ix_adv, p->ncos));
+        // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
+        for (uint32_t di = dlo; di < dhi; di++) {
+            const EvalHArgs a = evalh_args(p, di);
+            ZG_TRY(poly_evaluate_h(ctx, a, pk.dom[di].en, nb, A + I + pk.F, (double)((size_t)1 << ek) * ((double)pk.dom[di].en / parts_en)));
+        }
+        p->have_last = true;
+        p->last_split = split;
+        p->last_nb = nb;
+        const double ext_inv_unit = (double)nb * 2.0 * (double)((size_t)1 << ek) * 32.0;  // (ext -> coeff, 2 * 8n * 32 B)
+        if (!split) {
+            ctx->unit_next = ext_inv_unit;
+            ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[0].h, ek, (size_t)Q * n, pp_at(p->ix_hpiece), hat, 1, nb, pk.dom[0].en, pp_bs));
+        } else {
+            // h = A + (X^L1 - c1) B:  A (degree < L1) from the first coset, where X^L1 = c1 = shift1^L1;  B (degree < L2)
+            // from the second, where X^L1 = c2 and X^L2 = e are constants too:  B = (h - A) / (c2 - c1) there, with A
+            // folded modulo X^L2 - e before it is evaluated on those L2 points.
+            const PkDev::Dom &d1 = pk.dom[1], &d2 = pk.dom[2];
+            const uint32_t L1 = d1.en, L2 = d2.en;
+            const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
+            const Fe c1 = Fr::pow_u64(zeta, L1), c2 = Fr::pow_u64(zeta2, L1), e = Fr::pow_u64(zeta2, L2);
+            Fe* hp = pp_at(p->ix_hpiece);
+            const size_t tb = (size_t)3 * L2;
+            Fe *fold = p->split_tmp, *a2 = fold + L2, *bc = a2 + L2;
+            ctx->unit_next = ext_inv_unit;  // (the three transforms of the split form stand for ONE extended_to_coeff)
+            ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[1].h, d1.ek, L1, hp, hat, 1, nb, L1, pp_bs));  // A, in place of the low pieces
+            ZG_TRY(poly_fold(ctx, nb, hp, pp_bs, L2, L1 / L2, e, fold, tb));                       // A mod (X^L2 - e)
+            ctx->unit_next = 0.0;
+            ZG_TRY(coeff_to_coset_dev(ctx, fold, tb, L2, a2, tb, nb, d2.ek, false, 2));            // A on the second coset
+            const Fe unhat = hat ? Fr::inv(Fr::from_u64(32)) : Fr::one();
+            ZG_TRY(poly_diff_scale(ctx, nb, p->dbuf[2].h, L2, unhat, a2, tb, Fr::inv(Fr::sub(c2, c1)), a2, tb, L2));  // B on the second coset
+            ctx->unit_next = 0.0;
+            ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
+            ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
+        }
+        ctx->msm_dense_hint = true;  // (the quotient pieces are random vectors: every digit of every window is an addition)
+        const int st_h = commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0);
+        ctx->msm_dense_hint = false;
+        ZG_TRY(st_h);
+        ZG_TICK("h: queued");
+        ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
+        ZG_TICK("h: points on the host");
+        for (uint32_t b = 0; b < nb; b++)
+            for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
+
+        return ZG_OK;
+    }
+
+    int evaluations() {
+        // ---- evaluations
+        // distinct opening points, in any order (the powers table is indexed by slot)
+        rots = {0, 1, -1, -(int32_t)(bf + 1)};
+        auto rot_slot = [&](int32_t r) -> uint32_t {
+            for (size_t i = 0; i < rots.size(); i++)
+                if (rots[i] == r) return (uint32_t)i;
+            rots.push_back(r);
+            return (uint32_t)rots.size() - 1;
+        };
+        evq.clear();  // evaluations in transcript order, then h_poly at x
+        for (auto& q : pk.advice_queries) evq.push_back({p->ix_adv + q.column, rot_slot(q.rotation)});
+        e_fixed = evq.size();
+        for (auto& q : pk.fixed_queries) evq.push_back({p->ix_fixed + q.column, rot_slot(q.rotation)});
+        e_random = evq.size();
+        evq.push_back({p->ix_random, 0});
+        e_sigma = evq.size();
+        for (uint32_t c = 0; c < P; c++) evq.push_back({p->ix_sigma + c, 0});
+        e_pz = evq.size();
+        for (uint32_t s = 0; s < S; s++) {
+            evq.push_back({p->ix_pz + s, 0});
+            evq.push_back({p->ix_pz + s, 1});
+            if (s + 1 < S) evq.push_back({p->ix_pz + s, 3});
+        }
+        e_lk = evq.size();
+        for (uint32_t l = 0; l < NL; l++) {
+            evq.push_back({p->ix_lz + l, 0});            // z(x)
+            evq.push_back({p->ix_lz + l, 1});            // z(omega x)
+            evq.push_back({p->ix_perm + 2 * l, 0});      // a'(x)
+            evq.push_back({p->ix_perm + 2 * l, 2});      // a'(omega^-1 x)
+            evq.push_back({p->ix_perm + 2 * l + 1, 0});  // s'(x)
+        }
+        e_written = evq.size();
+        evq.push_back({p->ix_hpoly, 0});
+        e_h = e_written;
+        npoints = (uint32_t)rots.size();
+        ZG_REQUIRE(npoints <= p->max_points, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u distinct rotations are queried (max %u)", npoints,
+                   p->max_points);
+        ZG_REQUIRE(evq.size() <= p->max_evals, ZG_ERR_UNSUPPORTED, "zg_prover_prove: too many evaluations");
+
+        for (uint32_t b = 0; b < nb; b++) {
+            ProofConst& c = p->hpc[b];
+            const Fe x = tr[b].squeeze();
+            c.xn = Fr::pow_u64(x, n);
+            for (uint32_t i = 0; i < npoints; i++) c.points[i] = rotate_omega(pk, x, rots[i]);
+        }
+        ZG_TICK("x");
+        ZG_TRY(upload_consts(p, nb));
+        ZG_TICK("x uploaded");
+        lap(3);
+        // vanishing.evaluate: h(X) = sum_i xn^i h_i(X)
+        d_hlist = p->d_idx + (size_t)4 * p->max_evals;
+        {
+            std::vector<uint32_t> list(Q);
+            for (uint32_t i = 0; i < Q; i++) list[i] = p->ix_hpiece + (Q - 1 - i);
+            ZG_TRY(h2d_list(p, d_hlist, list));
+            ZG_TRY(poly_horner_combine_xn(ctx, polys, p->d_pc, nb, d_hlist, Q, pp_at(p->ix_hpoly), pp_bs, n));
+        }
+        ZG_TRY(poly_powers(ctx, p->d_pc, nb, npoints, n, p->pw, pw_bs));
+        std::vector<uint32_t> idx(2 * evq.size());
+        for (size_t i = 0; i < evq.size(); i++) {
+            idx[i] = evq[i].poly;
+            idx[evq.size() + i] = evq[i].slot;
+        }
+        ZG_TRY(h2d_list(p, p->d_idx, idx));
+        // (the evaluations too are written where the host reads them: no copy command behind the kernel)
+        uint32_t distinct_polys = 0;
+        {
+            std::vector<uint32_t> seen(idx.begin(), idx.begin() + evq.size());
+            std::sort(seen.begin(), seen.end());
+            distinct_polys = (uint32_t)(std::unique(seen.begin(), seen.end()) - seen.begin());
+        }
+        ZG_TRY(poly_dot(ctx, polys, nb, n, p->d_idx, p->d_idx + evq.size(), p->pw, pw_bs, (uint32_t)evq.size(),
+                        reinterpret_cast<Fe*>((char*)p->pinned_dev + p->pin_evals), p->max_evals, distinct_polys, npoints));
+        ev_all = reinterpret_cast<const Fe*>((char*)p->pinned + p->pin_evals);
+        ZG_TICK("evals: queued");
+        ZG_HIP(hipStreamSynchronize(st));
+        ZG_TICK("evals on the host");
+
+        return ZG_OK;
+    }
+
+    int openings() {
+        // ---- opening queries in create_proof's order: (poly, point slot, index of the evaluation)
+        struct OQ { uint32_t poly, slot; size_t ev; };
+        std::vector<OQ> oq;
+        for (size_t i = 0; i < e_fixed; i++) oq.push_back({evq[i].poly, evq[i].slot, i});
+        {
+            size_t e = e_pz;
+            std::vector<size_t> e_last(S, 0), e_cur(S, 0), e_next(S, 0);
+            for (uint32_t s = 0; s < S; s++) {
+                e_cur[s] = e++;
+                e_next[s] = e++;
+                if (s + 1 < S) e_last[s] = e++;
+            }
+            for (uint32_t s = 0; s < S; s++) {
+                oq.push_back({p->ix_pz + s, 0, e_cur[s]});
+                oq.push_back({p->ix_pz + s, 1, e_next[s]});
+            }
+            for (uint32_t s = S; s-- > 0;) {
+                if (s + 1 == S) continue;
+                oq.push_back({p->ix_pz + s, 3, e_last[s]});
+            }
+        }
+        for (uint32_t l = 0; l < NL; l++) {
+            const size_t e5 = e_lk + 5 * l;
+            oq.push_back({p->ix_lz + l, 0, e5 + 0});
+            oq.push_back({p->ix_perm + 2 * l, 0, e5 + 2});
+            oq.push_back({p->ix_perm + 2 * l + 1, 0, e5 + 4});
+            oq.push_back({p->ix_perm + 2 * l, 2, e5 + 3});
+            oq.push_back({p->ix_lz + l, 1, e5 + 1});
+        }
+        for (size_t i = e_fixed; i < e_random; i++) oq.push_back({evq[i].poly, evq[i].slot, i});
+        for (uint32_t c = 0; c < P; c++) oq.push_back({p->ix_sigma + c, 0, e_sigma + c});
+        oq.push_back({p->ix_hpoly, 0, e_h});
+        oq.push_back({p->ix_random, 0, e_random});
+
+        // ---- ProverGWC::create_proof: the point sets (circuit only), then per proof its v-weighted evaluation batches
+        uint32_t nsets = 0;
+        std::vector<uint32_t> lists, counts, set_slot;  // list of point set s at lists[s * 512 ..]
+        std::vector<std::vector<size_t>> set_evs;        // evaluation indices of set s, in list order
+        {
+            std::vector<char> done(oq.size(), 0);
+            for (size_t first = 0; first < oq.size(); first++) {
+                if (done[first]) continue;
+                const uint32_t slot = oq[first].slot;
+                lists.resize((size_t)(nsets + 1) * 512, 0);
+                set_evs.emplace_back();
+                uint32_t cnt = 0;
+                for (size_t j = first; j < oq.size(); j++) {
+                    if (done[j] || oq[j].slot != slot) continue;
+                    done[j] = 1;
+                    ZG_REQUIRE(cnt < 512, ZG_ERR_UNSUPPORTED, "zg_prover_prove: more than 512 polynomials opened at one point");
+                    lists[(size_t)nsets * 512 + cnt++] = oq[j].poly;
+                    set_evs.back().push_back(oq[j].ev);
+                }
+                counts.push_back(cnt);
+                set_slot.push_back(slot);
+                nsets++;
+            }
+        }
+        ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u opening points", nsets);
+        ZG_TICK("opening sets listed");
+        for (uint32_t b = 0; b < nb; b++) {
+            const Fe* ev = ev_all + (size_t)b * p->max_evals;
+            for (size_t i = 0; i < e_written; i++) tr[b].write_scalar(ev[i]);
+            ProofConst& c = p->hpc[b];
+            c.v = tr[b].squeeze();
+            for (uint32_t s = 0; s < nsets; s++) {
+                Fe eval_batch = fe_zero();
+                for (size_t e : set_evs[s]) eval_batch = Fr::add(Fr::mul(eval_batch, c.v), ev[e]);
+                c.subs[s] = eval_batch;
+            }
+        }
+        ZG_TICK("v");
+        ZG_TRY(upload_consts(p, nb));
+        ZG_TICK("v uploaded");
+        lap(4);
+        {
+            // poly_batch of every point set in one launch: set s -> wpoly[2s]
+            // (their own region of d_idx, behind the evaluation lists: nothing else writes there between proofs)
+            uint32_t* d_lists = d_hlist + 64;
+            ZG_TRY(h2d_list(p, d_lists, lists));
+            ZG_TRY(poly_horner_combine_sets(ctx, polys, p->d_pc, nb, d_lists, 512, counts.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, n));
+            // one batched kate_division: poly s at wpoly[2s], quotient at wpoly[2s+1]
+            ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
+                                      wp_bs, p->ktmp, n));
+            // the witness polynomials sit at odd slots: stride 2n
+            ctx->msm_dense_hint = true;  // (so are the opening quotients)
+            const int st_w = commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0);
+            ctx->msm_dense_hint = false;
+            ZG_TRY(st_w);
+            ZG_TICK("gwc: queued");
+            ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
+            ZG_TICK("gwc: points on the host");
+            for (uint32_t b = 0; b < nb; b++)
+                for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
+        }
+        return ZG_OK;
+    }
+
+    int finish() {
+        int first_bad = ZG_OK;
+        for (uint32_t b = 0; b < nb; b++) {
+            if (status[b] == ZG_OK && tr[b].failed) {
+                set_error("zg_prover_prove: a commitment of proof %u is the identity point; EvmTranscript cannot absorb it", b);
+                status[b] = ZG_ERR_INVALID_ARG;
+            }
+            if (status[b] == ZG_OK && tr[b].stream.size() > proof_cap) {
+                set_error("zg_prover_prove: proof buffer too small (%zu > %zu)", tr[b].stream.size(), proof_cap);
+                status[b] = ZG_ERR_INVALID_ARG;
+            }
+            if (status[b] == ZG_OK) {
+                memcpy(proofs[b], tr[b].stream.data(), tr[b].stream.size());
+                proof_lens[b] = tr[b].stream.size();
+            } else {
+                proof_lens[b] = 0;
+                if (first_bad == ZG_OK) first_bad = status[b];
+            }
+            if (statuses) statuses[b] = status[b];
+        }
+        ZG_TICK("proof bytes out");
+        lap(5);
+        p->phase_ms[6] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
+        p->in_flight = false;
+        return first_bad;
+    }
+};
+
 static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advice_host, void* const* advice_dev,
                             const zg_fr* const* instance, size_t instance_len, const uint8_t* keys /* [count][32] */,
                             uint8_t* const* proofs, size_t proof_cap, size_t* proof_lens, int* statuses) {
@@ -1138,516 +1758,9 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     ZG_REQUIRE(instance_len <= pk.usable, ZG_ERR_INVALID_ARG, "zg_prover_prove: instance too large (Error::InstanceTooLarge)");
     ZG_REQUIRE(p->world > 1 || p->shard_n == pk.n, ZG_ERR_INVALID_ARG,
                "zg_prover_prove: the base sets hold %u of %u points and no shard was declared (zg_prover_set_shard)", p->shard_n, pk.n);
-    zg_ctx* ctx = p->ctx;
-    ZG_ENTER(ctx);
-    hipStream_t st = ctx->stream;
-    const uint32_t nb = (uint32_t)count;
-    const uint32_t n = pk.n, k = pk.k, ek = pk.ext_k, bf = pk.bf, usable = pk.usable;
-    const uint32_t A = pk.A, I = pk.I, P = pk.P, NL = pk.NL, S = pk.sets, Q = pk.qpd;
-    const bool hat = pk.hat;
-    // extended-domain parts of this proof: the split pair in the throughput configuration, the single coset otherwise
-    const bool split = pk.nparts == 3 && (!p->use_side || p->lat_split);
-    // the coset forms of a phase's columns: on the side stream while that phase's commitments run (latency form), or all
-    // at once before evaluate_h (throughput form)
-    const bool phase_cosets = p->use_side || !split;
-    const uint32_t dlo = split ? 1u : 0u, dhi = split ? 3u : 1u;
-    // strides between consecutive proofs
-    const size_t pp_bs = (size_t)p->npp * n, adv_bs = (size_t)A * n, inst_bs = (size_t)I * n, perm_bs = (size_t)(2 * NL + 1) * n,
-                 zs_bs = (size_t)(S + NL + 1) * n, pw_bs = (size_t)p->max_points * n, wp_bs = (size_t)2 * p->max_points * n;
-    auto pp_at = [&](uint32_t ix) { return p->pp + (size_t)(ix - p->nsh) * n; };  // proof 0's polynomial ix (>= nsh)
-    PolySet polys;
-    polys.sh = pk.sh_polys; polys.pp = p->pp; polys.nsh = p->nsh; polys.n = n; polys.pp_bs = pp_bs;
-    std::vector<EvmTranscript> tr(nb);
-    std::vector<int> status(nb, ZG_OK);
-    std::vector<Jac> pts;
-    p->have_last = false;
-    if (p->in_flight) {  // the previous batch left through an error return: drain what it queued before its staging
-        (void)hipStreamSynchronize(st);  // arena and slots are reused
-        if (ctx->side) (void)hipStreamSynchronize(ctx->side->stream);
-    }
-    p->in_flight = true;
-    p->stage_off = p->pin_stage;
-#ifdef ZG_TICKS
-    TickLog ticks;
-#endif
-    using clk = std::chrono::steady_clock;
-    auto t_start = clk::now(), t_prev = t_start;
-    auto lap = [&](int slot) {
-        auto now = clk::now();
-        p->phase_ms[slot] = std::chrono::duration<double, std::milli>(now - t_prev).count();
-        t_prev = now;
-    };
-
-    // side stream: coefficient / coset forms of committed columns are computed there while the main
-    // stream runs the commitment MSM (whose tail is a chain of dependent EC additions on a few CUs)
-    // (p->use_side == false: everything stays on the main stream -- the throughput configuration, where
-    // other proofs in flight fill the gaps and every extra HIP stream costs a hardware queue)
-    zg_ctx* sx = p->use_side ? ctx->side : ctx;
-    hipStream_t ss = sx->stream;
-    auto fork = [&]() -> int {  // side stream continues after everything queued on the main stream so far
-        if (!p->use_side) return ZG_OK;
-        ZG_HIP(hipEventRecord(p->ev_fork, st));
-        ZG_HIP(hipStreamWaitEvent(ss, p->ev_fork, 0));
-        return ZG_OK;
-    };
-    auto join = [&]() -> int {  // main stream continues after everything queued on the side stream so far
-        if (!p->use_side) return ZG_OK;
-        ZG_HIP(hipEventRecord(p->ev_join, ss));
-        ZG_HIP(hipStreamWaitEvent(st, p->ev_join, 0));
-        return ZG_OK;
-    };
-    // two-level layouts of the transforms: `per` arrays per proof
-    auto grouping = [](uint32_t per, size_t in_outer, size_t out_outer) {
-        Grouping g;
-        g.per = per; g.in_outer = in_outer; g.out_outer = out_outer;
-        return g;
-    };
-    // coefficient forms (ix0 .. ix0 + per) of every proof -> their slabs on each part of the extended domain
-    // (profile charges: SURVEY.md 8d counts one coeff_to_extended as (n + 2^ext_k) * 32 B whatever parts it is computed on)
-    double parts_en = 0.0;
-    for (uint32_t di = dlo; di < dhi; di++) parts_en += (double)pk.dom[di].en;
-    const double ext_unit = ((double)n + (double)((size_t)1 << ek)) * 32.0;
-    auto to_cosets = [&](zg_ctx* c, uint32_t ix0, uint32_t per) -> int {
-        for (uint32_t di = dlo; di < dhi; di++) {
-            const PkDev::Dom& d = pk.dom[di];
-            const Grouping g = grouping(per, pp_bs, (size_t)p->ncos * d.en);
-            c->unit_next = (double)nb * per * ext_unit * ((double)d.en / parts_en);
-            ZG_TRY(coeff_to_coset_dev(c, pp_at(ix0), n, n, p->dbuf[di].cos + (size_t)(ix0 - p->ix_adv) * d.en, d.en, (size_t)nb * per,
-                                      d.ek, hat, d.zpow, &g));
-        }
-        return ZG_OK;
-    };
-
-    // ---- advice columns into their slots
-    for (uint32_t b = 0; b < nb; b++) {
-        Fe* slot = p->adv_val + b * adv_bs;
-        if (!A) break;
-        if (advice_host && advice_host[b]) {
-            ZG_HIP(hipMemcpyAsync(slot, advice_host[b], adv_bs * 32, hipMemcpyHostToDevice, st));
-        } else if (advice_dev && advice_dev[b] && advice_dev[b] != (void*)slot) {
-            ZG_HIP(hipMemcpyAsync(slot, advice_dev[b], adv_bs * 32, hipMemcpyDeviceToDevice, st));
-        }
-    }
-
-    // ---- vk + instance values into the transcripts; instance polynomials
-    for (uint32_t b = 0; b < nb; b++) {
-        memset(&p->hpc[b], 0, sizeof(ProofConst));
-        memcpy(p->hpc[b].key, keys + 32 * (size_t)b, 32);
-        tr[b].common_scalar(pk.vk_repr);
-    }
-    ZG_TRY(upload_consts(p, nb));
-    // vanishing::Argument::commit's random polynomial depends on no challenge: generate it now and
-    // commit it inside the permuted-lookup batch (coefficient basis `g` next to `g_lagrange` vectors)
-    Fe* random_row = p->perm + (size_t)(2 * NL) * n;  // (proof 0's; proof b's is perm_bs further)
-    // (the same launch draws the blinding rows of the advice columns: commit_lagrange's input below)
-    Fe* adv = p->adv_val;
-    ZG_TRY(poly_random_and_blind(ctx, p->d_pc, nb, random_row, perm_bs, pp_at(p->ix_random), pp_bs, n, TAG_RANDOM_POLY, adv, adv_bs,
-                                 n, A, usable, bf + 1, TAG_ADVICE_BLIND));
-    if (I) {
-        for (uint32_t b = 0; b < nb; b++) {
-            Fe* iv = p->inst_val + b * inst_bs;
-            if (p->inst_filled[b] > instance_len) ZG_HIP(hipMemsetAsync(iv, 0, inst_bs * 32, st));  // (zeroed at create)
-            p->inst_filled[b] = instance_len;
-            for (uint32_t c = 0; c < I; c++) {
-                const zg_fr* src = instance_len ? instance[b] + (size_t)c * instance_len : nullptr;
-                for (size_t i = 0; i < instance_len; i++) tr[b].common_scalar(to_fe(&src[i]));
-                if (instance_len) ZG_TRY(h2d(p, iv + (size_t)c * n, src, instance_len * 32));
-            }
-        }
-    }
-
-    // ---- advice: commit (Lagrange basis)
-    ZG_TRY(fork());
-    if (I) {
-        const Grouping g = grouping(I, inst_bs, pp_bs);
-        ZG_TRY(ntt_batch_to_dev(sx, p->inst_val, pp_at(p->ix_inst), n, (size_t)nb * I, k, pk.omega_inv, &pk.ifft_div, &g));
-        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_inst, I));
-    }
-    if (A) {
-        ZG_TRY(commit(p, p->gl, nullptr, A, adv, n, A, adv_bs, (size_t)nb * A, 0));
-        const Grouping g = grouping(A, adv_bs, pp_bs);
-        ZG_TRY(ntt_batch_to_dev(sx, adv, pp_at(p->ix_adv), n, (size_t)nb * A, k, pk.omega_inv, &pk.ifft_div, &g));
-        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_adv, A));
-        ZG_TICK("advice: queued");
-        ZG_TRY(wait_points(p, (size_t)nb * A, pts));
-        ZG_TICK("advice: points on the host");
-        for (uint32_t b = 0; b < nb; b++)
-            for (uint32_t c = 0; c < A; c++) tr[b].write_point(pts[(size_t)b * A + c]);
-    }
-    for (uint32_t b = 0; b < nb; b++) p->hpc[b].theta = tr[b].squeeze();
-    ZG_TICK("theta");
-    ZG_TRY(upload_consts(p, nb));
-    ZG_TICK("theta uploaded");
-    lap(0);
-
-    Cols base_cols;
-    base_cols.fixed = pk.fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
-    base_cols.log_size = k; base_cols.rot_scale = 1;
-    base_cols.adv_bs = adv_bs; base_cols.inst_bs = inst_bs;
-
-    // ---- lookups: commit_permuted (+ the random polynomial's commitment)
-    std::vector<Jac> random_commit(nb);
-    bool have_random = false;
-    if (NL) {
-        // permute_expression_pair on the device: canonical keys (written by the compression kernel itself, with
-        // the sentinel padding), bitonic sort of inputs and tables, scan-based construction of s' (sort.hip).
-        // raw rows [0, m) = inputs -> a', [m, 2m) = tables, m = nb * NL, row b * NL + l = lookup l of proof b.
-        const uint32_t m = nb * NL;
-        Fe *raw_in = p->raw, *raw_tab = p->raw + (size_t)m * n;
-        uint32_t* d_err = p->sort_u32 + (size_t)2 * m * n + 2 * m;  // behind permute_pairs' scratch: zeroed by the same fill
-        ZG_TRY(poly_lookup_compress(ctx, pk.dc, base_cols, p->d_pc, nb, p->cin, p->ctab, n, raw_in, raw_tab, usable));
-        auto t_sort = clk::now();
-        ZG_TRY(poly_sort_keys(ctx, p->raw, n, 2 * m));
-        ZG_TRY(poly_permute_pairs(ctx, raw_in, raw_tab, p->sraw, n, usable, m, p->sort_u32, p->sort_fe, d_err));
-        // perm[2l] = a'_l, perm[2l+1] = s'_l (Montgomery form) on the usable rows, then the blinding tail
-        // (blinding: a' rows get tag 2, s' rows tag 3, index = lookup * (bf+1) + j)
-        ZG_TRY(poly_permuted_finish(ctx, p->d_pc, nb, raw_in, p->sraw, p->perm, perm_bs, n, usable, bf + 1, NL, TAG_PERMUTED_INPUT,
-                                    TAG_PERMUTED_TABLE));
-        p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
-        ZG_TRY(fork());
-        // the lookups' error words leave on the side stream, beside the commitments (an event of their own)
-        uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
-        ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ss));
-        ZG_HIP(hipEventRecord(p->ev_err, ss));
-        // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
-        const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);  // (both or neither)
-        const uint64_t sorted_runs = cgl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
-        ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs, naf_gl_width(p)));
-        {
-            const Grouping g = grouping(2 * NL, perm_bs, pp_bs);
-            ZG_TRY(ntt_batch_to_dev(sx, p->perm, pp_at(p->ix_perm), n, (size_t)nb * 2 * NL, k, pk.omega_inv, &pk.ifft_div, &g));
-        }
-        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_perm, 2 * NL));
-        ZG_TICK("permuted: queued");
-        ZG_TRY(wait_points(p, (size_t)nb * (2 * NL + 1), pts));
-        ZG_HIP(hipEventSynchronize(p->ev_err));
-        ZG_TICK("permuted: points on the host");
-        for (uint32_t b = 0; b < nb; b++) {
-            for (uint32_t l = 0; l < NL; l++)
-                if (h_err[b * NL + l] && status[b] == ZG_OK) {
-                    set_error("zg_prover_prove: lookup %u of proof %u has an input outside its table (ConstraintSystemFailure)", l, b);
-                    status[b] = ZG_ERR_CONSTRAINT;
-                }
-            const Jac* q = &pts[(size_t)b * (2 * NL + 1)];
-            for (uint32_t i = 0; i < 2 * NL; i++) tr[b].write_point(q[i]);
-            random_commit[b] = q[2 * NL];
-        }
-        have_random = true;
-        if (nb == 1 && status[0] != ZG_OK) {  // a lone proof stops here, as upstream's `?` does
-            (void)hipStreamSynchronize(ss);
-            (void)hipStreamSynchronize(st);
-            if (statuses) statuses[0] = status[0];
-            proof_lens[0] = 0;
-            p->in_flight = false;
-            return status[0];
-        }
-    }
-    for (uint32_t b = 0; b < nb; b++) {
-        p->hpc[b].beta = tr[b].squeeze();
-        p->hpc[b].gamma = tr[b].squeeze();
-    }
-    ZG_TICK("beta, gamma");
-    ZG_TRY(upload_consts(p, nb));
-    ZG_TICK("beta, gamma uploaded");
-    lap(1);
-
-    // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
-    const uint32_t mb = S + NL;
-    if (S) ZG_TRY(poly_perm_terms(ctx, pk.dc, base_cols, p->d_pc, nb, pk.sigma_val, pk.omega_tw, p->num, p->den, mb, n));
-    // (a'_l / s'_l are interleaved in `perm`: two views with a stride of two columns)
-    ZG_TRY(poly_lookup_terms(ctx, p->d_pc, nb, p->cin, p->ctab, p->perm, p->perm + n, (size_t)2 * n, perm_bs, p->num, p->den, mb, S, n, NL));
-    if (mb) {
-        // all running products of the batch in one scan sequence; per proof the S permutation sets are chained
-        // through row n - bf - 1, the lookup products start from one
-        ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, nb * mb, S, n - bf - 1, mb, zs_bs));
-        ZG_TRY(poly_blind_rows2(ctx, p->d_pc, nb, p->zs, zs_bs, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf));  // (lz follows pz)
-        // The products stay constant wherever a row changes nothing (every padding row of the circuit): they are
-        // committed in the run form, sum_i (z_i - z_{i+1}) Q_i over the running sums Q of g_lagrange.
-        const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);
-        const uint64_t z_runs = cgl->run_table && mb < 64 ? (1ull << mb) - 1ull : 0ull;
-        ZG_TRY(fork());
-        uint32_t per = mb;
-        if (have_random) {
-            ZG_TRY(commit(p, cgl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs, naf_gl_width(p)));
-        } else {  // no lookups: the random polynomial rides here instead (row mb of zs)
-            for (uint32_t b = 0; b < nb; b++)
-                ZG_HIP(hipMemcpyAsync(p->zs + b * zs_bs + (size_t)mb * n, random_row + b * perm_bs, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
-            per = mb + 1;
-            ZG_TRY(commit(p, cgl, cg, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs, naf_gl_width(p)));
-        }
-        {
-            const Grouping g = grouping(mb, zs_bs, pp_bs);
-            ZG_TRY(ntt_batch_to_dev(sx, p->zs, pp_at(p->ix_pz), n, (size_t)nb * mb, k, pk.omega_inv, &pk.ifft_div, &g));
-        }
-        if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_pz, mb));
-        ZG_TICK("products: queued");
-        ZG_TRY(wait_points(p, (size_t)nb * per, pts));
-        ZG_TICK("products: points on the host");
-        for (uint32_t b = 0; b < nb; b++) {
-            const Jac* q = &pts[(size_t)b * per];
-            for (uint32_t i = 0; i < mb; i++) tr[b].write_point(q[i]);
-            if (!have_random) random_commit[b] = q[mb];
-        }
-        have_random = true;
-    }
-    if (!have_random) {  // neither lookups nor permutation: commit the random polynomial on its own
-        ZG_TRY(commit(p, p->g, nullptr, 1, random_row, n, 1, perm_bs, nb, 0));
-        ZG_TRY(wait_points(p, nb, pts));
-        for (uint32_t b = 0; b < nb; b++) random_commit[b] = pts[b];
-    }
-    for (uint32_t b = 0; b < nb; b++) tr[b].write_point(random_commit[b]);
-    ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
-    for (uint32_t b = 0; b < nb; b++) evalh_consts(p->hpc[b], tr[b].squeeze(), hat, evalh_terms(pk));
-    ZG_TICK("y");
-    ZG_TRY(upload_consts(p, nb));
-    ZG_TICK("y uploaded");
-    lap(2);
-
-    // (throughput configuration: nothing overlaps, so every witness polynomial goes to its cosets here, in one batch per
-    //  coset, instead of phase by phase)
-    if (!phase_cosets) ZG_TRY(to_cosets(ctx, p->ix_adv, p->ncos));
-    // ---- evaluate_h (+ division by X^n - 1) on every part of the extended domain, back to coefficients, h pieces
-    for (uint32_t di = dlo; di < dhi; di++) {
-        const EvalHArgs a = evalh_args(p, di);
-        ZG_TRY(poly_evaluate_h(ctx, a, pk.dom[di].en, nb, A + I + pk.F, (double)((size_t)1 << ek) * ((double)pk.dom[di].en / parts_en)));
-    }
-    p->have_last = true;
-    p->last_split = split;
-    p->last_nb = nb;
-    const double ext_inv_unit = (double)nb * 2.0 * (double)((size_t)1 << ek) * 32.0;  // (ext -> coeff, 2 * 8n * 32 B)
-    if (!split) {
-        ctx->unit_next = ext_inv_unit;
-        ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[0].h, ek, (size_t)Q * n, pp_at(p->ix_hpiece), hat, 1, nb, pk.dom[0].en, pp_bs));
-    } else {
-        // h = A + (X^L1 - c1) B:  A (degree < L1) from the first coset, where X^L1 = c1 = shift1^L1;  B (degree < L2)
-        // from the second, where X^L1 = c2 and X^L2 = e are constants too:  B = (h - A) / (c2 - c1) there, with A
-        // folded modulo X^L2 - e before it is evaluated on those L2 points.
-        const PkDev::Dom &d1 = pk.dom[1], &d2 = pk.dom[2];
-        const uint32_t L1 = d1.en, L2 = d2.en;
-        const Fe zeta = fr_zeta(), zeta2 = Fr::sqr(zeta);
-        const Fe c1 = Fr::pow_u64(zeta, L1), c2 = Fr::pow_u64(zeta2, L1), e = Fr::pow_u64(zeta2, L2);
-        Fe* hp = pp_at(p->ix_hpiece);
-        const size_t tb = (size_t)3 * L2;
-        Fe *fold = p->split_tmp, *a2 = fold + L2, *bc = a2 + L2;
-        ctx->unit_next = ext_inv_unit;  // (the three transforms of the split form stand for ONE extended_to_coeff)
-        ZG_TRY(coset_to_coeff_dev(ctx, p->dbuf[1].h, d1.ek, L1, hp, hat, 1, nb, L1, pp_bs));  // A, in place of the low pieces
-        ZG_TRY(poly_fold(ctx, nb, hp, pp_bs, L2, L1 / L2, e, fold, tb));                       // A mod (X^L2 - e)
-        ctx->unit_next = 0.0;
-        ZG_TRY(coeff_to_coset_dev(ctx, fold, tb, L2, a2, tb, nb, d2.ek, false, 2));            // A on the second coset
-        const Fe unhat = hat ? Fr::inv(Fr::from_u64(32)) : Fr::one();
-        ZG_TRY(poly_diff_scale(ctx, nb, p->dbuf[2].h, L2, unhat, a2, tb, Fr::inv(Fr::sub(c2, c1)), a2, tb, L2));  // B on the second coset
-        ctx->unit_next = 0.0;
-        ZG_TRY(coset_to_coeff_dev(ctx, a2, d2.ek, L2, bc, false, 2, nb, tb, tb));              // B
-        ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
-    }
-    ctx->msm_dense_hint = true;  // (the quotient pieces are random vectors: every digit of every window is an addition)
-    const int st_h = commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0);
-    ctx->msm_dense_hint = false;
-    ZG_TRY(st_h);
-    ZG_TICK("h: queued");
-    ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
-    ZG_TICK("h: points on the host");
-    for (uint32_t b = 0; b < nb; b++)
-        for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
-
-    // ---- evaluations
-    // distinct opening points, in any order (the powers table is indexed by slot)
-    std::vector<int32_t> rots = {0, 1, -1, -(int32_t)(bf + 1)};
-    auto rot_slot = [&](int32_t r) -> uint32_t {
-        for (size_t i = 0; i < rots.size(); i++)
-            if (rots[i] == r) return (uint32_t)i;
-        rots.push_back(r);
-        return (uint32_t)rots.size() - 1;
-    };
-    struct Q1 { uint32_t poly, slot; };
-    std::vector<Q1> evq;  // evaluations in transcript order, then h_poly at x
-    for (auto& q : pk.advice_queries) evq.push_back({p->ix_adv + q.column, rot_slot(q.rotation)});
-    const size_t e_fixed = evq.size();
-    for (auto& q : pk.fixed_queries) evq.push_back({p->ix_fixed + q.column, rot_slot(q.rotation)});
-    const size_t e_random = evq.size();
-    evq.push_back({p->ix_random, 0});
-    const size_t e_sigma = evq.size();
-    for (uint32_t c = 0; c < P; c++) evq.push_back({p->ix_sigma + c, 0});
-    const size_t e_pz = evq.size();
-    for (uint32_t s = 0; s < S; s++) {
-        evq.push_back({p->ix_pz + s, 0});
-        evq.push_back({p->ix_pz + s, 1});
-        if (s + 1 < S) evq.push_back({p->ix_pz + s, 3});
-    }
-    const size_t e_lk = evq.size();
-    for (uint32_t l = 0; l < NL; l++) {
-        evq.push_back({p->ix_lz + l, 0});            // z(x)
-        evq.push_back({p->ix_lz + l, 1});            // z(omega x)
-        evq.push_back({p->ix_perm + 2 * l, 0});      // a'(x)
-        evq.push_back({p->ix_perm + 2 * l, 2});      // a'(omega^-1 x)
-        evq.push_back({p->ix_perm + 2 * l + 1, 0});  // s'(x)
-    }
-    const size_t e_written = evq.size();
-    evq.push_back({p->ix_hpoly, 0});
-    const size_t e_h = e_written;
-    const uint32_t npoints = (uint32_t)rots.size();
-    ZG_REQUIRE(npoints <= p->max_points, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u distinct rotations are queried (max %u)", npoints,
-               p->max_points);
-    ZG_REQUIRE(evq.size() <= p->max_evals, ZG_ERR_UNSUPPORTED, "zg_prover_prove: too many evaluations");
-
-    for (uint32_t b = 0; b < nb; b++) {
-        ProofConst& c = p->hpc[b];
-        const Fe x = tr[b].squeeze();
-        c.xn = Fr::pow_u64(x, n);
-        for (uint32_t i = 0; i < npoints; i++) c.points[i] = rotate_omega(pk, x, rots[i]);
-    }
-    ZG_TICK("x");
-    ZG_TRY(upload_consts(p, nb));
-    ZG_TICK("x uploaded");
-    lap(3);
-    // vanishing.evaluate: h(X) = sum_i xn^i h_i(X)
-    uint32_t* d_hlist = p->d_idx + (size_t)4 * p->max_evals;
-    {
-        std::vector<uint32_t> list(Q);
-        for (uint32_t i = 0; i < Q; i++) list[i] = p->ix_hpiece + (Q - 1 - i);
-        ZG_TRY(h2d_list(p, d_hlist, list));
-        ZG_TRY(poly_horner_combine_xn(ctx, polys, p->d_pc, nb, d_hlist, Q, pp_at(p->ix_hpoly), pp_bs, n));
-    }
-    ZG_TRY(poly_powers(ctx, p->d_pc, nb, npoints, n, p->pw, pw_bs));
-    std::vector<uint32_t> idx(2 * evq.size());
-    for (size_t i = 0; i < evq.size(); i++) {
-        idx[i] = evq[i].poly;
-        idx[evq.size() + i] = evq[i].slot;
-    }
-    ZG_TRY(h2d_list(p, p->d_idx, idx));
-    // (the evaluations too are written where the host reads them: no copy command behind the kernel)
-    uint32_t distinct_polys = 0;
-    {
-        std::vector<uint32_t> seen(idx.begin(), idx.begin() + evq.size());
-        std::sort(seen.begin(), seen.end());
-        distinct_polys = (uint32_t)(std::unique(seen.begin(), seen.end()) - seen.begin());
-    }
-    ZG_TRY(poly_dot(ctx, polys, nb, n, p->d_idx, p->d_idx + evq.size(), p->pw, pw_bs, (uint32_t)evq.size(),
-                    reinterpret_cast<Fe*>((char*)p->pinned_dev + p->pin_evals), p->max_evals, distinct_polys, npoints));
-    const Fe* ev_all = reinterpret_cast<const Fe*>((char*)p->pinned + p->pin_evals);
-    ZG_TICK("evals: queued");
-    ZG_HIP(hipStreamSynchronize(st));
-    ZG_TICK("evals on the host");
-
-    // ---- opening queries in create_proof's order: (poly, point slot, index of the evaluation)
-    struct OQ { uint32_t poly, slot; size_t ev; };
-    std::vector<OQ> oq;
-    for (size_t i = 0; i < e_fixed; i++) oq.push_back({evq[i].poly, evq[i].slot, i});
-    {
-        size_t e = e_pz;
-        std::vector<size_t> e_last(S, 0), e_cur(S, 0), e_next(S, 0);
-        for (uint32_t s = 0; s < S; s++) {
-            e_cur[s] = e++;
-            e_next[s] = e++;
-            if (s + 1 < S) e_last[s] = e++;
-        }
-        for (uint32_t s = 0; s < S; s++) {
-            oq.push_back({p->ix_pz + s, 0, e_cur[s]});
-            oq.push_back({p->ix_pz + s, 1, e_next[s]});
-        }
-        for (uint32_t s = S; s-- > 0;) {
-            if (s + 1 == S) continue;
-            oq.push_back({p->ix_pz + s, 3, e_last[s]});
-        }
-    }
-    for (uint32_t l = 0; l < NL; l++) {
-        const size_t e5 = e_lk + 5 * l;
-        oq.push_back({p->ix_lz + l, 0, e5 + 0});
-        oq.push_back({p->ix_perm + 2 * l, 0, e5 + 2});
-        oq.push_back({p->ix_perm + 2 * l + 1, 0, e5 + 4});
-        oq.push_back({p->ix_perm + 2 * l, 2, e5 + 3});
-        oq.push_back({p->ix_lz + l, 1, e5 + 1});
-    }
-    for (size_t i = e_fixed; i < e_random; i++) oq.push_back({evq[i].poly, evq[i].slot, i});
-    for (uint32_t c = 0; c < P; c++) oq.push_back({p->ix_sigma + c, 0, e_sigma + c});
-    oq.push_back({p->ix_hpoly, 0, e_h});
-    oq.push_back({p->ix_random, 0, e_random});
-
-    // ---- ProverGWC::create_proof: the point sets (circuit only), then per proof its v-weighted evaluation batches
-    uint32_t nsets = 0;
-    std::vector<uint32_t> lists, counts, set_slot;  // list of point set s at lists[s * 512 ..]
-    std::vector<std::vector<size_t>> set_evs;        // evaluation indices of set s, in list order
-    {
-        std::vector<char> done(oq.size(), 0);
-        for (size_t first = 0; first < oq.size(); first++) {
-            if (done[first]) continue;
-            const uint32_t slot = oq[first].slot;
-            lists.resize((size_t)(nsets + 1) * 512, 0);
-            set_evs.emplace_back();
-            uint32_t cnt = 0;
-            for (size_t j = first; j < oq.size(); j++) {
-                if (done[j] || oq[j].slot != slot) continue;
-                done[j] = 1;
-                ZG_REQUIRE(cnt < 512, ZG_ERR_UNSUPPORTED, "zg_prover_prove: more than 512 polynomials opened at one point");
-                lists[(size_t)nsets * 512 + cnt++] = oq[j].poly;
-                set_evs.back().push_back(oq[j].ev);
-            }
-            counts.push_back(cnt);
-            set_slot.push_back(slot);
-            nsets++;
-        }
-    }
-    ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u opening points", nsets);
-    ZG_TICK("opening sets listed");
-    for (uint32_t b = 0; b < nb; b++) {
-        const Fe* ev = ev_all + (size_t)b * p->max_evals;
-        for (size_t i = 0; i < e_written; i++) tr[b].write_scalar(ev[i]);
-        ProofConst& c = p->hpc[b];
-        c.v = tr[b].squeeze();
-        for (uint32_t s = 0; s < nsets; s++) {
-            Fe eval_batch = fe_zero();
-            for (size_t e : set_evs[s]) eval_batch = Fr::add(Fr::mul(eval_batch, c.v), ev[e]);
-            c.subs[s] = eval_batch;
-        }
-    }
-    ZG_TICK("v");
-    ZG_TRY(upload_consts(p, nb));
-    ZG_TICK("v uploaded");
-    lap(4);
-    {
-        // poly_batch of every point set in one launch: set s -> wpoly[2s]
-        // (their own region of d_idx, behind the evaluation lists: nothing else writes there between proofs)
-        uint32_t* d_lists = d_hlist + 64;
-        ZG_TRY(h2d_list(p, d_lists, lists));
-        ZG_TRY(poly_horner_combine_sets(ctx, polys, p->d_pc, nb, d_lists, 512, counts.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, n));
-        // one batched kate_division: poly s at wpoly[2s], quotient at wpoly[2s+1]
-        ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
-                                  wp_bs, p->ktmp, n));
-        // the witness polynomials sit at odd slots: stride 2n
-        ctx->msm_dense_hint = true;  // (so are the opening quotients)
-        const int st_w = commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0);
-        ctx->msm_dense_hint = false;
-        ZG_TRY(st_w);
-        ZG_TICK("gwc: queued");
-        ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
-        ZG_TICK("gwc: points on the host");
-        for (uint32_t b = 0; b < nb; b++)
-            for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
-    }
-    int first_bad = ZG_OK;
-    for (uint32_t b = 0; b < nb; b++) {
-        if (status[b] == ZG_OK && tr[b].failed) {
-            set_error("zg_prover_prove: a commitment of proof %u is the identity point; EvmTranscript cannot absorb it", b);
-            status[b] = ZG_ERR_INVALID_ARG;
-        }
-        if (status[b] == ZG_OK && tr[b].stream.size() > proof_cap) {
-            set_error("zg_prover_prove: proof buffer too small (%zu > %zu)", tr[b].stream.size(), proof_cap);
-            status[b] = ZG_ERR_INVALID_ARG;
-        }
-        if (status[b] == ZG_OK) {
-            memcpy(proofs[b], tr[b].stream.data(), tr[b].stream.size());
-            proof_lens[b] = tr[b].stream.size();
-        } else {
-            proof_lens[b] = 0;
-            if (first_bad == ZG_OK) first_bad = status[b];
-        }
-        if (statuses) statuses[b] = status[b];
-    }
-    ZG_TICK("proof bytes out");
-    lap(5);
-    p->phase_ms[6] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
-    p->in_flight = false;
-    return first_bad;
+    ZG_ENTER(p->ctx);
+    ProveBatch job(p, count, advice_host, advice_dev, instance, instance_len, keys, proofs, proof_cap, proof_lens, statuses);
+    return job.run();
 }
 
 int zg_prover_prove_batch(zg_prover* p, size_t count, const zg_fr* const* advice, const zg_fr* const* instance,

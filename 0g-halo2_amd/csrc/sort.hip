@@ -314,7 +314,8 @@ int poly_permute_pairs(zg_ctx* ctx, const Fe* a, const Fe* t, Fe* sprime, uint32
         ZG_HIP(hipMemsetAsync(d_err, 0, (size_t)batch * 4, ctx->stream));
     }
     dim3 g((usable + 255) / 256, batch);
-    // what each kernel streams per row (round 3 charged all five n * 96: the scans touch 4-byte flags only)
+    // what each kernel streams per row AT LEAST (round 3 charged all five n * 96: the scans touch 4-byte flags only; the
+    // leftover list is written / read for the unconsumed rows only and is left out of the charge)
     const double rows = (double)batch * usable;
     ZG_LAUNCH(ctx, "permute_flags", rows * 72, pp_flags_kernel, g, dim3(256), 0, a, t, n, usable, repeated, consumed, d_err);
     const uint32_t ntile = (usable + PP_TILE - 1) / PP_TILE;
@@ -324,8 +325,8 @@ int poly_permute_pairs(zg_ctx* ctx, const Fe* a, const Fe* t, Fe* sprime, uint32
     if (!toff) return ZG_ERR_OOM;
     ZG_LAUNCH(ctx, "permute_scan", rows * 8 + (double)batch * ntile * 8, pp_scan_local_kernel, dim3(ntile, batch), dim3(PP_TILE), 0, repeated, consumed, n, usable, ntile, toff);
     ZG_LAUNCH(ctx, "permute_scan", (double)batch * ntile * 16, pp_scan_tiles_kernel, dim3(batch), dim3(PP_TILE), 0, toff, ntile, totals);
-    ZG_LAUNCH(ctx, "permute_leftover", rows * 68, pp_leftover_kernel, g, dim3(256), 0, t, consumed, n, usable, scratch_fe, toff, ntile);
-    ZG_LAUNCH(ctx, "permute_build", rows * 100, pp_build_kernel, g, dim3(256), 0, a, repeated, scratch_fe, totals, n, usable, sprime,
+    ZG_LAUNCH(ctx, "permute_leftover", rows * 36, pp_leftover_kernel, g, dim3(256), 0, t, consumed, n, usable, scratch_fe, toff, ntile);
+    ZG_LAUNCH(ctx, "permute_build", rows * 68, pp_build_kernel, g, dim3(256), 0, a, repeated, scratch_fe, totals, n, usable, sprime,
               d_err, toff, ntile);
     ZG_HIP(hipGetLastError());
     return ZG_OK;

@@ -528,6 +528,12 @@ class Prover:
         fn = self._exchange if self._exchange is not None else ctypes.cast(None, EXCHANGE_FN)
         _check(self.ctx.lib.zg_prover_set_shard(self.h, c_uint32(rank), c_uint32(world), c_size_t(first_point), fn, None))
 
+    def set_shard_c(self, rank: int, world: int, first_point: int, fn_ptr: int, user: int = 0):
+        """zg_prover_set_shard with a C function as the exchange (address of an
+        `int fn(void *user, const void *send, size_t nbytes, void *recv)`): no Python in the provers' threads."""
+        _check(self.ctx.lib.zg_prover_set_shard(self.h, c_uint32(rank), c_uint32(world), c_size_t(first_point),
+                                                ctypes.cast(fn_ptr, EXCHANGE_FN), c_void_p(user)))
+
     def set_shard_rccl(self, rank: int, world: int, first_point: int, comm: int):
         """comm: an initialised ncclComm_t (multi_gpu.RcclComm(...).handle); the exchange then runs inside the library."""
         _check(self.ctx.lib.zg_prover_set_shard_rccl(self.h, c_uint32(rank), c_uint32(world), c_size_t(first_point),

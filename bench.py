@@ -116,6 +116,8 @@ class Stream:
         # rank has one of its own (an RcclComm: the all-gather runs inside the library; else a host callback)
         if shard[1] > 1 and hasattr(exchange, "handle"):
             prover.set_shard_rccl(shard[0], shard[1], c.lo, exchange.handle)
+        elif shard[1] > 1 and hasattr(exchange, "c_fn"):  # a C function pointer (tools/shard_compute_leg.py's stub)
+            prover.set_shard_c(shard[0], shard[1], c.lo, exchange.c_fn, exchange.c_user)
         elif shard[1] > 1:
             prover.set_shard(shard[0], shard[1], c.lo, exchange)
         # the witness into every slot, once: a proof rewrites only the last blinding_factors+1 rows of its advice
@@ -750,7 +752,7 @@ def main():
                     "issue_peak_wave_instr_per_s": VALU_ISSUE_PEAK, "frac": ach / VALU_ISSUE_PEAK,
                     "peak_note": "one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32), 256 CUs x 4 SIMDs x 2.4 GHz",
                     "clock_GHz_under_load": round(clock, 3),
-                    "clock_source": f"{os.path.relpath(PROFILES, ROOT)}/sq_issue.json: GRBM_GUI_ACTIVE / duration of the kernels at >= 0.7 issue utilisation, time-weighted",
+                    "clock_source": f"{sq.get('_from')}: GRBM_GUI_ACTIVE / duration of the kernels at >= 0.7 issue utilisation, time-weighted",
                     "four_cycle_issue_rate_wave_instr_per_s": four_cycle, "frac_of_four_cycle_issue_rate": ach / four_cycle,
                     "nine_limb_product_loop_rate_wave_instr_per_s": product_loop,
                     "frac_of_nine_limb_product_loop_rate": ach / product_loop,

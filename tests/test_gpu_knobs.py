@@ -34,6 +34,8 @@ SETTINGS = {
     "ZG_LAT_FULL_C": [0, 4, 7],
     "ZG_LAT_FULL_K": [4, 48],
     "ZG_LAZY_DOT": [0],
+    "ZG_MSM_AFFINE": [0, 1, 2, 3, 4],
+    "ZG_LAT_PULL": [0, 1],
 }
 # knobs that act together: walked as pairs as well
 PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2, 4)] + [
@@ -42,6 +44,9 @@ PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2,
     {"ZG_MSM_C": 6, "ZG_MSM_NAF_GL": 0},
     {"ZG_LAT_SPLIT_K": 0, "ZG_SPLIT_DOMAIN": 0},
     {"ZG_LAT_FULL_C": 5, "ZG_MSM_RUNS": 0},
+    {"ZG_MSM_AFFINE": 2, "ZG_MSM_NAF": 0, "ZG_MSM_NAF_GL": 0},   # affine rounds over the window tables
+    {"ZG_MSM_AFFINE": 3, "ZG_MSM_K": 4},
+    {"ZG_MSM_AFFINE": 1, "ZG_MSM_RUNS": 0},
 ]
 CASES = [{k: v} for k, vs in SETTINGS.items() for v in vs] + PAIRS
 

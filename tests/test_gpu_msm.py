@@ -209,6 +209,63 @@ def test_digit_tables_give_the_same_points(ctx, zg, orc, srs, c):
     bases.free()
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 3, 4])
+@pytest.mark.parametrize("bit_table", [False, True])
+def test_batched_affine_rounds_give_the_same_points(zg, orc, srs, rounds, bit_table):
+    """ZG_MSM_AFFINE: R rounds of pairwise AFFINE additions (one inversion per launch and round, shared through HBM by
+    Montgomery's trick) before the buckets' XYZZ chains, throughput form.  An affine chord has no formula for P + P,
+    P + (-P) or an identity operand, and ONE zero denominator would poison every sum of the launch -- so the base sets
+    here are built to produce all of them inside the paired-up bucket order: repeated bases (doublings when two equal
+    points share a bucket), a base and its negation (cancelling pairs), identity bases, and scalars that put them into the
+    same bucket (equal scalars, +-s).  Every result == the oracle's best_multiexp."""
+    _, gl = srs
+    n = 1 << 10
+    base = gl[:n].copy()
+    FQ = zg.FQ_MODULUS
+
+    def neg(pt):
+        out = pt.copy()
+        out[4:] = zg.fq_from_int((FQ - zg.fq_to_int(pt[4:])) % FQ)  # (x, -y)
+        return out
+
+    adv = base.copy()
+    adv[1] = adv[0]                      # P, P        -> a doubling when the scalars agree
+    adv[3] = neg(adv[2])                 # P, -P       -> cancels when the scalars agree
+    adv[4:8] = 0                         # identities among the bases
+    for i in range(16, 48, 2):           # sixteen equal points in a row: a bucket of doublings, round after round
+        adv[i] = adv[16]
+    for i in range(48, 64):              # alternating P, -P
+        adv[i] = adv[48] if i % 2 == 0 else neg(adv[48])
+    c2 = zg.Ctx(0)
+    c2.set_msm_latency(False)
+    before = zg.tuning_get("ZG_MSM_AFFINE")
+    zg.tuning_set("ZG_MSM_AFFINE", rounds)
+    try:
+        for bases_np in (base, adv):
+            bases = c2.register_bases(bases_np)
+            if bit_table:
+                c2.enable_bit_table(bases, 9)
+            R = zg.FR_MODULUS
+            same = np.tile(orc.fr_from_int(0x1234567), (n, 1))            # every point in the same buckets
+            pm = same.copy()
+            pm[1::2] = orc.fr_from_int(R - 0x1234567)                     # s, -s alternating: same bucket, opposite signs
+            vectors = [orc.fill_fr(51, n), orc.fill_fr_sparse(52, n), np.zeros((n, 4), np.uint64), same, pm,
+                       np.tile(orc.fr_from_int(1), (n, 1)), np.tile(orc.fr_from_int(R - 1), (n, 1))]
+            small = np.zeros((n, 4), np.uint64)
+            small[:64] = np.stack([orc.fr_from_int(v) for v in list(range(1, 33)) * 2])  # few entries: mostly pad pairs
+            vectors.append(small)
+            got = c2.msm_batch(bases, np.stack(vectors))
+            for b, sc in enumerate(vectors):
+                assert np.array_equal(got[b], orc.msm(sc, bases_np, threads=8)), (rounds, bit_table, b)
+            for m in (1, 2, 3, 65, n - 1):  # ragged lengths
+                sc = orc.fill_fr(800 + m, m)
+                assert np.array_equal(c2.msm(bases, sc), orc.msm(sc, bases_np[:m], threads=4)), (rounds, m)
+            bases.free()
+    finally:
+        zg.tuning_set("ZG_MSM_AFFINE", before)
+        c2.close()
+
+
 @pytest.mark.gpu
 def test_field_inv_returns_zero_when_its_budget_runs_out_device_path():
     """Field::inv of a multiple of the modulus on the DEVICE: the loop ends (iteration budget) and the result is 0

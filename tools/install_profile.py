@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
-"""Copy the summaries of a `tools/profile_r03.sh TAG` run from gpurun_out/prof_TAG into profiles/r03/ and derive
+"""Copy the summaries of a `tools/profile.sh TAG` run from gpurun_out/prof_TAG into profiles/ROUND/ and derive
     pmc_traffic.json     HBM bytes per launch per kernel (FETCH_SIZE / WRITE_SIZE passes, with the per-kernel FETCH_SIZE
                          correction that tools/fetch_calib.hip measured) and VALU wave-instructions per proof
     sq_issue.json/.txt   per kernel, alone on the chip: clock, waves per SIMD, the active / issue-stall / wait split of the
                          wave cycles, VALU issue utilisation -- the evidence behind "issue-saturated"
     serial_kernels.json  the serialised per-kernel table (one prover: kernels one at a time) of DESIGN.md section 4
     fetch_calibration.json
-    python tools/install_r03.py TAG"""
+    affine_ab.json       (when the run had AFFINE=R) VALU instructions and HBM bytes per proof of the MSM kernels with and
+                         without R rounds of batched-affine pre-reduction
+    python tools/install_profile.py ROUND TAG          e.g. r04 v1"""
 import csv
 import glob
 import json
@@ -16,12 +18,12 @@ import shutil
 import sys
 from collections import defaultdict
 
-tag = sys.argv[1]
+rnd, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
-dst = os.path.join(root, "profiles", "r03")
+dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-BATCH = int(os.environ.get("BATCH", "32"))  # proofs per lock-step batch of the profiled runs (tools/profile_r03.sh)
+BATCH = int(os.environ.get("BATCH", "32"))  # proofs per lock-step batch of the profiled runs (tools/profile.sh)
 SIMDS = 256 * 4
 
 
@@ -45,7 +47,9 @@ def launch_name(kernel: str) -> str:
              "pp_flags": "permute_flags", "pp_scan": "permute_scan", "pp_scan_local": "permute_scan", "pp_scan_tiles": "permute_scan", "pp_leftover": "permute_leftover",
              "pp_build": "permute_build", "random_and_blind": "random_poly", "evaluate_h9": "evaluate_h",
              "horner_combine_sets": "horner_combine", "msm_digits_naf": "msm_digits", "sort_global_fused": "sort_global",
-             "gate_factor9": "gate_factor", "combine9": "horner_combine", "dot9": "eval_dot", "msm_accumulate_full": "msm_accumulate_full"}
+             "gate_factor9": "gate_factor", "combine9": "horner_combine", "dot9": "eval_dot", "msm_accumulate_full": "msm_accumulate_full",
+             "aff_prefix": "msm_aff_prefix", "aff_apply": "msm_aff_apply", "aff_inv_up": "msm_aff_invert", "aff_inv_top": "msm_aff_invert",
+             "aff_inv_down": "msm_aff_invert"}
     return alias.get(k, k)
 
 
@@ -98,15 +102,17 @@ json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE over tools/fetch_calib.bin (2 Gi
                     "(every 32-byte record costs a 64-byte request).", "counter_over_true_bytes": calib},
           open(os.path.join(dst, "fetch_calibration.json"), "w"), indent=1)
 # kernels whose reads are dominated by 64-byte gathers take the raw counter; everything else streams 16 B per lane
-GATHER_KERNELS = {"msm_accumulate": 1.0}
+# (msm_accumulate_full gathers 64-byte points from the digit tables the same way -- ADVICE r3; the batched-affine kernels'
+#  first round gathers the same table rows)
+GATHER_KERNELS = {"msm_accumulate": 1.0, "msm_accumulate_full": 1.0}
 
 fetch, nf, nbat = per_launch(one("pmc_FETCH_SIZE/*/*_counter_collection.csv"))
 write, _, _ = per_launch(one("pmc_WRITE_SIZE/*/*_counter_collection.csv"))
 out = {"_note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of ONE prover making lock-step batches of {BATCH} "
-                "(tools/profile_r03.sh: kernels serialised); counters are KB per dispatch; bytes per launch = "
+                "(tools/profile.sh: kernels serialised); counters are KB per dispatch; bytes per launch = "
                 "(fetch_correction * FETCH + WRITE) * 1024 averaged over the launches inside complete create_proof batches; "
                 "fetch_correction = 2 for kernels that stream 16 B per lane (the gfx950 halving, MI355X_MICROARCH.md), 1 for "
-                "msm_accumulate, whose reads are 64-byte gathers (profiles/r03/fetch_calibration.json: the counter is exact there)",
+                "msm_accumulate, whose reads are 64-byte gathers (profiles/{rnd}/fetch_calibration.json: the counter is exact there)",
        "proofs_per_launch": BATCH, "batches": nbat, "kernels": {}}
 for k in sorted(fetch, key=lambda k: -(2 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"])):
     f, w = fetch[k]["FETCH_SIZE"] / nf[k], write[k]["WRITE_SIZE"] / max(nf[k], 1)
@@ -121,7 +127,7 @@ per = {k: sq1[k]["SQ_INSTS_VALU"] / (nb1 * BATCH) for k in sq1}
 total = sum(per.values())
 out["valu"] = {"_note": f"VALU wave-instructions one create_proof issues in the benchmarked form (lock-step batch of {BATCH}, split "
                         f"extended domain): SQ_INSTS_VALU summed over the kernels of a batch / {BATCH}, averaged over the run's batches",
-               "source": f"profiles/r03/{tag}_valu_instructions_per_proof.txt", "batches": nb1,
+               "source": f"profiles/{rnd}/{tag}_valu_instructions_per_proof.txt", "batches": nb1,
                "wave_instructions_per_proof": total, "by_kernel": dict(sorted(per.items(), key=lambda kv: -kv[1]))}
 json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 with open(os.path.join(dst, f"{tag}_valu_instructions_per_proof.txt"), "w") as f:
@@ -190,6 +196,38 @@ for k in sorted(ser, key=lambda k: -ser[k][1]):
     serial["kernels"][k] = {"launches_per_batch": ser[k][0] / len(tb), "avg_launch_us": ser[k][1] / ser[k][0] / 1e3,
                             "us_per_proof": ser[k][1] / (len(tb) * BATCH) / 1e3, "share": ser[k][1] / ser_total}
 json.dump(serial, open(os.path.join(dst, "serial_kernels.json"), "w"), indent=1)
+
+# ---- batched-affine A/B (tools/profile.sh with AFFINE=R): the MSM kernels' instructions and bytes per proof, both forms
+if glob.glob(os.path.join(src, "aff_sq1/*/*_counter_collection.csv")):
+    asq, an, anb = per_launch(one("aff_sq1/*/*_counter_collection.csv"))
+    af, anf, _ = per_launch(one("aff_FETCH_SIZE/*/*_counter_collection.csv"))
+    aw, _, _ = per_launch(one("aff_WRITE_SIZE/*/*_counter_collection.csv"))
+
+    def msm_side(sq, nbat_sq, fe, wr, nfe, nbat_f):
+        rows = {}
+        for k in sq:
+            if not k.startswith("msm_"):
+                continue
+            corr = 1.0 if (k in GATHER_KERNELS or k.startswith("msm_aff_a") or k.startswith("msm_aff_p")) else 2.0
+            by = (corr * fe[k]["FETCH_SIZE"] + wr[k]["WRITE_SIZE"]) * 1024 / (nbat_f * BATCH) if k in fe else None
+            rows[k] = {"valu_instr_per_proof": sq[k]["SQ_INSTS_VALU"] / (nbat_sq * BATCH), "us_per_proof_alone": sq[k]["ns"] / (nbat_sq * BATCH) / 1e3,
+                       "hbm_bytes_per_proof": by}
+        return {"kernels": dict(sorted(rows.items(), key=lambda kv: -kv[1]["valu_instr_per_proof"])),
+                "msm_valu_instr_per_proof": sum(r["valu_instr_per_proof"] for r in rows.values()),
+                "msm_us_per_proof_alone": sum(r["us_per_proof_alone"] for r in rows.values()),
+                "msm_hbm_bytes_per_proof": sum(r["hbm_bytes_per_proof"] or 0 for r in rows.values()),
+                "whole_proof_valu_instr": sum(sq[k]["SQ_INSTS_VALU"] for k in sq) / (nbat_sq * BATCH)}
+
+    ab = {"_note": "ZG_MSM_AFFINE = 0 against R rounds of batched-affine pre-reduction (csrc/msm.hip, aff_* kernels): ONE prover, batches of "
+                   f"{BATCH}, kernels serialised under counter collection; SQ_INSTS_VALU, FETCH_SIZE (x 2 for streaming kernels, x 1 for the "
+                   "64-byte gathers of msm_accumulate and of the affine rounds), WRITE_SIZE per proof; us_per_proof_alone = the kernels' "
+                   "durations under the counter pass",
+          "rounds": int(os.environ.get("AFFINE", "2")),
+          "without": msm_side(sq1, nb1, fetch, write, nf, nbat), "with": msm_side(asq, anb, af, aw, anf, anb)}
+    json.dump(ab, open(os.path.join(dst, "affine_ab.json"), "w"), indent=1)
+    print("affine A/B: MSM instructions per proof %.4g -> %.4g, MSM HBM bytes per proof %.4g -> %.4g, MSM us/proof alone %.1f -> %.1f" % (
+        ab["without"]["msm_valu_instr_per_proof"], ab["with"]["msm_valu_instr_per_proof"], ab["without"]["msm_hbm_bytes_per_proof"],
+        ab["with"]["msm_hbm_bytes_per_proof"], ab["without"]["msm_us_per_proof_alone"], ab["with"]["msm_us_per_proof_alone"]))
 
 shutil.copy(one("serial/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_one_prover_kernel_stats.csv"))
 shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_create_proof_kernel_stats.csv"))

@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-3 profile on the GPU box:  ./tools/profile_r03.sh TAG     (outputs under gpurun_out/prof_TAG/)
+# The round's profile set on the GPU box:  ./tools/profile.sh TAG     (outputs under gpurun_out/prof_TAG/; one script for every
+# round since round 4 -- tools/install_profile.py ROUND TAG files the summaries under profiles/ROUND/)
 #   1. SERIALISED kernel stats: rocprofv3 --kernel-trace --stats of ONE prover making lock-step batches of $BATCH (default 32; one
 #      stream: every kernel alone on the chip) -- the per-kernel table of DESIGN.md section 4
 #   2. the same trace of the default bench command (12 provers sharing the chip): the roofline object's cross-check
@@ -11,7 +12,9 @@
 #        FETCH_SIZE, WRITE_SIZE
 #   4. tools/fetch_calib.bin under FETCH_SIZE: what the counter reports for 16-B streaming reads and for 64-B / 32-B gathers
 #   5. the bench line itself, without the profiler
-# tools/install_r03.py TAG copies the summaries into profiles/r03/.
+#   6. (AFFINE=R, optional) the sq1 / FETCH_SIZE / WRITE_SIZE passes again with ZG_MSM_AFFINE=R: the counters behind the
+#      batched-affine A/B (instructions saved against bytes added)
+# tools/install_profile.py ROUND TAG copies the summaries into profiles/ROUND/.
 set -e
 [ -x tools/fetch_calib.bin ] || hipcc -O3 --offload-arch=gfx950 tools/fetch_calib.hip -o tools/fetch_calib.bin
 TAG=${1:-cur}
@@ -34,6 +37,15 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/calib -- $R/tools/fetch_calib.bin > $OUT/calib_true.json 2> $OUT/calib.log
 echo "calibration done"
+if [ -n "$AFFINE" ]; then
+  export ZG_MSM_AFFINE=$AFFINE
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/aff_sq1 -- python3 $R/bench.py $ONE > /dev/null 2> $OUT/aff_sq1.log
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $c --output-format csv -d $OUT/aff_$c -- python3 $R/bench.py $ONE > /dev/null 2> $OUT/aff_$c.log
+  done
+  unset ZG_MSM_AFFINE
+  echo "affine passes done"
+fi
 cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls $OUT
