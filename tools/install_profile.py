@@ -231,6 +231,11 @@ if glob.glob(os.path.join(src, "aff_sq1/*/*_counter_collection.csv")):
 
 shutil.copy(one("serial/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_one_prover_kernel_stats.csv"))
 shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_create_proof_kernel_stats.csv"))
+if os.path.exists(os.path.join(src, "lone_timeline_k14.txt")) and os.path.getsize(os.path.join(src, "lone_timeline_k14.txt")):
+    with open(os.path.join(dst, "lone_timeline_k14.txt"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace of tools/lone_proof.py tiny latency (one lone create_proof, digit tables), cut by tools/timeline.py\n")
+        f.write("# " + open(os.path.join(src, "lone.txt")).read().strip().replace("\n", "\n# ") + "\n")
+        f.write(open(os.path.join(src, "lone_timeline_k14.txt")).read())
 shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
 shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
 b = json.load(open(os.path.join(dst, f"{tag}_bench.json")))

@@ -12,6 +12,7 @@
 #        FETCH_SIZE, WRITE_SIZE
 #   4. tools/fetch_calib.bin under FETCH_SIZE: what the counter reports for 16-B streaming reads and for 64-B / 32-B gathers
 #   5. the bench line itself, without the profiler
+#   7. rocprofv3 --kernel-trace of tools/lone_proof.py: the timeline of one lone proof (tools/timeline.py)
 #   6. (AFFINE=R, optional) the sq1 / FETCH_SIZE / WRITE_SIZE passes again with ZG_MSM_AFFINE=R: the counters behind the
 #      batched-affine A/B (instructions saved against bytes added)
 # tools/install_profile.py ROUND TAG copies the summaries into profiles/ROUND/.
@@ -46,6 +47,10 @@ if [ -n "$AFFINE" ]; then
   unset ZG_MSM_AFFINE
   echo "affine passes done"
 fi
+# 7. the kernel timeline of a LONE proof (latency form, digit tables): tools/timeline.py cuts the last proof out of the trace
+rocprofv3 --kernel-trace --output-format csv -d $OUT/lone -- python3 $R/tools/lone_proof.py tiny latency > $OUT/lone.txt 2> $OUT/lone.log
+echo "lone trace done"
 cd $R
+python3 tools/timeline.py $(ls -t $OUT/lone/*/*_kernel_trace.csv | head -1) > $OUT/lone_timeline_k14.txt 2>> $OUT/lone.log || true
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 ls $OUT
