@@ -8,7 +8,7 @@ import sys
 
 rows = []
 for r in csv.DictReader(open(sys.argv[1])):
-    name = re.sub(r"^(void )?zg::", "", r["Kernel_Name"]).split("(")[0]
+    name = re.sub(r"^(void )?zg::", "", r["Kernel_Name"]).replace("(anonymous namespace)::", "").split("(")[0]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 # a proof starts at random_kernel (vanishing argument's random polynomial is generated first)
