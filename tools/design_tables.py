@@ -40,7 +40,7 @@ if ser and sq:
         split = f"{q['active']:.2f} / {q['issue_stall']:.2f} / {q['wait']:.2f}" if "active" in q else ""
         print(f"| `{k}` | {v['us_per_proof']:.1f} | {100 * v['share']:.1f} % | {v['launches_per_batch']:.0f} × {v['avg_launch_us']:.0f} | "
               f"{q.get('valu_issue_util', float('nan')):.2f} | {split} | {q.get('waves_per_simd', float('nan')):.2f} | "
-              f"{a.get('algo_GBps', float('nan')):.0f} ({a.get('frac_of_hbm_peak', float('nan')):.3f}) |")
+              + (f"{a['algo_GBps']:.0f} ({a['frac_of_hbm_peak']:.3f}) |" if "algo_GBps" in a else "— |"))
     w = sq["whole_proof_serialised"]
     print(f"| everything else | {other:.1f} | | | | | | |")
     print(f"| **whole proof, kernels one at a time** | **{ser['device_us_per_proof']:.0f}** | | | {w['valu_issue_util']:.2f} | | | |\n")
