@@ -458,10 +458,12 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __rest
                                                           const uint32_t* __restrict__ slot,
                                                           uint32_t* __restrict__ sorted, uint32_t naf, size_t cap, uint32_t B,
                                                           uint32_t chunks) {
-    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3, per_vec = chunks * windows;
-    const uint32_t b = xcd + 8u * (j / per_vec);
+    // (grid: x = 8 * chunks * windows blocks, the XCD in the low three bits; y = groups of eight vectors.  Blocks are
+    //  dispatched x first, so the XCD of block (x, y) is x mod 8 whatever y is -- gridDim.x is a multiple of eight)
+    const uint32_t xcd = blockIdx.x & 7u, r = blockIdx.x >> 3;
+    const uint32_t b = xcd + 8u * blockIdx.y;
     if (b >= B) return;
-    const uint32_t r = j % per_vec, w = r / chunks;
+    const uint32_t w = r / chunks;
     const uint32_t i = (r % chunks) * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t nb = 1u << (c - 1);
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(256) void aff_prefix_kernel(AffArgs a) {
     const bool runs = vj < 64 && ((a.run_mask >> vj) & 1ull);
     const Affine* table = vj < a.split ? (runs ? a.run_a : a.table_a) : (runs ? a.run_b : a.table_b);
     const uint32_t* so = a.sorted + (size_t)b * a.cap;
-    const Affine* prev = a.prev + (size_t)b * (a.cap >> (a.r - 1));
+    const Affine* prev = FIRST ? nullptr : a.prev + (size_t)b * (a.cap >> (a.r - 1));
     const size_t nl = (size_t)gridDim.y * a.lanes, fl = (size_t)b * a.lanes + l;
     F9 acc = Fq9Params::one();
 #pragma unroll 1
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(256) void aff_apply_kernel(AffArgs a) {
     const bool runs = vj < 64 && ((a.run_mask >> vj) & 1ull);
     const Affine* table = vj < a.split ? (runs ? a.run_a : a.table_a) : (runs ? a.run_b : a.table_b);
     const uint32_t* so = a.sorted + (size_t)b * a.cap;
-    const Affine* prev = a.prev + (size_t)b * (a.cap >> (a.r - 1));
+    const Affine* prev = FIRST ? nullptr : a.prev + (size_t)b * (a.cap >> (a.r - 1));
     Affine* out = a.out + (size_t)b * (a.cap >> a.r);
     const size_t nl = (size_t)gridDim.y * a.lanes, fl = (size_t)b * a.lanes + l;
     F9 u = ld_f9_soa(a.val, nl, fl);  // 1 / (product of this lane's denominators)
@@ -1339,31 +1341,95 @@ constexpr uint32_t MSM_TREE_GROUPS = 64;   // additions in flight per workgroup 
 constexpr uint32_t MSM_FULL_PAIRS = 128;   // lane pairs per workgroup of the accumulation (256 lanes)
 
 // full[(w * D + d - 1) * n + i] = d * win[w][i] for d = 1 .. D, affine, in the x * 2^261 form of every MSM table.  One
-// lane per (i, w): a chain of mixed additions, every multiple normalised by an inversion of its own (build time only).
+// lane per (i, w): a chain of mixed additions, normalised four multiples at a time -- and the INVERSION behind the
+// normalisation is shared by the whole wave: every lane multiplies up the denominators t = zz * zzz of its four points,
+// the 64 lane products are scanned both ways through LDS (six steps each), ONE lane inverts the wave's total, and every
+// lane gets 1 / (its own product) = (1 / T) * (lanes before) * (lanes after).  Round 3 spent a binary-Euclid inversion --
+// ~20 000 instructions, and divergent: every lane its own trip counts -- on each of the 4 * 10^8 multiples of a k = 14
+// table: 1.23 s per base set, 3.7 s per prover; build time only, but the call is explicit now and its cost is the caller's.
 __global__ __launch_bounds__(64) void msm_full_table_kernel(const Affine* __restrict__ win, Affine* __restrict__ full, uint32_t n,
                                                             uint32_t D, Fe un) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, w = blockIdx.y;
-    if (i >= n) return;
+    __shared__ XYZZ q[4][64];
+    __shared__ Fe sc[64];
+    __shared__ Fe tinv;
+    const uint32_t ln = threadIdx.x;
+    const uint32_t i = blockIdx.x * blockDim.x + ln, w = blockIdx.y;
     const Fe c261 = Fq9Params::c261_fe();
     Affine p;  // library form
-    p.x = Fq::mul(ld_fe_g(&win[(size_t)w * n + i].x), un);
-    p.y = Fq::mul(ld_fe_g(&win[(size_t)w * n + i].y), un);
+    p.x = fe_zero();
+    p.y = fe_zero();
+    if (i < n) {
+        p.x = Fq::mul(ld_fe_g(&win[(size_t)w * n + i].x), un);
+        p.y = Fq::mul(ld_fe_g(&win[(size_t)w * n + i].y), un);
+    }
+    // (a lane without a point -- past the end, or an identity base, whose every multiple is the identity -- stays in the
+    //  wave for the barriers and contributes the factor one)
+    const bool live = i < n && !affine_is_identity(p);
     Affine* dst = full + (size_t)w * D * n + i;
-    if (affine_is_identity(p)) {
+    if (i < n && !live)
         for (uint32_t d = 0; d < D; d++) {
             st_fe_g(&dst[(size_t)d * n].x, fe_zero());
             st_fe_g(&dst[(size_t)d * n].y, fe_zero());
         }
-        return;
+    XYZZ acc = xyzz_identity();
+    if (live) {
+        acc = xyzz_from_affine(p);
+        st_fe_g(&dst[0].x, Fq::mul(p.x, c261));
+        st_fe_g(&dst[0].y, Fq::mul(p.y, c261));
     }
-    XYZZ acc = xyzz_from_affine(p);
-    st_fe_g(&dst[0].x, Fq::mul(p.x, c261));
-    st_fe_g(&dst[0].y, Fq::mul(p.y, c261));
-    for (uint32_t d = 1; d < D; d++) {
-        acc = xyzz_madd(acc, p);  // (d + 1) P: never the identity, never P again -- P has prime order r > D
-        const Affine a = xyzz_to_affine(acc);
-        st_fe_g(&dst[(size_t)d * n].x, Fq::mul(a.x, c261));
-        st_fe_g(&dst[(size_t)d * n].y, Fq::mul(a.y, c261));
+    auto emit = [&](uint32_t j, const Fe& ti, uint32_t d) {  // ti = 1 / (zz zzz) of q[j]
+        if (!live || d >= D) return;
+        const XYZZ qq = q[j][ln];
+        const Fe ax = Fq::mul(qq.x, Fq::mul(ti, qq.zzz));   // X / ZZ
+        const Fe ay = Fq::mul(qq.y, Fq::mul(ti, qq.zz));    // Y / ZZZ
+        st_fe_g(&dst[(size_t)d * n].x, Fq::mul(ax, c261));
+        st_fe_g(&dst[(size_t)d * n].y, Fq::mul(ay, c261));
+    };
+    auto scan = [&](const Fe& mine, bool up) {  // inclusive product scan over the wave's lanes (the block IS one wave)
+        sc[ln] = mine;
+        __syncthreads();
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const bool has = up ? ln >= o : ln + o < 64;
+            Fe v = fe_zero();
+            if (has) v = sc[up ? ln - o : ln + o];
+            __syncthreads();
+            if (has) sc[ln] = Fq::mul(sc[ln], v);
+            __syncthreads();
+        }
+    };
+    for (uint32_t d0 = 1; d0 < D; d0 += 4) {
+        // (d + 1) P for d = d0 .. d0 + 3: never the identity, never P again -- P has prime order r > D; t = zz * zzz != 0
+        Fe t0 = Fq::one(), t1 = t0, t2 = t0, t3 = t0;
+        if (live) {
+            acc = xyzz_madd(acc, p);
+            q[0][ln] = acc;
+            t0 = Fq::mul(acc.zz, acc.zzz);
+            acc = xyzz_madd(acc, p);
+            q[1][ln] = acc;
+            t1 = Fq::mul(acc.zz, acc.zzz);
+            acc = xyzz_madd(acc, p);
+            q[2][ln] = acc;
+            t2 = Fq::mul(acc.zz, acc.zzz);
+            acc = xyzz_madd(acc, p);
+            q[3][ln] = acc;
+            t3 = Fq::mul(acc.zz, acc.zzz);
+        }
+        const Fe pre2 = Fq::mul(t0, t1), pre3 = Fq::mul(pre2, t2), mine = Fq::mul(pre3, t3);
+        scan(mine, true);
+        const Fe before = ln ? sc[ln - 1] : Fq::one();
+        if (ln == 63) tinv = Fq::inv(sc[63]);  // the ONE inversion of the wave's chunk (no factor is zero)
+        __syncthreads();
+        scan(mine, false);
+        const Fe after = ln < 63 ? sc[ln + 1] : Fq::one();
+        Fe inv = Fq::mul(Fq::mul(tinv, before), after);  // 1 / (t0 t1 t2 t3) of this lane
+        __syncthreads();
+        emit(3, Fq::mul(inv, pre3), d0 + 3);
+        inv = Fq::mul(inv, t3);
+        emit(2, Fq::mul(inv, pre2), d0 + 2);
+        inv = Fq::mul(inv, t2);
+        emit(1, Fq::mul(inv, t0), d0 + 1);
+        inv = Fq::mul(inv, t1);
+        emit(0, inv, d0);
     }
 }
 
@@ -1832,11 +1898,9 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_LAUNCH(ctx, "msm_scan", scan_bytes, msm_scan_kernel, dim3(B), dim3(1024), (size_t)(nb + 2) * 4, cnt, c, W, toff, tot,
               ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket, R, sorted, cap, heavy_thr);
     {
-        const uint32_t chunks = (N + 255) / 256;
-        const uint64_t blocks = 8ull * ((B + 7) / 8) * chunks * W;
-        ZG_REQUIRE(blocks < (1ull << 31), ZG_ERR_UNSUPPORTED, "zg_msm: scatter grid of %llu blocks", (unsigned long long)blocks);
-        ZG_LAUNCH(ctx, "msm_scatter", scat_bytes, msm_scatter_kernel, dim3((uint32_t)blocks), dim3(256), 0, dig, N, c, W, off, slot,
-                  sorted, naf, cap, B, chunks);
+        const uint32_t chunks = (N + 255) / 256;  // (chunks * W <= entries / 256 + W < 2^23)
+        ZG_LAUNCH(ctx, "msm_scatter", scat_bytes, msm_scatter_kernel, dim3(8u * chunks * W, (B + 7) / 8), dim3(256), 0, dig, N, c, W, off,
+                  slot, sorted, naf, cap, B, chunks);
     }
     const Affine* aff_pts = nullptr;
     for (uint32_t r = 1; r <= R; r++) {

@@ -391,8 +391,8 @@ int zg_prover_set_overlap(zg_prover *p, int enable);
 /* Builds the digit tables (zg_bases_enable_digit_table) of the prover's three base sets -- ParamsKZG::g, ::g_lagrange and
  * the running sums of g_lagrange -- which a LONE proof (zg_prover_set_overlap(p, 1)) then uses instead of Pippenger buckets:
  * 2.9 -> 2.2 ms per create_proof at k = 14.  Footprint: 3 x ceil(255 / c) * 2^(c-1) * n * 64 B -- 78 GB at n = 2^14 (c = 11),
- * 84 GB at n = 2^15 (c = 10) -- and ~1 s of build time per table, which is why it is an explicit call (round 3 built them
- * inside the first latency-form proof).  max_bytes = what the three tables may take together; 0 = the library's cap (a third
+ * 84 GB at n = 2^15 (c = 10) -- and ~0.3 s of build time per table (0.8 s for the three at n = 2^14), which is why it is an
+ * explicit call (round 3 built them inside the first latency-form proof, in 3.7 s).  max_bytes = what the three tables may take together; 0 = the library's cap (a third
  * of the card's memory, at most 90 GB) -- window bits shrink until they fit; nothing is built (not an error) when no width
  * fits, when n >= 2^16, when ZG_LAT_FULL_C = 0 or when the card has not that much free memory plus a reserve.
  * *bytes_built (may be NULL) = what is resident afterwards.  The tables belong to the base sets (shared by every prover on
