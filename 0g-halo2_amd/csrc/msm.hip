@@ -457,11 +457,13 @@ __global__ __launch_bounds__(256) void msm_scatter_kernel(const uint32_t* __rest
                                                           uint32_t windows, const uint32_t* __restrict__ off,
                                                           const uint32_t* __restrict__ slot,
                                                           uint32_t* __restrict__ sorted, uint32_t naf, size_t cap, uint32_t B,
-                                                          uint32_t chunks) {
-    // (grid: x = 8 * chunks * windows blocks, the XCD in the low three bits; y = groups of eight vectors.  Blocks are
-    //  dispatched x first, so the XCD of block (x, y) is x mod 8 whatever y is -- gridDim.x is a multiple of eight)
-    const uint32_t xcd = blockIdx.x & 7u, r = blockIdx.x >> 3;
-    const uint32_t b = xcd + 8u * blockIdx.y;
+                                                          uint32_t chunks, uint32_t by_xcd) {
+    // by_xcd (a launch of many vectors): grid x = 8 * chunks * windows blocks, the XCD in the low three bits; y = groups
+    // of eight vectors.  Blocks are dispatched x first, so the XCD of block (x, y) is x mod 8 whatever y is (gridDim.x is a
+    // multiple of eight).  A launch of FEW vectors (a lone proof commits 6 - 9) keeps the plain (chunk x window, vector)
+    // grid: confined to one XCD each, its vectors would leave most of the chip idle.
+    const uint32_t r = by_xcd ? blockIdx.x >> 3 : blockIdx.x;
+    const uint32_t b = by_xcd ? (blockIdx.x & 7u) + 8u * blockIdx.y : blockIdx.y;
     if (b >= B) return;
     const uint32_t w = r / chunks;
     const uint32_t i = (r % chunks) * blockDim.x + threadIdx.x;
@@ -1899,8 +1901,9 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
               ttotal, hmap, hlist, nheavy, max_heavy, off, MSM_K, stoff, sbucket, R, sorted, cap, heavy_thr);
     {
         const uint32_t chunks = (N + 255) / 256;  // (chunks * W <= entries / 256 + W < 2^23)
-        ZG_LAUNCH(ctx, "msm_scatter", scat_bytes, msm_scatter_kernel, dim3(8u * chunks * W, (B + 7) / 8), dim3(256), 0, dig, N, c, W, off,
-                  slot, sorted, naf, cap, B, chunks);
+        const bool by_xcd = B >= 64;  // (eight vectors per XCD and more: every XCD has its share of the launch)
+        ZG_LAUNCH(ctx, "msm_scatter", scat_bytes, msm_scatter_kernel, by_xcd ? dim3(8u * chunks * W, (B + 7) / 8) : dim3(chunks * W, B),
+                  dim3(256), 0, dig, N, c, W, off, slot, sorted, naf, cap, B, chunks, by_xcd ? 1u : 0u);
     }
     const Affine* aff_pts = nullptr;
     for (uint32_t r = 1; r <= R; r++) {

@@ -560,14 +560,14 @@ def main():
                     help="tiny = model_28input_256entry_1hash_1bpi (k=14, the BASELINE metric's configuration)")
     ap.add_argument("--batch", type=int, default=32, help="proofs per lock-step batch (zg_prover_prove_batch)")
     ap.add_argument("--provers", type=int, default=None,
-                    help="proof streams per GPU (provers sharing one proving key): 12; 4 in shard-msm, where every prover "
-                         "holds a communicator of its own")
+                    help="proof streams per GPU (provers sharing one proving key): 12; in shard-msm 4 with the host exchange "
+                         "(an exchange group per prover) and 1 with raw RCCL communicators")
     ap.add_argument("--mode", choices=["replicas", "shard-msm"], default="replicas")
     ap.add_argument("--exchange", choices=["host", "rccl"], default=None,
-                    help="shard-msm: all-gather inside the library on raw RCCL communicators, one per prover "
-                         "(zg_prover_set_shard_rccl; the default when every rank owns a GPU) or through a host callback on "
-                         "torch.distributed groups, one per prover (the default of one-GPU rehearsals: RCCL refuses two "
-                         "ranks on one device)")
+                    help="shard-msm: all-gather inside the library on a raw RCCL communicator per prover "
+                         "(zg_prover_set_shard_rccl; the default when every rank owns a GPU: ONE prover per rank then) or "
+                         "through a host callback on torch.distributed groups, one per prover (the default of one-GPU "
+                         "rehearsals: RCCL refuses two ranks on one device)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="no per-launch HIP events in the timed region (no roofline object)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of the other three models")
