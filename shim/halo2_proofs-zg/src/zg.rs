@@ -417,7 +417,18 @@ where
     let key = fingerprint(params_kzg, pk_g1, false);
     let mut cache = PROVERS.lock().unwrap();
     if !cache.contains_key(&key) {
-        cache.insert(key, build_handle(params_kzg, pk_g1)?);
+        let h = build_handle(params_kzg, pk_g1)?;
+        // The lone-proof digit tables (78 GB at k = 14, ~0.8 s to build) are the APPLICATION's decision since round 4: zero_g
+        // opts in with ZG_HALO2_DIGIT_TABLES=<max bytes> (0 = the library's cap); without it a lone proof keeps the bucket
+        // form (2.9 instead of 2.2 ms at k = 14) and the card keeps its memory.
+        if let Some(v) = std::env::var_os("ZG_HALO2_DIGIT_TABLES") {
+            let max_bytes: u64 = v.to_string_lossy().parse().unwrap_or(0);
+            let mut built: u64 = 0;
+            if unsafe { zg_prover_enable_digit_tables(h.prover, max_bytes, &mut built) } != 0 {
+                return None; // (the tables are an optimisation: a failure to build them is not a failure to prove -- but say so)
+            }
+        }
+        cache.insert(key, h);
     }
     let h = cache.get(&key)?;
     let cs = pk.get_vk().cs(); // ConstraintSystem<Scheme::Scalar>
