@@ -227,9 +227,11 @@ enum Knob : int {
     K_MSM_AFFINE,     // rounds of batched-affine pairwise additions before the bucket chains, throughput form (0..4)
     K_MSM_HEAVY,      // task partials above which a bucket is merged by msm_heavy instead of its strip's lane (1..64)
     K_LAT_PULL,       // 1 = a lone proof's per-phase scalars are pulled from pinned host memory by a one-wave kernel (no copy command)
+    K_LAT_GATE,       // 1 = a lone proof queues each phase before the previous one's challenge exists, behind a gate word the host opens
     K_COUNT
 };
 int knob(Knob k);
+bool runtime_serialises_launches();  // AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING are set: no launch may wait for the host
 
 // prover.hip: what a witness program has to match before it may write into a prover's advice slots (witness.hip)
 struct ProverShape {

@@ -20,18 +20,27 @@ void set_error(const char* fmt, ...) {
 static const char* const kKnobNames[K_COUNT] = {"ZG_MSM_C", "ZG_MSM_K", "ZG_MSM_K_LAT", "ZG_MSM_RB", "ZG_MSM_LANES", "ZG_MSM_STRIP",
                                                 "ZG_MSM_NAF", "ZG_MSM_NAF_GL", "ZG_MSM_RUNS", "ZG_EVALH_GROUPED", "ZG_EVALH9",
                                                 "ZG_SPLIT_DOMAIN", "ZG_LAT_SPLIT_K", "ZG_LAT_FULL_C", "ZG_LAT_FULL_K", "ZG_LAZY_DOT",
-                                                "ZG_MSM_AFFINE", "ZG_MSM_HEAVY", "ZG_LAT_PULL"};
+                                                "ZG_MSM_AFFINE", "ZG_MSM_HEAVY", "ZG_LAT_PULL", "ZG_LAT_GATE"};
+// (read beside the knobs, not knobs: settings of the HIP RUNTIME under which every launch completes before the next one is
+//  submitted -- a stream that waits for the host, ZG_LAT_GATE, must not be started then)
+static const char* const kRuntimeSerialising[2] = {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"};
 static std::atomic<int> g_knobs[K_COUNT];
+static std::atomic<bool> g_runtime_serialises{false};
 static std::once_flag g_knobs_once;
 static void knobs_init() {
-    for (int i = 0; i < K_COUNT; i++) {
-        const char* e = getenv(kKnobNames[i]);  // the ONLY getenv of the library
-        g_knobs[i].store(e && *e ? atoi(e) : -1, std::memory_order_relaxed);
+    for (int i = 0; i < K_COUNT + 2; i++) {
+        const char* e = getenv(i < K_COUNT ? kKnobNames[i] : kRuntimeSerialising[i - K_COUNT]);  // the ONLY getenv of the library
+        if (i < K_COUNT) g_knobs[i].store(e && *e ? atoi(e) : -1, std::memory_order_relaxed);
+        else if (e && atoi(e)) g_runtime_serialises.store(true, std::memory_order_relaxed);
     }
 }
 int knob(Knob k) {
     std::call_once(g_knobs_once, knobs_init);
     return g_knobs[k].load(std::memory_order_relaxed);
+}
+bool runtime_serialises_launches() {
+    std::call_once(g_knobs_once, knobs_init);
+    return g_runtime_serialises.load(std::memory_order_relaxed);
 }
 static int knob_index(const char* name) {
     if (!name) return -1;

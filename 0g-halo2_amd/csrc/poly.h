@@ -146,8 +146,10 @@ int poly_perm_terms(zg_ctx* ctx, const DevCircuit& c, const Cols& cols, const Pr
 // starts from product j-1's value at row `last`.  num / den / tmp are flat ([q][n]); z of product q goes to
 // z + g * z_outer + j * n (z_outer = 0: flat).
 size_t poly_grand_product_tmp_elems(uint32_t n, uint32_t batch);
+// half: 0 = the whole sequence; 1 = only the launches up to the totals, 2 = only what follows them (the latency form's
+// host inversion of the totals -- a stream synchronisation -- and the apply launch): the two halves of one call, same arguments.
 int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
-                       uint32_t batch, uint32_t chain, uint32_t last, uint32_t per = 0, size_t z_outer = 0);
+                       uint32_t batch, uint32_t chain, uint32_t last, uint32_t per = 0, size_t z_outer = 0, int half = 0);
 // n_columns = advice + instance + fixed columns of the circuit, unit_share = the rows of EvaluationDomain's extended domain
 // this launch stands for (both only shape the profile's byte charges)
 int poly_evaluate_h(zg_ctx* ctx, const EvalHArgs& a, uint32_t en, uint32_t nb, uint32_t n_columns, double unit_share);

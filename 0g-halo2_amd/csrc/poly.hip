@@ -612,7 +612,7 @@ size_t poly_grand_product_tmp_elems(uint32_t n, uint32_t batch) {  // (room for 
 
 // the latency form's launch sequence (tmp: 2*batch*n + 2*batch*nblk + 2*batch elements)
 static int grand_product_blocks(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
-                                uint32_t batch, uint32_t chain, uint32_t last, uint32_t per, size_t z_outer) {
+                                uint32_t batch, uint32_t chain, uint32_t last, uint32_t per, size_t z_outer, int half) {
     const uint32_t nblk = (n + GP_BLOCK - 1) / GP_BLOCK;
     ZG_REQUIRE(nblk <= 1024, ZG_ERR_UNSUPPORTED, "grand product: n=%u > 2^18 not built", n);
     Fe* locn = tmp;
@@ -624,8 +624,9 @@ static int grand_product_blocks(zg_ctx* ctx, const Fe* num, const Fe* den, const
     // the UNIT: one running product = num, den in, z out = 3 n * 32 B, carried by the apply kernel; each
     // kernel's own streams beside it (the block-local products cross HBM between the launches)
     const double bytes = (double)batch * n * 96;
-    ZG_LAUNCH(ctx, "grand_product_local", (double)batch * n * 128, gp_local_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, num, den, locn,
-              locd, totn, totd, n, nblk);
+    if (half != 2)
+        ZG_LAUNCH(ctx, "grand_product_local", (double)batch * n * 128, gp_local_kernel, dim3(nblk, batch), dim3(GP_BLOCK), 0, num, den, locn,
+                  locd, totn, totd, n, nblk);
     // latency configuration: the host inverts the totals (one shared inversion) between the two launches
     const bool host_inv = ctx->msm_pair && batch <= FESET_MAX && batch == per;
     // (... which the totals kernel writes straight into the context's pinned, mapped host buffer: no copy command between
@@ -637,8 +638,13 @@ static int grand_product_blocks(zg_ctx* ctx, const Fe* num, const Fe* den, const
         h = reinterpret_cast<Fe*>(ctx->pinned);
         ZG_HIP(hipHostGetDevicePointer(&h_dev, ctx->pinned, 0));
     }
-    ZG_LAUNCH(ctx, "grand_product_totals", (double)batch * nblk * 128, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
-              host_inv ? reinterpret_cast<Fe*>(h_dev) : tinv, zlast, n, nblk, last, host_inv ? 1u : 0u);
+    if (half != 2)
+        ZG_LAUNCH(ctx, "grand_product_totals", (double)batch * nblk * 128, gp_totals_kernel, dim3(batch), dim3(1024), 0, totn, totd, locn, locd,
+                  host_inv ? reinterpret_cast<Fe*>(h_dev) : tinv, zlast, n, nblk, last, host_inv ? 1u : 0u);
+    if (half == 1) {
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
     FeSet inv_set;
     memset(&inv_set, 0, sizeof(inv_set));
     if (host_inv) {
@@ -667,7 +673,7 @@ static int grand_product_blocks(zg_ctx* ctx, const Fe* num, const Fe* den, const
 
 
 int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0, Fe* z, Fe* tmp, uint32_t n,
-                       uint32_t batch, uint32_t chain, uint32_t last, uint32_t per, size_t z_outer) {
+                       uint32_t batch, uint32_t chain, uint32_t last, uint32_t per, size_t z_outer, int half) {
     if (!batch || !n) return ZG_OK;
     if (per == 0) {  // one group, results back to back
         per = batch;
@@ -675,7 +681,7 @@ int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0
     }
     ZG_REQUIRE(batch % per == 0, ZG_ERR_INVALID_ARG, "grand product: %u products in groups of %u", batch, per);
     if (batch == per) z_outer = 0;
-    if (ctx->msm_pair && n <= (1u << 18)) return grand_product_blocks(ctx, num, den, d_z0, z, tmp, n, batch, chain, last, per, z_outer);
+    if (ctx->msm_pair && n <= (1u << 18)) return grand_product_blocks(ctx, num, den, d_z0, z, tmp, n, batch, chain, last, per, z_outer, half);
     const uint32_t lanes = n < GP_LANES ? n : GP_LANES;
     const uint32_t strip = (n + lanes - 1) / lanes;
     Fe* locd = tmp;
@@ -685,14 +691,19 @@ int poly_grand_product(zg_ctx* ctx, const Fe* num, const Fe* den, const Fe* d_z0
     const double bytes = (double)batch * n * 96;
     // latency configuration: the host inverts the totals (one shared inversion) between the two launches
     const bool host_inv = ctx->msm_pair && batch <= FESET_MAX && batch == per;
-    ZG_LAUNCH(ctx, "grand_product_scan", bytes, gp_strip_scan_kernel, dim3(batch), dim3(GP_LANES), 0, num, den, locd, aux, tinv,
-              zlast, n, lanes, strip, last, host_inv ? 1u : 0u);
+    if (half != 2)
+        ZG_LAUNCH(ctx, "grand_product_scan", bytes, gp_strip_scan_kernel, dim3(batch), dim3(GP_LANES), 0, num, den, locd, aux, tinv,
+                  zlast, n, lanes, strip, last, host_inv ? 1u : 0u);
+    if (host_inv) ZG_TRY(pinned_reserve(ctx, 4096));
+    Fe* h = reinterpret_cast<Fe*>(ctx->pinned);
+    if (host_inv && half != 2) ZG_HIP(hipMemcpyAsync(h, tinv, batch * sizeof(Fe), hipMemcpyDeviceToHost, ctx->stream));
+    if (half == 1) {
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
     FeSet inv_set;
     memset(&inv_set, 0, sizeof(inv_set));
     if (host_inv) {
-        ZG_TRY(pinned_reserve(ctx, 4096));
-        Fe* h = reinterpret_cast<Fe*>(ctx->pinned);
-        ZG_HIP(hipMemcpyAsync(h, tinv, batch * sizeof(Fe), hipMemcpyDeviceToHost, ctx->stream));
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         // Montgomery's trick: prefix products, one inversion, walk back (a zero total inverts to zero, as Fr::inv does)
         Fe pre[FESET_MAX], acc = Fr::one();

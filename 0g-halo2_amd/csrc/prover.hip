@@ -183,7 +183,19 @@ struct zg_prover {
     uint32_t* d_idx = nullptr;  // index lists (circuit only: the same for every proof)
     std::map<uint32_t*, std::vector<uint32_t>> uploaded_lists;  // what h2d_list left at each destination
     std::vector<size_t> inst_filled;  // per slot: rows of inst_val that may be non-zero
-    hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr, ev_err = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_err = nullptr;
+    // One event per WAIT of a proof (the five commitment phases and the evaluations): with the gate (below) the next phase's
+    // launches -- and its commit's event record -- are queued before the host waits for this one, so they cannot share one.
+    static constexpr int N_WAITS = 6;
+    hipEvent_t evs[N_WAITS] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // The gate of a lone proof (ZG_LAT_GATE, ProveBatch::run): a word of the pinned arena that gate_pull_kernel polls and
+    // the host writes once the next challenge is staged -- the next phase is then already in the queue behind that kernel.
+    // gate_word()[0] = the last gate opened (a sequence number), [16] = the gate that gave up waiting, if any.
+    uint32_t gate_seq = 0;
+    uint32_t* gate_word() const { return reinterpret_cast<uint32_t*>((char*)pinned + pinned_cap - 128); }
+    // (what the last COMPLETED proof looked like -- ProveBatch::form_sig: a first proof in a form creates twiddle tables
+    //  and workspace, with stream synchronisations the gate must not stand in front of; only a repeat is gated)
+    uint64_t warm_sig = 0;
     void* pinned = nullptr;
     void* pinned_dev = nullptr;  // the same memory as the device addresses it (hipHostGetDevicePointer)
     size_t pinned_cap = 0, pin_results = 0, pin_evals = 0, pin_stage = 0;
@@ -230,6 +242,7 @@ Fe rotate_omega(const PkDev& k, const Fe& x, int32_t rot) {
     return Fr::mul(x, w);
 }
 
+constexpr int LAT_GATE_DEFAULT = 1;  // (ZG_LAT_GATE: ProveBatch::run)
 constexpr int LAT_PULL_DEFAULT = 1;  // (ZG_LAT_PULL: a lone proof's small uploads by a one-wave kernel instead of a copy command)
 // Small host->device transfers go through a pinned staging arena: hipMemcpyAsync from pageable memory
 // blocks the calling thread until the stream has drained up to the copy, which serialises host and
@@ -259,6 +272,32 @@ int h2d_list(zg_prover* p, uint32_t* d_dst, const std::vector<uint32_t>& list) {
 __global__ void pull_kernel(const uint4* __restrict__ src_mapped, uint4* __restrict__ dst, uint32_t n16) {
     for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src_mapped[i];
 }
+// The gate: ONE workgroup that waits until the host has written `seq` into the gate word (mapped, coherent host memory),
+// then copies the scalars the host staged BEFORE that store to where the kernels read them -- wait and upload in one
+// dispatch.  (hipStreamWaitValue32 + pull_kernel, the first version, were two: on this runtime the stream wait is itself
+// a spinning kernel, __amd_rocclr_streamOpsWait.)  Every wave reaches the end: a gate nobody opens within `max_ticks` of
+// the 100 MHz clock gives up, says so in *gave_up (the host then fails the proof) and leaves dst alone.
+__global__ void gate_pull_kernel(const uint32_t* gate, uint32_t seq, uint32_t* gave_up, uint64_t max_ticks, const uint4* __restrict__ src_mapped,
+                                 uint4* __restrict__ dst, uint32_t n16) {
+    __shared__ uint32_t open;
+    if (threadIdx.x == 0) {
+        const uint64_t t0 = wall_clock64();
+        uint32_t got = 1;
+        while (__hip_atomic_load(gate, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            if (wall_clock64() - t0 > max_ticks) {
+                got = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!got) __hip_atomic_store(gave_up, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        open = got;
+    }
+    __syncthreads();
+    if (!open) return;
+    for (uint32_t i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src_mapped[i];
+}
+constexpr uint64_t GATE_MAX_TICKS = 400000000ull;  // 4 s: a host thread that is merely descheduled comes back sooner
 int h2d(zg_prover* p, void* d_dst, const void* src, size_t bytes) {
     const void* s = stage(p, src, bytes);
     const int pull = knob(K_LAT_PULL);
@@ -349,7 +388,7 @@ __global__ void xyzz_sum_ranks_kernel(const XYZZ* __restrict__ parts, uint32_t w
 }
 
 int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, const Fe* scalars, size_t stride, size_t per,
-           size_t outer, size_t count, uint64_t run_mask, uint32_t naf_width = 0) {
+           size_t outer, size_t count, uint64_t run_mask, uint32_t naf_width = 0, int wait_ix = 0) {
     ZG_REQUIRE(count <= p->maxv * (size_t)p->cap, ZG_ERR_INVALID_ARG, "zg_prover: %zu commitments in one phase", count);
     // The last kernel of the MSM writes its sums straight into the pinned host buffer the transcript reads (the memory is
     // mapped into the device's address space): no copy command between the MSM and the host -- a command costs a lone
@@ -367,16 +406,16 @@ int commit(zg_prover* p, const zg_bases* a, const zg_bases* b2, size_t split, co
                   dim3((uint32_t)((count + 63) / 64)), dim3(64), 0, p->gathered, p->world, (uint32_t)count, h_out);
         ZG_HIP(hipGetLastError());
     }
-    ZG_HIP(hipEventRecord(p->ev, p->ctx->stream));
+    ZG_HIP(hipEventRecord(p->evs[wait_ix], p->ctx->stream));
     return ZG_OK;
 }
 // ... and waits for ONLY that launch sequence; with a sharded SRS the partial commitments of all ranks are exchanged
 // (all-gather) and summed here -- EC addition is not a reduction operator of the collective library
-int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out) {
+int wait_points(zg_prover* p, size_t count, std::vector<Jac>& out, int wait_ix = 0) {
     // (hipEventSynchronize already polls: the events are created without hipEventBlockingSync.  A hand-written
     //  hipEventQuery loop in its place never saw the event complete on this runtime -- round 3, gpurun_out/r3_t3.log --
     //  and bought nothing: the wait was never a sleep.)
-    ZG_HIP(hipEventSynchronize(p->ev));
+    ZG_HIP(hipEventSynchronize(p->evs[wait_ix]));
     const XYZZ* local = (const XYZZ*)((char*)p->pinned + p->pin_results);
     out.resize(count);
     if (p->world <= 1 || p->rccl_comm) {  // (whole sums already: a lone prover, or gathered and added on the device)
@@ -534,6 +573,7 @@ int alloc_slots_impl(zg_prover* p, uint32_t cap) {
     // hipEventReleaseToSystem event measured the same: 2.17 against 2.18 ms for a lone k = 14 proof).
     ZG_HIP(hipHostMalloc(&p->pinned, p->pinned_cap, hipHostMallocMapped | hipHostMallocCoherent));
     ZG_HIP(hipHostGetDevicePointer(&p->pinned_dev, p->pinned, 0));
+    memset((char*)p->pinned + p->pinned_cap - 4096, 0, 4096);  // (the margin behind the staging arena: zg_prover::gate_word)
     return ZG_OK;
 }
 
@@ -664,10 +704,11 @@ void zg_prover_destroy(zg_prover* p) {
         free_slots(p);
         if (p->gathered) (void)hipFree(p->gathered);
         p->owned_bases.reset();  // (the tables go with the last prover that uses them)
-        if (p->ev) (void)hipEventDestroy(p->ev);
         if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
         if (p->ev_join) (void)hipEventDestroy(p->ev_join);
         if (p->ev_err) (void)hipEventDestroy(p->ev_err);
+        for (hipEvent_t e : p->evs)
+            if (e) (void)hipEventDestroy(e);
         p->pk.reset();  // (the key's HBM goes with its last prover)
     }
     delete p;
@@ -690,10 +731,10 @@ int zg_prover_create_shared(zg_ctx* ctx, const zg_circuit* cs, const zg_fr* fixe
 }
 
 static int prover_events(zg_prover* p) {
-    ZG_HIP(hipEventCreateWithFlags(&p->ev, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
     ZG_HIP(hipEventCreateWithFlags(&p->ev_err, hipEventDisableTiming));
+    for (hipEvent_t& e : p->evs) ZG_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     return ZG_OK;
 }
 
@@ -1201,6 +1242,15 @@ struct ProveBatch {
     uint32_t npoints = 0;
     uint32_t* d_hlist = nullptr;
     const Fe* ev_all = nullptr;
+    uint32_t* h_err = nullptr;  // the lookups' error words on the host
+    uint32_t prod_per = 0;      // commitments per proof of the products phase (the random polynomial rides there without lookups)
+    uint32_t nsets = 0;         // opening point sets: list of set s at lists[s * 512 ..], its evaluation indices in list order
+    std::vector<uint32_t> lists, counts, set_slot;
+    std::vector<std::vector<size_t>> set_evs;
+    // ---- the gate (run())
+    enum Wait { W_ADVICE, W_PERMUTED, W_PRODUCTS, W_QUOTIENT, W_EVALS, W_GWC };
+    bool gated = false, armed = false;
+    void* gate_slot = nullptr;
     clk::time_point t_start, t_prev;
 #ifdef ZG_TICKS
     TickLog ticks;
@@ -1265,17 +1315,105 @@ struct ProveBatch {
         return ZG_OK;
     }
 
+    // The phases of create_proof, each in two halves: X_queue() puts the phase's device work on the streams (it needs only
+    // the circuit and what the device already holds -- every challenge reaches the kernels through d_pc), X_absorb() waits
+    // for the phase's results, writes them into the transcripts and PUBLISHES the next challenge (publish(): hpc -> d_pc).
+    //
+    // Plain order: queue, absorb, queue, absorb ...  A lone proof with the gate (ZG_LAT_GATE) queues the NEXT phase before
+    // it absorbs this one: arm() reserves a staging slot and puts gate_pull_kernel on the stream (it waits for the gate
+    // word, then copies the slot to d_pc), the next phase's launches follow behind it, and publish() fills the slot and
+    // opens the gate -- between the host having a challenge and the device using it stands one store, not a launch
+    // sequence.  What follows the grand products' totals is never queued ahead: it starts with the HOST inverting them.
     int run() {
         begin();
         ZG_TRY(load_inputs());
-        ZG_TRY(commit_advice());
-        ZG_TRY(commit_permuted());
-        ZG_TRY(commit_products());
-        ZG_TRY(quotient());
-        ZG_TRY(evaluations());
-        ZG_TRY(openings());
+        gated = gate_wanted();
+        ZG_TRY(advice_queue());
+        if (!gated) {
+            ZG_TRY(advice_absorb());
+            ZG_TRY(permuted_queue());
+            ZG_TRY(permuted_absorb());
+            ZG_TRY(products_terms_queue());
+            ZG_TRY(products_queue());
+            ZG_TRY(products_absorb());
+            ZG_TRY(evaluation_lists());
+            ZG_TRY(quotient_queue());
+            ZG_TRY(quotient_absorb());
+            ZG_TRY(evaluations_queue());
+            ZG_TRY(openings_lists());
+            ZG_TRY(evaluations_absorb());
+            ZG_TRY(openings_queue());
+        } else {
+            ZG_TRY(arm());
+            ZG_TRY(permuted_queue());    // behind theta
+            ZG_TRY(advice_absorb());
+            ZG_TRY(arm());
+            ZG_TRY(products_terms_queue());  // behind beta, gamma
+            ZG_TRY(permuted_absorb());
+            ZG_TRY(products_queue());  // (starts with the host's share of the grand products: never queued ahead)
+            ZG_TRY(evaluation_lists());
+            ZG_TRY(arm());
+            ZG_TRY(quotient_queue());    // behind y
+            ZG_TRY(products_absorb());
+            ZG_TRY(arm());
+            ZG_TRY(evaluations_queue());  // behind x
+            ZG_TRY(quotient_absorb());
+            ZG_TRY(openings_lists());
+            ZG_TRY(arm());
+            ZG_TRY(openings_queue());    // behind v
+            ZG_TRY(evaluations_absorb());
+        }
+        ZG_TRY(openings_absorb());
         return finish();
     }
+
+    // ---- the gate
+    uint64_t form_sig() const {
+        return 1u | (uint64_t)p->use_side << 1 | (uint64_t)split << 2 | (uint64_t)(p->g->full_table.load() != nullptr) << 3 |
+               (uint64_t)(p->gl->full_table.load() != nullptr) << 4 | (uint64_t)ctx->msm_pair << 5 | (uint64_t)nb << 8;
+    }
+    bool gate_wanted() {
+        const int v = knob(K_LAT_GATE);
+        if ((v < 0 ? LAT_GATE_DEFAULT : v) == 0 || !p->use_side || nb != 1 || p->world > 1 || p->rccl_comm) return false;
+        if (p->warm_sig != form_sig()) return false;  // (first-use allocations and their synchronisations are behind us)
+        // (a runtime that completes every launch before it submits the next one would never reach publish())
+        const bool serialising = runtime_serialises_launches();
+        // room in the staging arena for the five gated uploads and the index lists behind them
+        const size_t need = 5 * ((size_t)nb * sizeof(ProofConst) + 64) + (256u << 10);
+        if (serialising || sizeof(ProofConst) % 16 != 0 || p->stage_off + need > p->pinned_cap - 4096) return false;
+        p->gate_word()[16] = 0;  // (no gate kernel is in flight between proofs)
+        return true;
+    }
+    int arm() {
+        const size_t bytes = (size_t)nb * sizeof(ProofConst);
+        const size_t off = (p->stage_off + 63) & ~size_t(63);
+        // (gate_wanted() checked the arena's room: a phase queued ahead WITHOUT its gate would run on the previous challenge)
+        ZG_REQUIRE(gated && !armed && off + bytes <= p->pinned_cap - 4096, ZG_ERR_INVALID_ARG, "zg_prover_prove: no room to arm the gate");
+        gate_slot = (char*)p->pinned + off;
+        p->stage_off = off + bytes;
+        if (++p->gate_seq == 0) ++p->gate_seq;
+        armed = true;  // (from here on somebody has to open it: ~ProveBatch)
+        uint32_t* gate_dev = reinterpret_cast<uint32_t*>((char*)p->pinned_dev + p->pinned_cap - 128);
+        const uint4* dev_view = reinterpret_cast<const uint4*>((const char*)p->pinned_dev + off);
+        ZG_LAUNCH(ctx, "gate_pull", (double)bytes * 2, gate_pull_kernel, dim3(1), dim3(256), 0, gate_dev, p->gate_seq, gate_dev + 16, GATE_MAX_TICKS,
+                  dev_view, (uint4*)p->d_pc, (uint32_t)(bytes / 16));
+        ZG_HIP(hipGetLastError());
+        return ZG_OK;
+    }
+    void open_gate() {
+        if (!armed) return;
+        __atomic_store_n(p->gate_word(), p->gate_seq, __ATOMIC_SEQ_CST);
+        armed = false;
+    }
+    // the per-proof scalars as the host holds them now -> d_pc: through the armed gate, else behind the work already queued
+    int publish() {
+        if (!armed) return upload_consts(p, nb);
+        memcpy(gate_slot, p->hpc.data(), (size_t)nb * sizeof(ProofConst));
+        open_gate();
+        return ZG_OK;
+    }
+    // (an error return between arm() and publish(): the queue must drain whatever it then computes)
+    ~ProveBatch() { open_gate(); }
 
     void begin() {
         p->have_last = false;
@@ -1325,11 +1463,13 @@ struct ProveBatch {
                 }
             }
         }
-
+        base_cols.fixed = pk.fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
+        base_cols.log_size = k; base_cols.rot_scale = 1;
+        base_cols.adv_bs = adv_bs; base_cols.inst_bs = inst_bs;
         return ZG_OK;
     }
 
-    int commit_advice() {
+    int advice_queue() {
         // ---- advice: commit (Lagrange basis)
         ZG_TRY(fork());
         if (I) {
@@ -1338,33 +1478,31 @@ struct ProveBatch {
             if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_inst, I));
         }
         if (A) {
-            ZG_TRY(commit(p, p->gl, nullptr, A, adv, n, A, adv_bs, (size_t)nb * A, 0));
+            ZG_TRY(commit(p, p->gl, nullptr, A, adv, n, A, adv_bs, (size_t)nb * A, 0, 0, W_ADVICE));
             const Grouping g = grouping(A, adv_bs, pp_bs);
             ZG_TRY(ntt_batch_to_dev(sx, adv, pp_at(p->ix_adv), n, (size_t)nb * A, k, pk.omega_inv, &pk.ifft_div, &g));
             if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_adv, A));
-            ZG_TICK("advice: queued");
-            ZG_TRY(wait_points(p, (size_t)nb * A, pts));
+        }
+        ZG_TICK("advice: queued");
+        return ZG_OK;
+    }
+    int advice_absorb() {
+        if (A) {
+            ZG_TRY(wait_points(p, (size_t)nb * A, pts, W_ADVICE));
             ZG_TICK("advice: points on the host");
             for (uint32_t b = 0; b < nb; b++)
                 for (uint32_t c = 0; c < A; c++) tr[b].write_point(pts[(size_t)b * A + c]);
         }
         for (uint32_t b = 0; b < nb; b++) p->hpc[b].theta = tr[b].squeeze();
         ZG_TICK("theta");
-        ZG_TRY(upload_consts(p, nb));
+        ZG_TRY(publish());
         ZG_TICK("theta uploaded");
         lap(0);
-
-        base_cols.fixed = pk.fixed_val; base_cols.advice = adv; base_cols.instance = p->inst_val;
-        base_cols.log_size = k; base_cols.rot_scale = 1;
-        base_cols.adv_bs = adv_bs; base_cols.inst_bs = inst_bs;
-
         return ZG_OK;
     }
 
-    int commit_permuted() {
+    int permuted_queue() {
         // ---- lookups: commit_permuted (+ the random polynomial's commitment)
-        random_commit.resize(nb);
-        have_random = false;
         if (NL) {
             // permute_expression_pair on the device: canonical keys (written by the compression kernel itself, with
             // the sentinel padding), bitonic sort of inputs and tables, scan-based construction of s' (sort.hip).
@@ -1383,20 +1521,27 @@ struct ProveBatch {
             p->phase_ms[7] = std::chrono::duration<double, std::milli>(clk::now() - t_sort).count();
             ZG_TRY(fork());
             // the lookups' error words leave on the side stream, beside the commitments (an event of their own)
-            uint32_t* h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
+            h_err = reinterpret_cast<uint32_t*>((char*)p->pinned + p->pin_evals + (size_t)p->cap * p->max_evals * sizeof(Fe));
             ZG_HIP(hipMemcpyAsync(h_err, d_err, m * sizeof(uint32_t), hipMemcpyDeviceToHost, ss));
             ZG_HIP(hipEventRecord(p->ev_err, ss));
             // (a' and s' are sorted: equal neighbours everywhere, so the run form leaves one entry per distinct value)
             const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);  // (both or neither)
             const uint64_t sorted_runs = cgl->run_table && 2 * NL < 64 ? (1ull << (2 * NL)) - 1ull : 0ull;
-            ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs, naf_gl_width(p)));
+            ZG_TRY(commit(p, cgl, cg, 2 * NL, p->perm, n, 2 * NL + 1, perm_bs, (size_t)nb * (2 * NL + 1), sorted_runs, naf_gl_width(p), W_PERMUTED));
             {
                 const Grouping g = grouping(2 * NL, perm_bs, pp_bs);
                 ZG_TRY(ntt_batch_to_dev(sx, p->perm, pp_at(p->ix_perm), n, (size_t)nb * 2 * NL, k, pk.omega_inv, &pk.ifft_div, &g));
             }
             if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_perm, 2 * NL));
-            ZG_TICK("permuted: queued");
-            ZG_TRY(wait_points(p, (size_t)nb * (2 * NL + 1), pts));
+        }
+        ZG_TICK("permuted: queued");
+        return ZG_OK;
+    }
+    int permuted_absorb() {
+        random_commit.resize(nb);
+        have_random = false;
+        if (NL) {
+            ZG_TRY(wait_points(p, (size_t)nb * (2 * NL + 1), pts, W_PERMUTED));
             ZG_HIP(hipEventSynchronize(p->ev_err));
             ZG_TICK("permuted: points on the host");
             for (uint32_t b = 0; b < nb; b++) {
@@ -1411,6 +1556,7 @@ struct ProveBatch {
             }
             have_random = true;
             if (nb == 1 && status[0] != ZG_OK) {  // a lone proof stops here, as upstream's `?` does
+                open_gate();  // (whatever was queued ahead runs out on stale scalars: nobody reads its results)
                 (void)hipStreamSynchronize(ss);
                 (void)hipStreamSynchronize(st);
                 if (statuses) statuses[0] = status[0];
@@ -1424,70 +1570,82 @@ struct ProveBatch {
             p->hpc[b].gamma = tr[b].squeeze();
         }
         ZG_TICK("beta, gamma");
-        ZG_TRY(upload_consts(p, nb));
+        ZG_TRY(publish());
         ZG_TICK("beta, gamma uploaded");
         lap(1);
-
         return ZG_OK;
     }
 
-    int commit_products() {
-        // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
+    // ---- permutation products (sets chained through z[n - bf - 1]) and lookup products
+    // (in two parts: the terms and the running products up to their totals need beta and gamma only; what follows the
+    //  totals begins, in the latency form, with the HOST inverting them -- it cannot be queued ahead of anything)
+    int products_terms_queue() {
         const uint32_t mb = S + NL;
         if (S) ZG_TRY(poly_perm_terms(ctx, pk.dc, base_cols, p->d_pc, nb, pk.sigma_val, pk.omega_tw, p->num, p->den, mb, n));
         // (a'_l / s'_l are interleaved in `perm`: two views with a stride of two columns)
         ZG_TRY(poly_lookup_terms(ctx, p->d_pc, nb, p->cin, p->ctab, p->perm, p->perm + n, (size_t)2 * n, perm_bs, p->num, p->den, mb, S, n, NL));
+        // all running products of the batch in one scan sequence; per proof the S permutation sets are chained
+        // through row n - bf - 1, the lookup products start from one
+        if (mb) ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, nb * mb, S, n - bf - 1, mb, zs_bs, 1));
+        ZG_TICK("product terms: queued");
+        return ZG_OK;
+    }
+    int products_queue() {
+        const uint32_t mb = S + NL;
         if (mb) {
-            // all running products of the batch in one scan sequence; per proof the S permutation sets are chained
-            // through row n - bf - 1, the lookup products start from one
-            ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, nb * mb, S, n - bf - 1, mb, zs_bs));
+            ZG_TRY(poly_grand_product(ctx, p->num, p->den, nullptr, p->zs, p->tmp, n, nb * mb, S, n - bf - 1, mb, zs_bs, 2));
             ZG_TRY(poly_blind_rows2(ctx, p->d_pc, nb, p->zs, zs_bs, n, S, TAG_PERM_Z, NL, TAG_LOOKUP_Z, n - bf, bf));  // (lz follows pz)
             // The products stay constant wherever a row changes nothing (every padding row of the circuit): they are
             // committed in the run form, sum_i (z_i - z_{i+1}) Q_i over the running sums Q of g_lagrange.
             const zg_bases *cgl = naf_of(p, p->gl), *cg = cgl == p->gl ? p->g : naf_of(p, p->g);
             const uint64_t z_runs = cgl->run_table && mb < 64 ? (1ull << mb) - 1ull : 0ull;
             ZG_TRY(fork());
-            uint32_t per = mb;
+            prod_per = mb;
             if (have_random) {
-                ZG_TRY(commit(p, cgl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs, naf_gl_width(p)));
+                ZG_TRY(commit(p, cgl, nullptr, mb, p->zs, n, mb, zs_bs, (size_t)nb * mb, z_runs, naf_gl_width(p), W_PRODUCTS));
             } else {  // no lookups: the random polynomial rides here instead (row mb of zs)
                 for (uint32_t b = 0; b < nb; b++)
                     ZG_HIP(hipMemcpyAsync(p->zs + b * zs_bs + (size_t)mb * n, random_row + b * perm_bs, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
-                per = mb + 1;
-                ZG_TRY(commit(p, cgl, cg, mb, p->zs, n, per, zs_bs, (size_t)nb * per, z_runs, naf_gl_width(p)));
+                prod_per = mb + 1;
+                ZG_TRY(commit(p, cgl, cg, mb, p->zs, n, prod_per, zs_bs, (size_t)nb * prod_per, z_runs, naf_gl_width(p), W_PRODUCTS));
             }
             {
                 const Grouping g = grouping(mb, zs_bs, pp_bs);
                 ZG_TRY(ntt_batch_to_dev(sx, p->zs, pp_at(p->ix_pz), n, (size_t)nb * mb, k, pk.omega_inv, &pk.ifft_div, &g));
             }
             if (phase_cosets) ZG_TRY(to_cosets(sx, p->ix_pz, mb));
-            ZG_TICK("products: queued");
-            ZG_TRY(wait_points(p, (size_t)nb * per, pts));
+        } else if (!have_random) {  // neither lookups nor permutation: commit the random polynomial on its own
+            ZG_TRY(commit(p, p->g, nullptr, 1, random_row, n, 1, perm_bs, nb, 0, 0, W_PRODUCTS));
+        }
+        ZG_TICK("products: queued");
+        return ZG_OK;
+    }
+    int products_absorb() {
+        const uint32_t mb = S + NL;
+        if (mb) {
+            ZG_TRY(wait_points(p, (size_t)nb * prod_per, pts, W_PRODUCTS));
             ZG_TICK("products: points on the host");
             for (uint32_t b = 0; b < nb; b++) {
-                const Jac* q = &pts[(size_t)b * per];
+                const Jac* q = &pts[(size_t)b * prod_per];
                 for (uint32_t i = 0; i < mb; i++) tr[b].write_point(q[i]);
                 if (!have_random) random_commit[b] = q[mb];
             }
-            have_random = true;
-        }
-        if (!have_random) {  // neither lookups nor permutation: commit the random polynomial on its own
-            ZG_TRY(commit(p, p->g, nullptr, 1, random_row, n, 1, perm_bs, nb, 0));
-            ZG_TRY(wait_points(p, nb, pts));
+        } else if (!have_random) {
+            ZG_TRY(wait_points(p, nb, pts, W_PRODUCTS));
             for (uint32_t b = 0; b < nb; b++) random_commit[b] = pts[b];
         }
+        have_random = true;
         for (uint32_t b = 0; b < nb; b++) tr[b].write_point(random_commit[b]);
-        ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
         for (uint32_t b = 0; b < nb; b++) evalh_consts(p->hpc[b], tr[b].squeeze(), hat, evalh_terms(pk));
         ZG_TICK("y");
-        ZG_TRY(upload_consts(p, nb));
+        ZG_TRY(publish());
         ZG_TICK("y uploaded");
         lap(2);
-
         return ZG_OK;
     }
 
-    int quotient() {
+    int quotient_queue() {
+        ZG_TRY(join());  // evaluate_h reads every coset the side stream produced
         // (throughput configuration: nothing overlaps, so every witness polynomial goes to its cosets here, in one batch per
         //  coset, instead of phase by phase)
         if (!phase_cosets) ZG_TRY(to_cosets(ctx, p->ix_adv, p->ncos));
@@ -1526,20 +1684,33 @@ struct ProveBatch {
             ZG_TRY(poly_split_combine(ctx, nb, hp, pp_bs, bc, tb, L2, c1, L1));                    // h = A - c1 B + X^L1 B
         }
         ctx->msm_dense_hint = true;  // (the quotient pieces are random vectors: every digit of every window is an addition)
-        const int st_h = commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0);
+        const int st_h = commit(p, dense_g(p), nullptr, Q, pp_at(p->ix_hpiece), n, Q, pp_bs, (size_t)nb * Q, 0, 0, W_QUOTIENT);
         ctx->msm_dense_hint = false;
         ZG_TRY(st_h);
         ZG_TICK("h: queued");
-        ZG_TRY(wait_points(p, (size_t)nb * Q, pts));
+        return ZG_OK;
+    }
+    // (h's commitments, then x and the opening points: needs evaluation_lists())
+    int quotient_absorb() {
+        ZG_TRY(wait_points(p, (size_t)nb * Q, pts, W_QUOTIENT));
         ZG_TICK("h: points on the host");
         for (uint32_t b = 0; b < nb; b++)
             for (uint32_t i = 0; i < Q; i++) tr[b].write_point(pts[(size_t)b * Q + i]);
-
+        for (uint32_t b = 0; b < nb; b++) {
+            ProofConst& c = p->hpc[b];
+            const Fe x = tr[b].squeeze();
+            c.xn = Fr::pow_u64(x, n);
+            for (uint32_t i = 0; i < npoints; i++) c.points[i] = rotate_omega(pk, x, rots[i]);
+        }
+        ZG_TICK("x");
+        ZG_TRY(publish());
+        ZG_TICK("x uploaded");
+        lap(3);
         return ZG_OK;
     }
 
-    int evaluations() {
-        // ---- evaluations
+    // ---- evaluations: which polynomial is evaluated at which opening point (circuit only)
+    int evaluation_lists() {
         // distinct opening points, in any order (the powers table is indexed by slot)
         rots = {0, 1, -1, -(int32_t)(bf + 1)};
         auto rot_slot = [&](int32_t r) -> uint32_t {
@@ -1578,16 +1749,9 @@ struct ProveBatch {
                    p->max_points);
         ZG_REQUIRE(evq.size() <= p->max_evals, ZG_ERR_UNSUPPORTED, "zg_prover_prove: too many evaluations");
 
-        for (uint32_t b = 0; b < nb; b++) {
-            ProofConst& c = p->hpc[b];
-            const Fe x = tr[b].squeeze();
-            c.xn = Fr::pow_u64(x, n);
-            for (uint32_t i = 0; i < npoints; i++) c.points[i] = rotate_omega(pk, x, rots[i]);
-        }
-        ZG_TICK("x");
-        ZG_TRY(upload_consts(p, nb));
-        ZG_TICK("x uploaded");
-        lap(3);
+        return ZG_OK;
+    }
+    int evaluations_queue() {
         // vanishing.evaluate: h(X) = sum_i xn^i h_i(X)
         d_hlist = p->d_idx + (size_t)4 * p->max_evals;
         {
@@ -1613,14 +1777,33 @@ struct ProveBatch {
         ZG_TRY(poly_dot(ctx, polys, nb, n, p->d_idx, p->d_idx + evq.size(), p->pw, pw_bs, (uint32_t)evq.size(),
                         reinterpret_cast<Fe*>((char*)p->pinned_dev + p->pin_evals), p->max_evals, distinct_polys, npoints));
         ev_all = reinterpret_cast<const Fe*>((char*)p->pinned + p->pin_evals);
+        ZG_HIP(hipEventRecord(p->evs[W_EVALS], st));
         ZG_TICK("evals: queued");
-        ZG_HIP(hipStreamSynchronize(st));
+        return ZG_OK;
+    }
+    // (the evaluations into the transcripts, then v and each point set's v-weighted evaluation: needs openings_lists())
+    int evaluations_absorb() {
+        ZG_HIP(hipEventSynchronize(p->evs[W_EVALS]));
         ZG_TICK("evals on the host");
-
+        for (uint32_t b = 0; b < nb; b++) {
+            const Fe* ev = ev_all + (size_t)b * p->max_evals;
+            for (size_t i = 0; i < e_written; i++) tr[b].write_scalar(ev[i]);
+            ProofConst& c = p->hpc[b];
+            c.v = tr[b].squeeze();
+            for (uint32_t s = 0; s < nsets; s++) {
+                Fe eval_batch = fe_zero();
+                for (size_t e : set_evs[s]) eval_batch = Fr::add(Fr::mul(eval_batch, c.v), ev[e]);
+                c.subs[s] = eval_batch;
+            }
+        }
+        ZG_TICK("v");
+        ZG_TRY(publish());
+        ZG_TICK("v uploaded");
+        lap(4);
         return ZG_OK;
     }
 
-    int openings() {
+    int openings_lists() {
         // ---- opening queries in create_proof's order: (poly, point slot, index of the evaluation)
         struct OQ { uint32_t poly, slot; size_t ev; };
         std::vector<OQ> oq;
@@ -1656,9 +1839,8 @@ struct ProveBatch {
         oq.push_back({p->ix_random, 0, e_random});
 
         // ---- ProverGWC::create_proof: the point sets (circuit only), then per proof its v-weighted evaluation batches
-        uint32_t nsets = 0;
-        std::vector<uint32_t> lists, counts, set_slot;  // list of point set s at lists[s * 512 ..]
-        std::vector<std::vector<size_t>> set_evs;        // evaluation indices of set s, in list order
+        nsets = 0;
+        lists.clear(); counts.clear(); set_slot.clear(); set_evs.clear();
         {
             std::vector<char> done(oq.size(), 0);
             for (size_t first = 0; first < oq.size(); first++) {
@@ -1681,46 +1863,40 @@ struct ProveBatch {
         }
         ZG_REQUIRE(nsets <= HC_MAX_SETS, ZG_ERR_UNSUPPORTED, "zg_prover_prove: %u opening points", nsets);
         ZG_TICK("opening sets listed");
-        for (uint32_t b = 0; b < nb; b++) {
-            const Fe* ev = ev_all + (size_t)b * p->max_evals;
-            for (size_t i = 0; i < e_written; i++) tr[b].write_scalar(ev[i]);
-            ProofConst& c = p->hpc[b];
-            c.v = tr[b].squeeze();
-            for (uint32_t s = 0; s < nsets; s++) {
-                Fe eval_batch = fe_zero();
-                for (size_t e : set_evs[s]) eval_batch = Fr::add(Fr::mul(eval_batch, c.v), ev[e]);
-                c.subs[s] = eval_batch;
-            }
-        }
-        ZG_TICK("v");
-        ZG_TRY(upload_consts(p, nb));
-        ZG_TICK("v uploaded");
-        lap(4);
-        {
-            // poly_batch of every point set in one launch: set s -> wpoly[2s]
-            // (their own region of d_idx, behind the evaluation lists: nothing else writes there between proofs)
-            uint32_t* d_lists = d_hlist + 64;
-            ZG_TRY(h2d_list(p, d_lists, lists));
-            ZG_TRY(poly_horner_combine_sets(ctx, polys, p->d_pc, nb, d_lists, 512, counts.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, n));
-            // one batched kate_division: poly s at wpoly[2s], quotient at wpoly[2s+1]
-            ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
-                                      wp_bs, p->ktmp, n));
-            // the witness polynomials sit at odd slots: stride 2n
-            ctx->msm_dense_hint = true;  // (so are the opening quotients)
-            const int st_w = commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0);
-            ctx->msm_dense_hint = false;
-            ZG_TRY(st_w);
-            ZG_TICK("gwc: queued");
-            ZG_TRY(wait_points(p, (size_t)nb * nsets, pts));
-            ZG_TICK("gwc: points on the host");
-            for (uint32_t b = 0; b < nb; b++)
-                for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
-        }
+        return ZG_OK;
+    }
+    int openings_queue() {
+        // poly_batch of every point set in one launch: set s -> wpoly[2s]
+        // (their own region of d_idx, behind the evaluation lists: nothing else writes there between proofs)
+        uint32_t* d_lists = d_hlist + 64;
+        ZG_TRY(h2d_list(p, d_lists, lists));
+        ZG_TRY(poly_horner_combine_sets(ctx, polys, p->d_pc, nb, d_lists, 512, counts.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, n));
+        // one batched kate_division: poly s at wpoly[2s], quotient at wpoly[2s+1]
+        ZG_TRY(poly_kate_division(ctx, p->d_pc, nb, set_slot.data(), nsets, p->wpoly, (size_t)2 * n, wp_bs, p->wpoly + n, (size_t)2 * n,
+                                  wp_bs, p->ktmp, n));
+        // the witness polynomials sit at odd slots: stride 2n
+        ctx->msm_dense_hint = true;  // (so are the opening quotients)
+        const int st_w = commit(p, dense_g(p), nullptr, nsets, p->wpoly + n, (size_t)2 * n, nsets, wp_bs, (size_t)nb * nsets, 0, 0, W_GWC);
+        ctx->msm_dense_hint = false;
+        ZG_TRY(st_w);
+        ZG_TICK("gwc: queued");
+        return ZG_OK;
+    }
+    int openings_absorb() {
+        ZG_TRY(wait_points(p, (size_t)nb * nsets, pts, W_GWC));
+        ZG_TICK("gwc: points on the host");
+        for (uint32_t b = 0; b < nb; b++)
+            for (uint32_t s = 0; s < nsets; s++) tr[b].write_point(pts[(size_t)b * nsets + s]);
         return ZG_OK;
     }
 
     int finish() {
         int first_bad = ZG_OK;
+        if (gated && p->gate_word()[16] != 0) {  // (every gate kernel has ended: the last commitments came from behind them)
+            set_error("zg_prover_prove: a phase waited more than 4 s for its challenge and ran without it (ZG_LAT_GATE)");
+            for (uint32_t b = 0; b < nb; b++)
+                if (status[b] == ZG_OK) status[b] = ZG_ERR_HIP;
+        }
         for (uint32_t b = 0; b < nb; b++) {
             if (status[b] == ZG_OK && tr[b].failed) {
                 set_error("zg_prover_prove: a commitment of proof %u is the identity point; EvmTranscript cannot absorb it", b);
@@ -1743,6 +1919,7 @@ struct ProveBatch {
         lap(5);
         p->phase_ms[6] = std::chrono::duration<double, std::milli>(clk::now() - t_start).count();
         p->in_flight = false;
+        p->warm_sig = first_bad == ZG_OK ? form_sig() : 0;
         return first_bad;
     }
 };

@@ -68,7 +68,7 @@ const char *zg_version(void);
  * them all against the oracle).  Knobs that shape resident data are read when that object is built (ZG_MSM_C: a base
  * set registered with window_bits = 0; ZG_MSM_NAF, ZG_MSM_NAF_GL, ZG_MSM_RUNS, ZG_EVALH9, ZG_EVALH_GROUPED,
  * ZG_SPLIT_DOMAIN: zg_prover_create*; ZG_LAT_SPLIT_K: zg_prover_create* and zg_prover_set_overlap; ZG_LAT_FULL_C: zg_prover_enable_digit_tables), launch shapes at every launch (ZG_MSM_K, ZG_MSM_K_LAT, ZG_MSM_RB, ZG_MSM_LANES,
- * ZG_MSM_STRIP, ZG_LAT_FULL_K, ZG_LAZY_DOT, ZG_MSM_AFFINE, ZG_MSM_HEAVY, ZG_LAT_PULL).
+ * ZG_MSM_STRIP, ZG_LAT_FULL_K, ZG_LAZY_DOT, ZG_MSM_AFFINE, ZG_MSM_HEAVY, ZG_LAT_PULL, ZG_LAT_GATE).
  *   ZG_MSM_C          window bits of the MSM tables, 2..16 (default from n: k - 2)
  *   ZG_MSM_K          points per bucket-accumulation task in the throughput form, 4..120 (48)
  *   ZG_MSM_K_LAT      ... in the latency form (16; 32 / 48 from n = 2^16 / 2^17)
@@ -90,7 +90,11 @@ const char *zg_version(void);
  *   ZG_MSM_HEAVY      task partials of a bucket above which it is merged ahead of the bucket reduction (msm_heavy), 1..64
  *                     (4 in the throughput form, 16 in the latency form)
  *   ZG_LAT_PULL       1 = a lone proof's per-phase scalars (challenges, opening points) reach the device through a one-wave
- *                     kernel that reads the pinned staging arena, 0 = through a copy command */
+ *                     kernel that reads the pinned staging arena, 0 = through a copy command
+ *   ZG_LAT_GATE       1 = a lone proof (latency form, one proof per call, unsharded) puts each phase's launches on the stream
+ *                     BEFORE the host has the challenge they depend on, behind a wait on a signal word
+ *                     (hipStreamWaitValue32) that the host opens with one store once the challenge is staged; 0 = every
+ *                     phase is launched after its challenge.  Ignored where the device cannot wait on memory. */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */

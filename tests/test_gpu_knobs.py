@@ -36,6 +36,7 @@ SETTINGS = {
     "ZG_LAZY_DOT": [0],
     "ZG_MSM_AFFINE": [0, 1, 2, 3, 4],
     "ZG_LAT_PULL": [0, 1],
+    "ZG_LAT_GATE": [0, 1],
     "ZG_MSM_HEAVY": [1, 5, 64],
 }
 # knobs that act together: walked as pairs as well

@@ -67,6 +67,48 @@ def test_single_stream_schedule_gives_the_same_bytes(ctx, zg, orc):
     prover.close()
 
 
+def test_gated_lone_proofs_give_the_same_bytes(ctx, zg, orc):
+    """ZG_LAT_GATE: a repeated lone proof in the latency form queues each phase behind a gate kernel before the previous
+    phase's challenge exists (five gates per proof).  Same bytes as the oracle with the gate and without it; the first
+    proof in a form is never gated; a failing lookup under the gate is still ConstraintSystemFailure and stalls nothing."""
+    import time
+
+    cs, asg, ilen, pk, prover = setup(orc, zg, ctx, 9)
+    adv, inst = asg.advice_values(), asg.instance_values(ilen)
+    want = [orc.create_proof(pk, adv, inst, s)[1] for s in range(4)]
+    prover.set_overlap("tables")
+
+    def gate_launches(seed):
+        ctx.profile(True)
+        proof = prover.prove(adv, inst, seed)
+        stats = ctx.profile_collect()
+        ctx.profile(False)
+        assert proof == want[seed]
+        return stats["gate_pull"][0] if "gate_pull" in stats else 0
+
+    try:
+        zg.tuning_set("ZG_LAT_GATE", 1)
+        assert gate_launches(0) == 0  # (the first proof in this form: allocations and their synchronisations ahead)
+        assert gate_launches(1) == 5
+        zg.tuning_set("ZG_LAT_GATE", 0)
+        assert gate_launches(2) == 0
+        zg.tuning_set("ZG_LAT_GATE", 1)
+        assert gate_launches(3) == 5
+        bad = adv.copy()
+        bad[1, 2] = orc.fr_from_int(1000)
+        t0 = time.perf_counter()
+        with pytest.raises(zg.ZgError) as e:
+            prover.prove(bad, inst, 1)
+        assert e.value.status == -5
+        assert prover.prove(adv, inst, 2) == want[2]
+        assert time.perf_counter() - t0 < 2.0, "a gate waited for its timeout"
+        prover.set_overlap(False)  # (another form: ungated again, and the throughput form never is)
+        assert gate_launches(1) == 0
+    finally:
+        zg.tuning_set("ZG_LAT_GATE", -1)
+    prover.close()
+
+
 @pytest.mark.parametrize("force_degree,parts", [(None, "one coset: 4n is exact"), (6, "4n + n"), (7, "4n + 2n"), (8, "one coset: 7 is no sum of two powers of two")])
 def test_split_extended_domain_gives_the_same_bytes(ctx, zg, orc, force_degree, parts):
     """Throughput form (overlap off): the quotient comes from two cosets holding (degree - 1) * n points
