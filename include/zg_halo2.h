@@ -91,10 +91,11 @@ const char *zg_version(void);
  *                     (4 in the throughput form, 16 in the latency form)
  *   ZG_LAT_PULL       1 = a lone proof's per-phase scalars (challenges, opening points) reach the device through a one-wave
  *                     kernel that reads the pinned staging arena, 0 = through a copy command
- *   ZG_LAT_GATE       1 = a lone proof (latency form, one proof per call, unsharded) puts each phase's launches on the stream
- *                     BEFORE the host has the challenge they depend on, behind a wait on a signal word
- *                     (hipStreamWaitValue32) that the host opens with one store once the challenge is staged; 0 = every
- *                     phase is launched after its challenge.  Ignored where the device cannot wait on memory. */
+ *   ZG_LAT_GATE       1 (default) = a lone proof (latency form, one proof per call, unsharded; from the second proof in that
+ *                     form on) puts each phase's launches on the stream BEFORE the host has the challenge they depend on,
+ *                     behind a one-workgroup kernel that polls a word of mapped host memory; the host opens it with one
+ *                     store once the challenge is staged.  0 = every phase is launched after its challenge.  Ignored
+ *                     under AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING; a gate nobody opens for 4 s fails the proof. */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */
