@@ -48,7 +48,11 @@ if [ -n "$AFFINE" ]; then
   echo "affine passes done"
 fi
 # 7. the kernel timeline of a LONE proof (latency form, digit tables): tools/timeline.py cuts the last proof out of the trace
+#    (ZG_LAT_GATE=0: under the profiler a launch costs the host ~20 us, and the gated schedule launches the next phase BEFORE
+#     it reads this one's results -- the trace would show the profiler's overhead, not the schedule; tools/gate_ab.py measures it)
+export ZG_LAT_GATE=0
 rocprofv3 --kernel-trace --output-format csv -d $OUT/lone -- python3 $R/tools/lone_proof.py tiny latency > $OUT/lone.txt 2> $OUT/lone.log
+unset ZG_LAT_GATE
 echo "lone trace done"
 cd $R
 python3 tools/timeline.py $(ls -t $OUT/lone/*/*_kernel_trace.csv | head -1) > $OUT/lone_timeline_k14.txt 2>> $OUT/lone.log || true
