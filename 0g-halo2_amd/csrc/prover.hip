@@ -242,7 +242,12 @@ Fe rotate_omega(const PkDev& k, const Fe& x, int32_t rot) {
     return Fr::mul(x, w);
 }
 
-constexpr int LAT_GATE_DEFAULT = 1;  // (ZG_LAT_GATE: ProveBatch::run)
+// ZG_LAT_GATE (ProveBatch::run).  OFF unless asked for: a kernel that waits for the host is only safe while every stream
+// of the process has a hardware queue of its own (GPU_MAX_HW_QUEUES, default 4): packets of streams that share a queue
+// run in order, so this prover's side stream -- which the host waits for before it opens the next gate -- may sit behind
+// another stream's wait for work that itself sits behind the gate.  The kernel's time limit turns that cycle into a
+// stall and a second, plain run of the proof (prove_batch_impl), never into a hang or a wrong proof.
+constexpr int LAT_GATE_DEFAULT = 0;
 constexpr int LAT_PULL_DEFAULT = 1;  // (ZG_LAT_PULL: a lone proof's small uploads by a one-wave kernel instead of a copy command)
 // Small host->device transfers go through a pinned staging arena: hipMemcpyAsync from pageable memory
 // blocks the calling thread until the stream has drained up to the copy, which serialises host and
@@ -1250,6 +1255,9 @@ struct ProveBatch {
     // ---- the gate (run())
     enum Wait { W_ADVICE, W_PERMUTED, W_PRODUCTS, W_QUOTIENT, W_EVALS, W_GWC };
     bool gated = false, armed = false;
+    bool no_gate = false;       // (the second run of a proof whose gate gave up)
+    bool gate_gave_up = false;  // finish(): a gate kernel ran into its time limit -- the proof was made on stale scalars
+    uint32_t gates_armed = 0;
     void* gate_slot = nullptr;
     clk::time_point t_start, t_prev;
 #ifdef ZG_TICKS
@@ -1374,7 +1382,7 @@ struct ProveBatch {
     }
     bool gate_wanted() {
         const int v = knob(K_LAT_GATE);
-        if ((v < 0 ? LAT_GATE_DEFAULT : v) == 0 || !p->use_side || nb != 1 || p->world > 1 || p->rccl_comm) return false;
+        if (no_gate || (v < 0 ? LAT_GATE_DEFAULT : v) == 0 || !p->use_side || nb != 1 || p->world > 1 || p->rccl_comm) return false;
         if (p->warm_sig != form_sig()) return false;  // (first-use allocations and their synchronisations are behind us)
         // (a runtime that completes every launch before it submits the next one would never reach publish())
         const bool serialising = runtime_serialises_launches();
@@ -1395,8 +1403,11 @@ struct ProveBatch {
         armed = true;  // (from here on somebody has to open it: ~ProveBatch)
         uint32_t* gate_dev = reinterpret_cast<uint32_t*>((char*)p->pinned_dev + p->pinned_cap - 128);
         const uint4* dev_view = reinterpret_cast<const uint4*>((const char*)p->pinned_dev + off);
-        ZG_LAUNCH(ctx, "gate_pull", (double)bytes * 2, gate_pull_kernel, dim3(1), dim3(256), 0, gate_dev, p->gate_seq, gate_dev + 16, GATE_MAX_TICKS,
-                  dev_view, (uint4*)p->d_pc, (uint32_t)(bytes / 16));
+        // (ZG_LAT_GATE=2, for the tests: the proof's first gate is never opened by publish() and gives up after 0.2 s)
+        const bool lost = knob(K_LAT_GATE) == 2 && gates_armed == 0;
+        gates_armed++;
+        ZG_LAUNCH(ctx, "gate_pull", (double)bytes * 2, gate_pull_kernel, dim3(1), dim3(256), 0, gate_dev, lost ? p->gate_seq ^ 0x80000000u : p->gate_seq,
+                  gate_dev + 16, lost ? GATE_MAX_TICKS / 20 : GATE_MAX_TICKS, dev_view, (uint4*)p->d_pc, (uint32_t)(bytes / 16));
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
@@ -1894,8 +1905,9 @@ struct ProveBatch {
         int first_bad = ZG_OK;
         if (gated && p->gate_word()[16] != 0) {  // (every gate kernel has ended: the last commitments came from behind them)
             set_error("zg_prover_prove: a phase waited more than 4 s for its challenge and ran without it (ZG_LAT_GATE)");
-            for (uint32_t b = 0; b < nb; b++)
-                if (status[b] == ZG_OK) status[b] = ZG_ERR_HIP;
+            gate_gave_up = true;  // (nothing is handed out: prove_batch_impl makes the proof again in the plain order)
+            p->in_flight = false;
+            return ZG_ERR_HIP;
         }
         for (uint32_t b = 0; b < nb; b++) {
             if (status[b] == ZG_OK && tr[b].failed) {
@@ -1936,8 +1948,17 @@ static int prove_batch_impl(zg_prover* p, size_t count, const zg_fr* const* advi
     ZG_REQUIRE(p->world > 1 || p->shard_n == pk.n, ZG_ERR_INVALID_ARG,
                "zg_prover_prove: the base sets hold %u of %u points and no shard was declared (zg_prover_set_shard)", p->shard_n, pk.n);
     ZG_ENTER(p->ctx);
-    ProveBatch job(p, count, advice_host, advice_dev, instance, instance_len, keys, proofs, proof_cap, proof_lens, statuses);
-    return job.run();
+    {
+        ProveBatch job(p, count, advice_host, advice_dev, instance, instance_len, keys, proofs, proof_cap, proof_lens, statuses);
+        const int st = job.run();
+        if (!job.gate_gave_up) return st;
+    }
+    // A gate ran into its time limit (the host thread was away for seconds, or a stream that shares a hardware queue with
+    // this prover's stood in the way -- LAT_GATE_DEFAULT): the phases behind it ran on the previous challenge.  The inputs
+    // are where they were (the blinding rows are a function of the key): the same proof again, every phase after its challenge.
+    ProveBatch again(p, count, advice_host, advice_dev, instance, instance_len, keys, proofs, proof_cap, proof_lens, statuses);
+    again.no_gate = true;
+    return again.run();
 }
 
 int zg_prover_prove_batch(zg_prover* p, size_t count, const zg_fr* const* advice, const zg_fr* const* instance,

@@ -460,14 +460,26 @@ def latency_probe(stream: Stream):
     p.set_overlap(True)
     # the lone-proof digit tables (78 GB at k = 14): an explicit call since round 4, here before the timed proofs
     table_bytes = p.enable_digit_tables()
-    for _ in range(2):
-        p.prove_dev(p.advice_slot(0), c.instance, 1)
-    t0 = time.perf_counter()
-    for i in range(3):
-        p.prove_dev(p.advice_slot(0), c.instance, 2 + i)
-    latency_s = (time.perf_counter() - t0) / 3
+    # ... and so is the gate (ZG_LAT_GATE, include/zg_halo2.h): each phase queued behind a kernel that waits for the host's
+    # challenge.  Opt-in in the library -- it needs every stream of the process on a hardware queue of its own, which this
+    # process arranges (GPU_MAX_HW_QUEUES above) and during this probe no other stream has work.  LONE_PROOF_GATE says so
+    # in the line; ZG_LAT_GATE=0 in the environment keeps the probe plain.
+    gate = os.environ.get("ZG_LAT_GATE", "1") != "0"
+    if gate:
+        zg.tuning_set("ZG_LAT_GATE", 1)
+    try:
+        for _ in range(2):
+            p.prove_dev(p.advice_slot(0), c.instance, 1)
+        t0 = time.perf_counter()
+        for i in range(3):
+            p.prove_dev(p.advice_slot(0), c.instance, 2 + i)
+        latency_s = (time.perf_counter() - t0) / 3
+    finally:
+        if gate:
+            zg.tuning_set("ZG_LAT_GATE", -1)
     phases = p.phase_ms()
     p.set_overlap(False)
+    latency_probe.gate = gate
     return latency_s, phases, table_bytes
 
 
@@ -789,7 +801,8 @@ def main():
             "ranks_share_a_device": bool(world > 1 and "ZG_BENCH_DEVICE" in os.environ),
             "inputs": "host memory, uploaded per proof" if HOST_ADVICE else "resident in HBM",
             "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
-            "create_proof_wall_s": latency_s, "lone_proof_digit_table_bytes": table_bytes, "provers_per_gpu": nprov, "batch": batch,
+            "create_proof_wall_s": latency_s, "lone_proof_digit_table_bytes": table_bytes,
+            "lone_proof_gate": getattr(latency_probe, "gate", None), "provers_per_gpu": nprov, "batch": batch,
             "launches_per_proof": launches_per_proof,
             # SURVEY.md 8d's per-proof figure, twice: from its formula and as the library charged it launch by launch
             # (the units of the msm / ntt / evaluate_h / products families, each once) -- the two must agree

@@ -91,11 +91,16 @@ const char *zg_version(void);
  *                     (4 in the throughput form, 16 in the latency form)
  *   ZG_LAT_PULL       1 = a lone proof's per-phase scalars (challenges, opening points) reach the device through a one-wave
  *                     kernel that reads the pinned staging arena, 0 = through a copy command
- *   ZG_LAT_GATE       1 (default) = a lone proof (latency form, one proof per call, unsharded; from the second proof in that
- *                     form on) puts each phase's launches on the stream BEFORE the host has the challenge they depend on,
- *                     behind a one-workgroup kernel that polls a word of mapped host memory; the host opens it with one
- *                     store once the challenge is staged.  0 = every phase is launched after its challenge.  Ignored
- *                     under AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING; a gate nobody opens for 4 s fails the proof. */
+ *   ZG_LAT_GATE       1 = a lone proof (latency form, one proof per call, unsharded; from the second proof in that form on)
+ *                     puts each phase's launches on the stream BEFORE the host has the challenge they depend on, behind a
+ *                     one-workgroup kernel that polls a word of mapped host memory; the host opens it with one store once
+ *                     the challenge is staged (-1 to -2 % latency).  0 (default) = every phase is launched after its
+ *                     challenge.  OPT-IN because a kernel that waits for the host needs every stream of the process on a
+ *                     hardware queue of its own (GPU_MAX_HW_QUEUES >= the process's streams; two per latency-form prover):
+ *                     where streams share a queue another stream's work can stand between this prover's streams and the
+ *                     gate then only opens at its time limit (4 s), after which the proof is made again in the plain
+ *                     order -- a stall, never a wrong proof.  Ignored under AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING.
+ *                     (2: as 1, with the first gate of every proof left closed for 0.2 s -- exercises that path in tests.) */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */

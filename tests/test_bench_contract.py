@@ -21,6 +21,8 @@ def test_committed_bench_line_has_the_contracts_keys():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None  # (BASELINE.md publishes no number for this metric)
     assert "workload" in d["config"] and "model" not in d["config"]
     assert "model_28input_256entry_1hash_1bpi" in d["metric"]
+    # the lone proof's two explicit choices are named in the line: digit tables (bytes resident) and the gate (opt-in)
+    assert d["lone_proof_digit_table_bytes"] > 0 and d["lone_proof_gate"] is True
     # value is the whole job's rate over the timed region: steps x proofs per step / time
     assert abs(d["value"] - d["steps"] * d["proofs_per_step"] / (d["ms_per_step"] * d["steps"] / 1e3) * 3600.0) < 1e-6 * d["value"]
     r = d["roofline"]

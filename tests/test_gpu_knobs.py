@@ -36,7 +36,7 @@ SETTINGS = {
     "ZG_LAZY_DOT": [0],
     "ZG_MSM_AFFINE": [0, 1, 2, 3, 4],
     "ZG_LAT_PULL": [0, 1],
-    "ZG_LAT_GATE": [0, 1],
+    "ZG_LAT_GATE": [1],  # (engages from a prover's second proof in a form on: tests/test_gpu_prover.py walks it there)
     "ZG_MSM_HEAVY": [1, 5, 64],
 }
 # knobs that act together: walked as pairs as well

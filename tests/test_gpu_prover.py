@@ -68,8 +68,8 @@ def test_single_stream_schedule_gives_the_same_bytes(ctx, zg, orc):
 
 
 def test_gated_lone_proofs_give_the_same_bytes(ctx, zg, orc):
-    """ZG_LAT_GATE: a repeated lone proof in the latency form queues each phase behind a gate kernel before the previous
-    phase's challenge exists (five gates per proof).  Same bytes as the oracle with the gate and without it; the first
+    """ZG_LAT_GATE = 1 (opt-in): a repeated lone proof in the latency form queues each phase behind a gate kernel before the
+    previous phase's challenge exists (five gates per proof).  Same bytes as the oracle with the gate and without it; the first
     proof in a form is never gated; a failing lookup under the gate is still ConstraintSystemFailure and stalls nothing."""
     import time
 
@@ -102,6 +102,14 @@ def test_gated_lone_proofs_give_the_same_bytes(ctx, zg, orc):
         assert e.value.status == -5
         assert prover.prove(adv, inst, 2) == want[2]
         assert time.perf_counter() - t0 < 2.0, "a gate waited for its timeout"
+        # a gate nobody opens (knob value 2 leaves the proof's first gate closed): it gives up at its time limit, the phases
+        # behind it run on the previous challenge, and the library makes the proof again in the plain order -- right bytes
+        zg.tuning_set("ZG_LAT_GATE", 2)
+        t0 = time.perf_counter()
+        assert gate_launches(1) == 5
+        assert 0.15 < time.perf_counter() - t0 < 2.0
+        zg.tuning_set("ZG_LAT_GATE", 1)
+        assert gate_launches(0) == 5
         prover.set_overlap(False)  # (another form: ungated again, and the throughput form never is)
         assert gate_launches(1) == 0
     finally:
