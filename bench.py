@@ -39,6 +39,16 @@ sys.path.insert(0, os.path.join(ROOT, "harness"))
 # ROCm multiplexes a process's HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); every prover stream
 # should have a queue of its own, next to torch's and RCCL's.  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# Kernel arguments in device memory instead of host memory read over PCIe at every dispatch: -2.4 % on a lone proof's 73
+# launches (2.17 / 2.20 / 2.21 -> 2.14 / 2.15 / 2.13 ms, three alternations on one box, profiles/r04/ab_runtime_env.txt),
+# nothing on the throughput form.  A setting of the HIP runtime, read when it initialises: the process's to make
+# (INTEGRATION.md), not the library's.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Completion signals polled instead of waited for through an interrupt: a lone proof's host waits six times for the device
+# (2.121 / 2.130 / 2.133 -> 2.097 / 2.119 / 2.090 ms, three alternations, profiles/r04/ab_runtime_env.txt); the throughput
+# form is unchanged (0.6601 against 0.6606 ms/proof) -- its twelve host threads wait in turns.
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+RUNTIME_ENV = {k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "HIP_FORCE_DEV_KERNARG", "HSA_ENABLE_INTERRUPT")}
 
 import numpy as np
 import torch
@@ -802,7 +812,7 @@ def main():
             "inputs": "host memory, uploaded per proof" if HOST_ADVICE else "resident in HBM",
             "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
             "create_proof_wall_s": latency_s, "lone_proof_digit_table_bytes": table_bytes,
-            "lone_proof_gate": getattr(latency_probe, "gate", None), "provers_per_gpu": nprov, "batch": batch,
+            "lone_proof_gate": getattr(latency_probe, "gate", None), "runtime_env": RUNTIME_ENV, "provers_per_gpu": nprov, "batch": batch,
             "launches_per_proof": launches_per_proof,
             # SURVEY.md 8d's per-proof figure, twice: from its formula and as the library charged it launch by launch
             # (the units of the msm / ntt / evaluate_h / products families, each once) -- the two must agree
