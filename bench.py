@@ -478,12 +478,15 @@ def latency_probe(stream: Stream):
     if gate:
         zg.tuning_set("ZG_LAT_GATE", 1)
     try:
-        for _ in range(2):
+        for _ in range(3):
             p.prove_dev(p.advice_slot(0), c.instance, 1)
-        t0 = time.perf_counter()
-        for i in range(3):
+        each = []
+        for i in range(9):  # (one proof per measurement: the median of nine)
+            t0 = time.perf_counter()
             p.prove_dev(p.advice_slot(0), c.instance, 2 + i)
-        latency_s = (time.perf_counter() - t0) / 3
+            each.append(time.perf_counter() - t0)
+        latency_s = sorted(each)[len(each) // 2]
+        latency_probe.samples_ms = [round(x * 1e3, 4) for x in each]
     finally:
         if gate:
             zg.tuning_set("ZG_LAT_GATE", -1)
@@ -687,6 +690,7 @@ def main():
             x.sync()
 
     latency_s, phases, table_bytes = probed if probed else (None, [0.0] * 8, 0)
+    lone_samples_ms, lone_gate = (getattr(latency_probe, "samples_ms", None), getattr(latency_probe, "gate", None)) if probed else (None, None)
     # timed region: every launch carries its own start / stop event (hipExtLaunchKernelGGL on the prover's stream): a
     # lock-step batch is ~100 launches for `batch` proofs, so timing them all costs nothing measurable
     dt, stats = measure(streams, ctxs, args.steps, args.warmup, barrier, profile=not args.no_kernel_events)
@@ -812,7 +816,7 @@ def main():
             "inputs": "host memory, uploaded per proof" if HOST_ADVICE else "resident in HBM",
             "proofs_per_step": proofs_per_step, "ms_per_proof": ms_per_proof,
             "create_proof_wall_s": latency_s, "lone_proof_digit_table_bytes": table_bytes,
-            "lone_proof_gate": getattr(latency_probe, "gate", None), "runtime_env": RUNTIME_ENV, "provers_per_gpu": nprov, "batch": batch,
+            "create_proof_wall_ms_samples": lone_samples_ms, "lone_proof_gate": lone_gate, "runtime_env": RUNTIME_ENV, "provers_per_gpu": nprov, "batch": batch,
             "launches_per_proof": launches_per_proof,
             # SURVEY.md 8d's per-proof figure, twice: from its formula and as the library charged it launch by launch
             # (the units of the msm / ntt / evaluate_h / products families, each once) -- the two must agree
