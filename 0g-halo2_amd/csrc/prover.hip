@@ -507,6 +507,7 @@ void free_slots(zg_prover* p) {
     p->pinned = nullptr;
     p->cap = 0;
     p->uploaded_lists.clear();
+    p->warm_sig = 0;  // (new buffers: the next proof is a first proof again -- ProveBatch::gate_wanted)
 }
 
 int alloc_slots_impl(zg_prover* p, uint32_t cap);
