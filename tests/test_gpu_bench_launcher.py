@@ -1,7 +1,9 @@
-"""`python bench.py --gpus 2` end to end on the GPU box -- the driver's command shape: the process that
-parses the arguments starts its two ranks as a child torch.distributed.run, relays ONE JSON line, and that line says two
-GPUs and two ranks counted by the collective backend.  This pool has one GPU per box, so both ranks share cuda:0 and the
-backend is gloo (RCCL refuses two ranks on one device): a rehearsal of the plumbing, not a measurement."""
+"""`python bench.py ...` end to end on the GPU box, as the driver types it.  --gpus 2: the process that
+parses the arguments starts its two ranks as a child torch.distributed.run, relays ONE JSON line, and that line says two GPUs
+and two ranks counted by the collective backend.  This pool has one GPU per box, so both ranks share cuda:0 and the backend is
+gloo (RCCL refuses two ranks on one device): a rehearsal of the plumbing, not a measurement.  Since round 5
+every line is the compact one: < 4 KB, json round trip, `roofline` present (and `cpu_baseline` at N = 1), details in
+bench_detail.json."""
 import json
 import os
 import subprocess
@@ -10,28 +12,74 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config")
+
+
+def _run(argv, env_extra=None, timeout=900):
+    env = dict(os.environ, ZG_BENCH_STALL_S="240", **(env_extra or {}))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # the contract: ONE json line on stdout
+    assert len(lines[0].encode()) < 4096
+    d = json.loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert "roofline" in d and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    detail = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert detail["value"] == pytest.approx(d["value"], rel=1e-5)
+    return d, detail, r.stderr
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["replicas", "shard-msm"])
 def test_gpus_2_starts_two_ranks_and_says_so(mode):
-    env = dict(os.environ, ZG_BENCH_DEVICE="0", ZG_BENCH_BACKEND="gloo", ZG_BENCH_STALL_S="240")
-    env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", mode, "--steps", "1", "--warmup", "1",
-           "--provers", "2", "--batch", "4"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
-    assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines  # the contract: ONE json line on stdout
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["collective"]["ranks_seen"] == 2 and d["collective"]["backend"] == "gloo"
-    assert d["rccl_ranks"] is None and d["ranks_share_a_device"] is True
-    assert d["verified"] is True
+    d, detail, _ = _run(["--gpus", "2", "--mode", mode, "--steps", "1", "--warmup", "1", "--provers", "2", "--batch", "4"],
+                        {"ZG_BENCH_DEVICE": "0", "ZG_BENCH_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["collective"] == {"backend": "gloo", "ranks_seen": 2}
+    assert detail["rccl_ranks"] is None and detail["ranks_share_a_device"] is True
+    assert d["verified"] is True and "errors" not in d
     assert d["mode"] == mode and d["scaling"] == ("weak" if mode == "replicas" else "strong")
+    # the ranks of an N > 1 run do not get the lone probe's runtime settings
+    assert d["runtime_env"] == {"GPU_MAX_HW_QUEUES": "16"}
     # replicas: 2 ranks x 2 provers x 4 proofs per step; shard-msm: both ranks prove the SAME 2 x 4 proofs
-    assert d["proofs_per_step"] == 8
+    assert d["config"]["proofs_per_step"] == 8 and d["config"]["workload"].startswith("image -> proof")
     expect = 8 * (2 if mode == "replicas" else 1) / (d["ms_per_step"] / 1e3) * 3600.0
-    assert abs(d["value"] - expect) < 1e-6 * expect
+    assert abs(d["value"] - expect) < 1e-4 * expect
+
+
+@pytest.mark.gpu
+def test_msm_only_over_two_ranks_gathers_the_oracles_sums():
+    """the commitment MSMs by themselves, sharded by point range over two ranks (gloo, one card), ONE
+    all-gather per step; sampled sums == the oracle's best_multiexp over the whole vectors."""
+    d, detail, _ = _run(["--gpus", "2", "--mode", "msm-only", "--steps", "2", "--warmup", "1", "--batch", "2"],
+                        {"ZG_BENCH_DEVICE": "0", "ZG_BENCH_BACKEND": "gloo"})
+    assert d["unit"] == "MSMs/s" and d["n_gpus"] == 2 and d["collective"]["ranks_seen"] == 2 and d["scaling"] == "strong"
+    assert d["verified"] is True and d["mode"] == "msm-only" and detail["msms_per_step"] == 60 and detail["points_per_rank"] == 8192
+    assert abs(d["value"] - 2 * 60 / (2 * d["ms_per_step"] / 1e3)) < 1e-4 * d["value"]
+    assert d["roofline"]["kernel"] == "msm_accumulate"
+
+
+@pytest.mark.gpu
+def test_one_gpu_line_carries_roofline_cpu_baseline_and_both_lone_pairs():
+    """The driver's N = 1 shape at a small size (the other three models are left to the real bench): the headline is
+    image -> proof, the from-resident figure sits beside it, the lone proof is reported as opted-in AND as the library comes,
+    its gated proofs' bytes were re-made in the plain order, nothing failed."""
+    d, detail, err = _run(["--steps", "2", "--warmup", "1", "--provers", "2", "--batch", "4", "--no-other-configs"])
+    assert d["n_gpus"] == 1 and d["verified"] is True and "errors" not in d, detail.get("errors")
+    assert d["config"]["workload"].startswith("image -> proof") and d["from_resident_columns_ms_per_proof"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "proofs/hour" and c["value"] > 0
+    lo, ld = d["lone"]["opted_in"], d["lone"]["default"]
+    assert lo["gate"] is True and lo["digit_table_bytes"] > 0 and lo["bytes_equal_plain_order"] is True
+    assert ld["gate"] is False and ld["digit_table_bytes"] == 0 and ld["bytes_equal_plain_order"] is True
+    assert lo["witness_run_ms"] > 0 and lo["image_to_proof_ms"] > lo["create_proof_ms"]
+    assert detail["lone"]["default"]["runtime_env"] == {"GPU_MAX_HW_QUEUES": None, "HIP_FORCE_DEV_KERNARG": None, "HSA_ENABLE_INTERRUPT": None}
+    assert d["runtime_env"] == {"GPU_MAX_HW_QUEUES": "16", "HIP_FORCE_DEV_KERNARG": "1", "HSA_ENABLE_INTERRUPT": "0"}
+    assert d["roofline"]["serialised"]["frac"] >= d["roofline"]["frac"]
+    assert "headline" in err  # (written when the timed region ended, before the tail legs)
 
 
 @pytest.mark.gpu
