@@ -119,6 +119,19 @@ struct zg_ctx {
     double unit_next = -1.0;
     bool msm_dense_hint = false;  // set by a caller around an MSM whose vectors are all random (latency form: one lane per task)
     uint32_t* msm_tickets = nullptr;  // last-workgroup-done counters of the MSM reduction (msm.hip), zero between launches
+    // While a prover's gate kernel (prover.hip, ZG_LAT_GATE) spins on this context's stream -- or on the main stream this side
+    // context's stream follows -- the host must not WAIT for that stream before it has opened the gate.  Every path of the
+    // library that can block behind a stream from inside a proof (a workspace block that has to be allocated, a pinned arena
+    // that has to grow, a twiddle table made on first use, the MSM's ticket counters) calls gate_yield() first: it opens the
+    // gate at once and marks the proof as made on stale scalars (the prover makes it again in the plain order) -- a missed
+    // case costs one proof, never the gate's time limit.
+    struct GateHold {
+        uint32_t* word = nullptr;  // the gate word in mapped host memory; nullptr = no gate armed
+        uint32_t seq = 0;
+        bool yielded = false;
+        uint32_t yields = 0;
+    };
+    GateHold* gate_hold = nullptr;
 };
 
 struct zg_bases {
@@ -178,6 +191,8 @@ struct WsScope {
     }
 };
 int pinned_reserve(zg_ctx* ctx, size_t bytes);
+void gate_yield(zg_ctx* ctx);      // see zg_ctx::GateHold
+uint32_t tuning_generation();      // bumped by every zg_tuning_set (a warm prover's next proof is a first proof again)
 
 // Launch wrapper: when profiling is on, the dispatch carries a start and a stop event of its own
 // (hipExtLaunchKernelGGL: the timestamps are the kernel's begin and end, as rocprofv3 reports them -- events

@@ -60,6 +60,7 @@ void* ws_alloc(zg_ctx* ctx, size_t bytes) {
         return best->p;
     }
     void* p = nullptr;
+    gate_yield(ctx);  // (an allocation may wait for the device)
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) {
         set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -79,6 +80,7 @@ void ws_release(zg_ctx* ctx, void* p) {
 
 int pinned_reserve(zg_ctx* ctx, size_t bytes) {
     if (ctx->pinned_cap >= bytes) return ZG_OK;
+    gate_yield(ctx);
     if (ctx->pinned) {
         ZG_HIP(hipStreamSynchronize(ctx->stream));
         ZG_HIP(hipHostFree(ctx->pinned));
@@ -91,6 +93,19 @@ int pinned_reserve(zg_ctx* ctx, size_t bytes) {
     ctx->pinned_cap = cap;
     return ZG_OK;
 }
+
+void gate_yield(zg_ctx* ctx) {
+    zg_ctx::GateHold* h = ctx->gate_hold;
+    if (!h || !h->word) return;
+    h->yielded = true;
+    h->yields++;
+    __atomic_store_n(h->word, h->seq, __ATOMIC_SEQ_CST);
+    h->word = nullptr;
+}
+
+static std::atomic<uint32_t> g_tuning_generation{0};
+uint32_t tuning_generation() { return g_tuning_generation.load(std::memory_order_relaxed); }
+void bump_tuning_generation() { g_tuning_generation.fetch_add(1, std::memory_order_relaxed); }
 
 static hipEvent_t pool_event(zg_ctx* ctx) {
     if (!ctx->event_pool.empty()) {
@@ -145,6 +160,7 @@ int zg_tuning_set(const char* name, int value) {
     ZG_REQUIRE(i >= 0, ZG_ERR_INVALID_ARG, "zg_tuning_set: unknown knob %s", name ? name : "(null)");
     (void)knob((Knob)i);  // (the environment is read first, so that it cannot overwrite this value later)
     g_knobs[i].store(value < 0 ? -1 : value, std::memory_order_relaxed);
+    bump_tuning_generation();  // (a knob may change buffer sizes or forms: a warm prover's next proof is a first proof again)
     return ZG_OK;
 }
 int zg_tuning_get(const char* name, int* value) {
@@ -224,6 +240,28 @@ int zg_ctx_sync(zg_ctx* ctx) {
     ZG_ENTER(ctx);
     ZG_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->side) ZG_HIP(hipStreamSynchronize(ctx->side->stream));
+    return ZG_OK;
+}
+
+int zg_ctx_trim(zg_ctx* ctx, uint64_t* freed_bytes) {
+    ZG_REQUIRE(ctx != nullptr, ZG_ERR_INVALID_ARG, "zg_ctx_trim: ctx is null");
+    ZG_ENTER(ctx);
+    uint64_t freed = 0;
+    for (zg_ctx* c : {ctx, ctx->side}) {
+        if (!c) continue;
+        ZG_HIP(hipStreamSynchronize(c->stream));
+        std::vector<WsBlock> keep;
+        for (auto& b : c->pool) {
+            if (b.used) {
+                keep.push_back(b);
+            } else {
+                (void)hipFree(b.p);
+                freed += b.cap;
+            }
+        }
+        c->pool.swap(keep);
+    }
+    if (freed_bytes) *freed_bytes = freed;
     return ZG_OK;
 }
 

@@ -1820,6 +1820,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     ZG_REQUIRE(nblk <= 256 && nblk <= rb, ZG_ERR_UNSUPPORTED, "zg_msm: window_bits %u too large", c);
 
     if (!ctx->msm_tickets) {  // one ticket counter per vector of a batch; the kernels leave them at zero
+        gate_yield(ctx);
         ZG_HIP(hipMalloc(&ctx->msm_tickets, MSM_MAX_BATCH * sizeof(uint32_t)));
         ZG_HIP(hipMemset(ctx->msm_tickets, 0, MSM_MAX_BATCH * sizeof(uint32_t)));
     }

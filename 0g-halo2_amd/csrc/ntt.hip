@@ -314,6 +314,7 @@ int get_twiddles(zg_ctx* ctx, uint32_t log_n, const Fe& omega, Fe** out) {
     }
     uint32_t n = 1u << log_n;
     Fe* tw = nullptr;
+    gate_yield(ctx);  // (a new table: an allocation and a stream synchronisation)
     ZG_HIP(hipMalloc(&tw, (size_t)2 * n * sizeof(Fe)));
     uint32_t threads = 256, per = 16;
     uint32_t blocks = (n + threads * per - 1) / (threads * per);

@@ -196,6 +196,7 @@ struct zg_prover {
     // (what the last COMPLETED proof looked like -- ProveBatch::form_sig: a first proof in a form creates twiddle tables
     //  and workspace, with stream synchronisations the gate must not stand in front of; only a repeat is gated)
     uint64_t warm_sig = 0;
+    uint64_t gate_stats[4] = {0, 0, 0, 0};  // zg_prover_gate_stats
     void* pinned = nullptr;
     void* pinned_dev = nullptr;  // the same memory as the device addresses it (hipHostGetDevicePointer)
     size_t pinned_cap = 0, pin_results = 0, pin_evals = 0, pin_stage = 0;
@@ -1260,6 +1261,7 @@ struct ProveBatch {
     bool gate_gave_up = false;  // finish(): a gate kernel ran into its time limit -- the proof was made on stale scalars
     uint32_t gates_armed = 0;
     void* gate_slot = nullptr;
+    zg_ctx::GateHold hold;  // what a blocking call inside a queued-ahead phase needs to let the gate go (common.h)
     clk::time_point t_start, t_prev;
 #ifdef ZG_TICKS
     TickLog ticks;
@@ -1334,6 +1336,24 @@ struct ProveBatch {
     // opens the gate -- between the host having a challenge and the device using it stands one store, not a launch
     // sequence.  What follows the grand products' totals is never queued ahead: it starts with the HOST inverting them.
     int run() {
+        const int st_run = run_phases();
+        p->gate_stats[0] += gated ? 1 : 0;
+        p->gate_stats[1] += gates_armed;
+        p->gate_stats[3] += hold.yields;
+        // An error that surfaced BEHIND a failed gate (a time limit, a yield) is the stale scalars' doing, not the caller's:
+        // drain what was queued and let prove_batch_impl make the proof again in the plain order.
+        if (st_run != ZG_OK && !gate_gave_up && gate_failed()) {
+            open_gate();
+            (void)hipStreamSynchronize(st);
+            if (ctx->side) (void)hipStreamSynchronize(ctx->side->stream);
+            p->in_flight = false;
+            gate_gave_up = true;
+        }
+        if (gate_gave_up) p->gate_stats[2]++;
+        if (st_run != ZG_OK) p->warm_sig = 0;  // (whatever way a proof failed: the next one is a first proof)
+        return st_run;
+    }
+    int run_phases() {
         begin();
         ZG_TRY(load_inputs());
         gated = gate_wanted();
@@ -1378,8 +1398,13 @@ struct ProveBatch {
 
     // ---- the gate
     uint64_t form_sig() const {
+        // (everything that shapes the proof's allocation requests and launch sequence: a proof whose signature differs from
+        //  the last completed one's is a FIRST proof -- it may create tables and workspace, with synchronisations -- and is
+        //  never gated: scheduling form, domain split, digit tables, batch, instance length, and the tuning generation,
+        //  which every zg_tuning_set bumps)
         return 1u | (uint64_t)p->use_side << 1 | (uint64_t)split << 2 | (uint64_t)(p->g->full_table.load() != nullptr) << 3 |
-               (uint64_t)(p->gl->full_table.load() != nullptr) << 4 | (uint64_t)ctx->msm_pair << 5 | (uint64_t)nb << 8;
+               (uint64_t)(p->gl->full_table.load() != nullptr) << 4 | (uint64_t)ctx->msm_pair << 5 | (uint64_t)(nb & 0xFFu) << 8 |
+               (uint64_t)(instance_len & 0xFFFFu) << 16 | (uint64_t)tuning_generation() << 32;
     }
     bool gate_wanted() {
         const int v = knob(K_LAT_GATE);
@@ -1402,6 +1427,10 @@ struct ProveBatch {
         p->stage_off = off + bytes;
         if (++p->gate_seq == 0) ++p->gate_seq;
         armed = true;  // (from here on somebody has to open it: ~ProveBatch)
+        hold.word = p->gate_word();
+        hold.seq = p->gate_seq;
+        ctx->gate_hold = &hold;  // (... or gate_yield(), from a blocking call of the phase queued behind it)
+        if (ctx->side) ctx->side->gate_hold = &hold;
         uint32_t* gate_dev = reinterpret_cast<uint32_t*>((char*)p->pinned_dev + p->pinned_cap - 128);
         const uint4* dev_view = reinterpret_cast<const uint4*>((const char*)p->pinned_dev + off);
         // (ZG_LAT_GATE=2, for the tests: the proof's first gate is never opened by publish() and gives up after 0.2 s)
@@ -1416,16 +1445,23 @@ struct ProveBatch {
         if (!armed) return;
         __atomic_store_n(p->gate_word(), p->gate_seq, __ATOMIC_SEQ_CST);
         armed = false;
+        hold.word = nullptr;
     }
+    // a gate kernel ran into its time limit, or a blocking call let one go early: phases ran on the previous challenge
+    bool gate_failed() const { return gated && (p->gate_word()[16] != 0 || hold.yielded); }
     // the per-proof scalars as the host holds them now -> d_pc: through the armed gate, else behind the work already queued
     int publish() {
         if (!armed) return upload_consts(p, nb);
         memcpy(gate_slot, p->hpc.data(), (size_t)nb * sizeof(ProofConst));
-        open_gate();
+        open_gate();  // (a gate that gate_yield() already opened copied the previous scalars: gate_failed(), the proof is re-made)
         return ZG_OK;
     }
     // (an error return between arm() and publish(): the queue must drain whatever it then computes)
-    ~ProveBatch() { open_gate(); }
+    ~ProveBatch() {
+        open_gate();
+        if (ctx->gate_hold == &hold) ctx->gate_hold = nullptr;
+        if (ctx->side && ctx->side->gate_hold == &hold) ctx->side->gate_hold = nullptr;
+    }
 
     void begin() {
         p->have_last = false;
@@ -1567,6 +1603,7 @@ struct ProveBatch {
                 random_commit[b] = q[2 * NL];
             }
             have_random = true;
+            if (nb == 1 && status[0] != ZG_OK && gate_failed()) return ZG_ERR_HIP;  // (error words from behind a failed gate: run() re-makes the proof)
             if (nb == 1 && status[0] != ZG_OK) {  // a lone proof stops here, as upstream's `?` does
                 open_gate();  // (whatever was queued ahead runs out on stale scalars: nobody reads its results)
                 (void)hipStreamSynchronize(ss);
@@ -1904,8 +1941,9 @@ struct ProveBatch {
 
     int finish() {
         int first_bad = ZG_OK;
-        if (gated && p->gate_word()[16] != 0) {  // (every gate kernel has ended: the last commitments came from behind them)
-            set_error("zg_prover_prove: a phase waited more than 4 s for its challenge and ran without it (ZG_LAT_GATE)");
+        if (gate_failed()) {  // (every gate kernel has ended: the last commitments came from behind them)
+            set_error(hold.yielded ? "zg_prover_prove: a phase queued ahead of its challenge had to allocate or synchronise; its gate was let go (ZG_LAT_GATE)"
+                                   : "zg_prover_prove: a phase waited more than 4 s for its challenge and ran without it (ZG_LAT_GATE)");
             gate_gave_up = true;  // (nothing is handed out: prove_batch_impl makes the proof again in the plain order)
             p->in_flight = false;
             return ZG_ERR_HIP;
@@ -2039,6 +2077,12 @@ int zg_prover_enable_digit_tables(zg_prover* p, uint64_t max_bytes, uint64_t* by
 int zg_prover_phase_ms(const zg_prover* p, double* out, size_t cap) {
     ZG_REQUIRE(p && out, ZG_ERR_INVALID_ARG, "zg_prover_phase_ms: null argument");
     for (size_t i = 0; i < cap && i < 8; i++) out[i] = p->phase_ms[i];
+    return ZG_OK;
+}
+
+int zg_prover_gate_stats(const zg_prover* p, uint64_t* out, size_t cap) {
+    ZG_REQUIRE(p && out, ZG_ERR_INVALID_ARG, "zg_prover_gate_stats: null argument");
+    for (size_t i = 0; i < cap && i < 4; i++) out[i] = p->gate_stats[i];
     return ZG_OK;
 }
 

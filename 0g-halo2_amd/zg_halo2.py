@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "zg_domain_omega", "zg_ctx_profile_enable", "zg_ctx_profile_collect", "zg_params_new",
     "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
     "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
-    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_set_overlap", "zg_ctx_set_msm_latency",
+    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_gate_stats", "zg_ctx_trim", "zg_prover_set_overlap", "zg_ctx_set_msm_latency",
     "zg_prover_create_shared", "zg_prover_fork", "zg_prover_set_batch", "zg_prover_batch", "zg_prover_advice_slot",
     "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
@@ -229,6 +229,12 @@ class Ctx:
     def sync(self):
         _check(self.lib.zg_ctx_sync(self.h))
 
+    def drop_workspace(self) -> int:
+        """zg_ctx_trim: the free blocks of the workspace pool go back to the device allocator; returns the bytes freed"""
+        freed = ctypes.c_uint64(0)
+        _check(self.lib.zg_ctx_trim(self.h, ctypes.byref(freed)))
+        return freed.value
+
     @property
     def stream(self) -> int:
         return self.lib.zg_ctx_stream(self.h)
@@ -242,12 +248,14 @@ class Ctx:
     def profile_collect(self) -> dict:
         """{kernel: (launches, total_ms, algo_bytes, unit_bytes)} since the last collect; synchronises.  algo_bytes = what
         the kernel itself streams, unit_bytes = SURVEY 8d's figure of the units it carries (include/zg_halo2.h)."""
-        cap = 64
+        cap = 256  # (distinct ZG_LAUNCH labels: ~60; the call drains the records, so the array must hold them all at once)
         arr = (KernelStat * cap)()
         cnt = c_size_t(0)
         _check(self.lib.zg_ctx_profile_collect(self.h, arr, c_size_t(cap), ctypes.byref(cnt)))
+        if cnt.value > cap:
+            raise ZgError(-1, f"zg_ctx_profile_collect: {cnt.value} kernels for an array of {cap}: records were dropped")
         return {arr[i].name.decode(): (int(arr[i].launches), float(arr[i].total_ms), float(arr[i].algo_bytes), float(arr[i].unit_bytes))
-                for i in range(min(cap, cnt.value))}
+                for i in range(cnt.value)}
 
     # ---- SRS ----
     def params_new(self, k: int, s: np.ndarray):
@@ -640,6 +648,12 @@ class Prover:
         out = (ctypes.c_double * 8)()
         _check(self.ctx.lib.zg_prover_phase_ms(self.h, out, c_size_t(8)))
         return list(out)
+
+    def gate_stats(self) -> dict:
+        """zg_prover_gate_stats: what the gate (ZG_LAT_GATE) did on this prover so far"""
+        out = (ctypes.c_uint64 * 4)()
+        _check(self.ctx.lib.zg_prover_gate_stats(self.h, out, c_size_t(4)))
+        return dict(zip(("gated_proofs", "gates_armed", "remade_plain", "yields"), (int(x) for x in out)))
 
     def fetch(self, what: int, index: int, count: int, slot: int = 0) -> np.ndarray:
         out = np.zeros((count, 4), np.uint64)

@@ -99,7 +99,12 @@ const char *zg_version(void);
  *                     hardware queue of its own (GPU_MAX_HW_QUEUES >= the process's streams; two per latency-form prover):
  *                     where streams share a queue another stream's work can stand between this prover's streams and the
  *                     gate then only opens at its time limit (4 s), after which the proof is made again in the plain
- *                     order -- a stall, never a wrong proof.  Ignored under AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING.
+ *                     order -- a stall, never a wrong proof.  Ignored under AMD_SERIALIZE_KERNEL / HIP_LAUNCH_BLOCKING; must be
+ *                     OFF under counter collection (rocprofv3 --pmc serialises kernels across queues, which the library
+ *                     cannot see).  A proof is gated only when it repeats the last completed proof's signature (scheduling
+ *                     form, batch, instance length, digit tables, and no zg_tuning_set / zg_prover_set_batch in between):
+ *                     anything else may allocate or synchronise and is made in the plain order; should a queued-ahead
+ *                     phase still reach a blocking call, the gate is let go at once and the proof re-made (zg_prover_gate_stats).
  *                     (2: as 1, with the first gate of every proof left closed for 0.2 s -- exercises that path in tests.) */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
@@ -114,6 +119,10 @@ size_t zg_tuning_names(const char **out, size_t cap);
 int zg_ctx_create(int device_id, zg_ctx **out);
 void zg_ctx_destroy(zg_ctx *ctx);
 int zg_ctx_sync(zg_ctx *ctx);
+/* Returns the free blocks of the context's workspace pool (and of its side stream's) to the device allocator, after
+ * draining both streams; the pool grows again on demand.  For a long-lived process between workloads of different sizes
+ * (upstream has no counterpart: halo2's buffers are Vec<F> owned by create_proof).  *freed_bytes (may be NULL) = what went. */
+int zg_ctx_trim(zg_ctx *ctx, uint64_t *freed_bytes);
 /* The hipStream_t every call of this context is ordered on (as void* to keep HIP out of the ABI). */
 void *zg_ctx_stream(zg_ctx *ctx);
 
@@ -389,6 +398,10 @@ int zg_prover_fetch_slot(zg_prover *p, size_t slot, uint32_t what, uint32_t inde
  * 2 permutation/lookup products + random poly, 3 evaluate_h + h commitments, 4 evaluations,
  * 5 GWC openings, 6 total. */
 int zg_prover_phase_ms(const zg_prover *p, double *out, size_t cap);
+/* What the gate (ZG_LAT_GATE) did on this prover so far (diagnostics; upstream has no counterpart -- create_proof there
+ * launches nothing ahead): out[0] proofs made in the gated order, out[1] gates armed, out[2] proofs re-made in the plain
+ * order because a gate ran into its time limit or was let go, out[3] gates let go early by a blocking call. */
+int zg_prover_gate_stats(const zg_prover *p, uint64_t *out, size_t cap);
 
 /* Scheduling of one proof on its GPU.  enable = 1 (default): the coefficient / coset transforms run on a
  * second HIP stream beside the commitment MSMs -- lowest latency for a lone proof.  enable = 0: one

@@ -8,7 +8,9 @@
     fetch_calibration.json
     affine_ab.json       (when the run had AFFINE=R) VALU instructions and HBM bytes per proof of the MSM kernels with and
                          without R rounds of batched-affine pre-reduction
-    python tools/install_profile.py ROUND TAG          e.g. r04 v1"""
+    python tools/install_profile.py ROUND TAG [MODEL]        e.g. r05 v1 / r05 v1 medium
+The tiny model's files carry no prefix (as in rounds 1-4); another MODEL's are MODEL_* (no shared-chip trace, calibration or
+bench line for those: tools/profile.sh takes them for the tiny model only)."""
 import csv
 import glob
 import json
@@ -19,11 +21,14 @@ import sys
 from collections import defaultdict
 
 rnd, tag = sys.argv[1], sys.argv[2]
+MODEL = sys.argv[3] if len(sys.argv) > 3 else "tiny"
+PRE = "" if MODEL == "tiny" else MODEL + "_"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+src = os.path.join(root, "gpurun_out", f"prof_{tag}" if MODEL == "tiny" else f"prof_{tag}_{MODEL}")
 dst = os.path.join(root, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-BATCH = int(os.environ.get("BATCH", "32"))  # proofs per lock-step batch of the profiled runs (tools/profile.sh)
+# proofs per lock-step batch of the profiled runs (tools/profile.sh)
+BATCH = int(os.environ.get("BATCH", {"tiny": "32", "large": "8"}.get(MODEL, "16")))
 SIMDS = 256 * 4
 
 
@@ -65,8 +70,10 @@ def dispatches(path):
 def batches(rows):
     """the run's dispatches cut into create_proof batches at the kernel each batch starts with; complete ones only"""
     out, cur = [], None
+    # (image -> proof batches start with the witness program; from-resident ones with the random polynomial)
+    start = "witness_run" if any(n == "witness_run" for _, n, _, _ in rows) else "random_poly"
     for _, n, c, ns in rows:
-        if n == "random_poly":
+        if n == start:
             cur = []
             out.append(cur)
         if cur is not None:
@@ -87,16 +94,18 @@ def per_launch(path):
 
 
 # ---- FETCH_SIZE calibration (tools/fetch_calib.hip): counter / true bytes for the library's three access shapes
-true = json.load(open(os.path.join(src, "calib_true.json")))["true_bytes"]
-cal = defaultdict(list)
-for r in csv.DictReader(open(one("calib/*/*_counter_collection.csv"))):
+calib = None
+if os.path.exists(os.path.join(src, "calib_true.json")):
+  true = json.load(open(os.path.join(src, "calib_true.json")))["true_bytes"]
+  cal = defaultdict(list)
+  for r in csv.DictReader(open(one("calib/*/*_counter_collection.csv"))):
     if r["Counter_Name"] == "FETCH_SIZE":
         cal[re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]].append(float(r["Counter_Value"]) * 1024)
-mean = lambda v: sum(v) / len(v)
-calib = {"stream16_16B_per_lane_coalesced": mean(cal["stream16"]) / true["stream16"],
+  mean = lambda v: sum(v) / len(v)
+  calib = {"stream16_16B_per_lane_coalesced": mean(cal["stream16"]) / true["stream16"],
          "gather_64B_record_per_lane": mean(cal["gather<4>"]) / true["gather<4>"],
          "gather_32B_record_per_lane": mean(cal["gather<2>"]) / true["gather<2>"]}
-json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE over tools/fetch_calib.bin (2 GiB table, every byte read once): FETCH_SIZE * 1024 / "
+  json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE over tools/fetch_calib.bin (2 GiB table, every byte read once): FETCH_SIZE * 1024 / "
                     "true bytes.  0.5 for 16-byte-per-lane streaming reads (the guide's halving: double the counter); 1.0 for "
                     "64-byte gathers (msm_accumulate's table points: the counter is exact, no doubling); 2.0 for 32-byte gathers "
                     "(every 32-byte record costs a 64-byte request).", "counter_over_true_bytes": calib},
@@ -127,10 +136,10 @@ per = {k: sq1[k]["SQ_INSTS_VALU"] / (nb1 * BATCH) for k in sq1}
 total = sum(per.values())
 out["valu"] = {"_note": f"VALU wave-instructions one create_proof issues in the benchmarked form (lock-step batch of {BATCH}, split "
                         f"extended domain): SQ_INSTS_VALU summed over the kernels of a batch / {BATCH}, averaged over the run's batches",
-               "source": f"profiles/{rnd}/{tag}_valu_instructions_per_proof.txt", "batches": nb1,
+               "source": f"profiles/{rnd}/{PRE}{tag}_valu_instructions_per_proof.txt", "batches": nb1,
                "wave_instructions_per_proof": total, "by_kernel": dict(sorted(per.items(), key=lambda kv: -kv[1]))}
-json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
-with open(os.path.join(dst, f"{tag}_valu_instructions_per_proof.txt"), "w") as f:
+json.dump(out, open(os.path.join(dst, PRE + "pmc_traffic.json"), "w"), indent=1)
+with open(os.path.join(dst, f"{PRE}{tag}_valu_instructions_per_proof.txt"), "w") as f:
     f.write(f"SQ_INSTS_VALU per proof (wave-instructions), {nb1} batches of {BATCH}: total {total:.6g}\n")
     for n, v in sorted(per.items(), key=lambda kv: -kv[1]):
         f.write(f"{n:28s} {v:14.6g}  {100 * v / total:6.2f} %\n")
@@ -168,8 +177,8 @@ tot_cycles = sum(sq1[k]["GRBM_GUI_ACTIVE"] for k in sq1) / 8.0
 tot_valu = sum(sq1[k]["SQ_INSTS_VALU"] for k in sq1)
 issue["whole_proof_serialised"] = {"ms_per_proof": tot_ns / (nb1 * BATCH) / 1e6, "clock_GHz": tot_cycles / tot_ns,
                                    "valu_issue_util": 4 * tot_valu / (SIMDS * tot_cycles)}
-json.dump(issue, open(os.path.join(dst, "sq_issue.json"), "w"), indent=1)
-with open(os.path.join(dst, f"{tag}_sq_issue.txt"), "w") as f:
+json.dump(issue, open(os.path.join(dst, PRE + "sq_issue.json"), "w"), indent=1)
+with open(os.path.join(dst, f"{PRE}{tag}_sq_issue.txt"), "w") as f:
     f.write(f"{'kernel':24s} {'us/proof':>9s} {'GHz':>5s} {'waves/SIMD':>10s} {'active':>7s} {'iss.stall':>9s} {'wait':>6s} {'VALU util':>9s} {'int64':>6s}\n")
     for k, r in rows:
         f.write(f"{k:24s} {r['us_per_proof']:9.1f} {r['clock_GHz']:5.2f} {r['waves_per_simd']:10.2f} {r['active']:7.2f} "
@@ -195,7 +204,7 @@ serial = {"_note": f"rocprofv3 --kernel-trace of ONE prover making lock-step bat
 for k in sorted(ser, key=lambda k: -ser[k][1]):
     serial["kernels"][k] = {"launches_per_batch": ser[k][0] / len(tb), "avg_launch_us": ser[k][1] / ser[k][0] / 1e3,
                             "us_per_proof": ser[k][1] / (len(tb) * BATCH) / 1e3, "share": ser[k][1] / ser_total}
-json.dump(serial, open(os.path.join(dst, "serial_kernels.json"), "w"), indent=1)
+json.dump(serial, open(os.path.join(dst, PRE + "serial_kernels.json"), "w"), indent=1)
 
 # ---- batched-affine A/B (tools/profile.sh with AFFINE=R): the MSM kernels' instructions and bytes per proof, both forms
 if glob.glob(os.path.join(src, "aff_sq1/*/*_counter_collection.csv")):
@@ -229,21 +238,29 @@ if glob.glob(os.path.join(src, "aff_sq1/*/*_counter_collection.csv")):
         ab["without"]["msm_valu_instr_per_proof"], ab["with"]["msm_valu_instr_per_proof"], ab["without"]["msm_hbm_bytes_per_proof"],
         ab["with"]["msm_hbm_bytes_per_proof"], ab["without"]["msm_us_per_proof_alone"], ab["with"]["msm_us_per_proof_alone"]))
 
-shutil.copy(one("serial/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_one_prover_kernel_stats.csv"))
-shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_create_proof_kernel_stats.csv"))
-if os.path.exists(os.path.join(src, "lone_timeline_k14.txt")) and os.path.getsize(os.path.join(src, "lone_timeline_k14.txt")):
-    with open(os.path.join(dst, "lone_timeline_k14.txt"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace of tools/lone_proof.py tiny latency (one lone create_proof, digit tables), cut by tools/timeline.py\n")
+shutil.copy(one("serial/*/*_kernel_stats.csv"), os.path.join(dst, f"{PRE}{tag}_one_prover_kernel_stats.csv"))
+tl = os.path.join(src, "lone_timeline.txt")
+if os.path.exists(tl) and os.path.getsize(tl):
+    kk = {"tiny": 14, "small": 15, "medium": 15, "large": 17}[MODEL]
+    with open(os.path.join(dst, f"{PRE}lone_timeline_k{kk}.txt"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace of tools/lone_proof.py {MODEL} latency (one lone create_proof), cut by tools/timeline.py\n")
         f.write("# " + open(os.path.join(src, "lone.txt")).read().strip().replace("\n", "\n# ") + "\n")
-        f.write(open(os.path.join(src, "lone_timeline_k14.txt")).read())
-shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench.json"))
-shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
-b = json.load(open(os.path.join(dst, f"{tag}_bench.json")))
-u = json.load(open(os.path.join(dst, f"{tag}_bench_under_rocprof.json")))
-print(f"calibration {calib}")
-print(f"VALU per proof {total:.4g} over {nb1} batches; bench ms/proof {b['ms_per_proof']:.4f} (under rocprof {u['ms_per_proof']:.4f}); "
-      f"dominant {b['roofline']['kernel']} avg launch {b['roofline']['avg_launch_ms']:.4f} ms (under rocprof {u['roofline']['avg_launch_ms']:.4f})")
-for r in csv.DictReader(open(os.path.join(dst, f"{tag}_create_proof_kernel_stats.csv"))):
-    if launch_name(r["Name"]) == b["roofline"]["kernel"]:
-        print("rocprof (shared chip):", r["Name"].split("(")[0], "avg us", float(r["AverageNs"]) / 1e3, "calls", r["Calls"])
-print(open(os.path.join(dst, f"{tag}_sq_issue.txt")).read())
+        f.write(open(tl).read())
+print(open(os.path.join(dst, f"{PRE}{tag}_sq_issue.txt")).read())
+print(f"VALU per proof {total:.4g} over {nb1} batches of {BATCH}")
+top = sorted(out["kernels"].items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"])[:6]
+for k, v in top:
+    print(f"  HBM bytes per launch {k:22s} {v['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
+if MODEL == "tiny":
+    shutil.copy(one("trace/*/*_kernel_stats.csv"), os.path.join(dst, f"{tag}_create_proof_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{tag}_bench_line.json"))
+    shutil.copy(os.path.join(src, "bench_detail.json"), os.path.join(dst, f"{tag}_bench_detail.json"))
+    shutil.copy(os.path.join(src, "bench_under_trace.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+    b = json.load(open(os.path.join(dst, f"{tag}_bench_line.json")))
+    u = json.load(open(os.path.join(dst, f"{tag}_bench_under_rocprof.json")))
+    print(f"calibration {calib}")
+    print(f"bench ms/proof {b['ms_per_proof']:.4f} (under rocprof {u['ms_per_proof']:.4f}); "
+          f"dominant {b['roofline']['kernel']} avg launch {b['roofline']['avg_launch_ms']:.4f} ms (under rocprof {u['roofline']['avg_launch_ms']:.4f})")
+    for r in csv.DictReader(open(os.path.join(dst, f"{tag}_create_proof_kernel_stats.csv"))):
+        if launch_name(r["Name"]) == b["roofline"]["kernel"]:
+            print("rocprof (shared chip):", r["Name"].split("(")[0], "avg us", float(r["AverageNs"]) / 1e3, "calls", r["Calls"])
