@@ -243,6 +243,7 @@ enum Knob : int {
     K_MSM_HEAVY,      // task partials above which a bucket is merged by msm_heavy instead of its strip's lane (1..64)
     K_LAT_PULL,       // 1 = a lone proof's per-phase scalars are pulled from pinned host memory by a one-wave kernel (no copy command)
     K_LAT_GATE,       // 1 = a lone proof queues each phase before the previous one's challenge exists, behind a gate word the host opens
+    K_WITNESS_LDS,    // 0 = the witness program keeps every operand in HBM (witness.hip; read when a plan is made)
     K_COUNT
 };
 int knob(Knob k);

@@ -67,7 +67,7 @@ ABI_SYMBOLS = [
     "zg_domain_omega", "zg_ctx_profile_enable", "zg_ctx_profile_collect", "zg_params_new",
     "zg_params_new_dev", "zg_prover_create", "zg_prover_destroy", "zg_prover_prove", "zg_prover_prove_dev",
     "zg_prover_proof_size", "zg_prover_fetch", "zg_grand_product_dev", "zg_eval_polys_dev",
-    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_gate_stats", "zg_ctx_trim", "zg_prover_set_overlap", "zg_ctx_set_msm_latency",
+    "zg_kate_division_dev", "zg_keccak256", "zg_ctx_profile_filter", "zg_prover_phase_ms", "zg_prover_gate_stats", "zg_ctx_trim", "zg_witness_plan_info", "zg_prover_set_overlap", "zg_ctx_set_msm_latency",
     "zg_prover_create_shared", "zg_prover_fork", "zg_prover_set_batch", "zg_prover_batch", "zg_prover_advice_slot",
     "zg_prover_prove_batch", "zg_prover_prove_batch_dev", "zg_prover_set_shard", "zg_prover_fetch_slot",
     "zg_grand_product", "zg_xyzz_sum_ranks", "zg_prover_evaluate_h",
@@ -438,6 +438,14 @@ class WitnessPlan:
                                           c_size_t(self.image_bytes), ctypes.byref(h)))
         self.h = h
         ctx._adopt(self)
+
+    def info(self) -> dict:
+        """zg_witness_plan_info: how the program was laid out (LDS cells, values left in HBM, levels with a global barrier)"""
+        out = (ctypes.c_uint64 * 10)()
+        _check(self.ctx.lib.zg_witness_plan_info(self.h, out, c_size_t(10)))
+        return dict(zip(("lds_bytes", "narrow_cells", "wide_cells", "values_in_lds", "values_in_hbm", "hbm_levels", "wide_values", "levels",
+                         "narrow_ops", "lanes"),
+                        (int(x) for x in out)))
 
     def run(self, images: np.ndarray, d_advice) -> np.ndarray:
         """images: uint8[count, image_bytes...]; d_advice: `count` device addresses ([n_advice][2^k] field elements

@@ -105,7 +105,11 @@ const char *zg_version(void);
  *                     form, batch, instance length, digit tables, and no zg_tuning_set / zg_prover_set_batch in between):
  *                     anything else may allocate or synchronise and is made in the plain order; should a queued-ahead
  *                     phase still reach a blocking call, the gate is let go at once and the proof re-made (zg_prover_gate_stats).
- *                     (2: as 1, with the first gate of every proof left closed for 0.2 s -- exercises that path in tests.) */
+ *                     (2: as 1, with the first gate of every proof left closed for 0.2 s -- exercises that path in tests.)
+ *   ZG_WITNESS_LDS    0 = a witness plan (zg_witness_plan_create) keeps every operand of its program in HBM; 1 (default) =
+ *                     the plan is register-allocated into LDS cells when it is made (live values in LDS, a level costs an LDS
+ *                     round trip instead of three HBM round trips); n >= 2 = at most n KB of cells (what does not fit stays
+ *                     in HBM: the medium and large models' case at the full 150 KB); read when the plan is created */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */
@@ -475,6 +479,12 @@ int zg_witness_plan_create(zg_ctx* ctx, const zg_witness_op* ops, size_t n_ops, 
 void zg_witness_plan_destroy(zg_witness_plan* plan);
 size_t zg_witness_plan_image_bytes(const zg_witness_plan* plan);
 size_t zg_witness_plan_instance_len(const zg_witness_plan* plan);
+/* How the plan was laid out on the device (diagnostics; upstream has no counterpart -- its synthesis runs on the host):
+ * out[0] bytes of LDS per workgroup (0: every operand in HBM, ZG_WITNESS_LDS = 0), out[1] / out[2] 8-byte / 32-byte LDS cells,
+ * out[3] values that live in an LDS cell, out[4] consumed values left in HBM, out[5] levels whose barrier waits for HBM,
+ * out[6] values whose interval bound exceeds 64 bits, out[7] levels, out[8] operations that run on 64-bit integers (operands
+ * and result below 2^64 by their bounds), out[9] lanes of the workgroup. */
+int zg_witness_plan_info(const zg_witness_plan* plan, uint64_t* out, size_t cap);
 /* images: host, count * image_bytes; d_advice[i]: device, [n_advice][2^k] zg_fr (e.g. zg_prover_advice_slot);
  * instance_out: host, [count][n_instance].  At most 64 inputs per call.  Returns when the columns are written. */
 int zg_witness_run_dev(zg_witness_plan* plan, const uint8_t* images, size_t count, void* const* d_advice, zg_fr* instance_out);

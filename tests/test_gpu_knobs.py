@@ -34,6 +34,7 @@ SETTINGS = {
     "ZG_LAT_FULL_C": [0, 4, 7],
     "ZG_LAT_FULL_K": [4, 48],
     "ZG_LAZY_DOT": [0],
+    "ZG_WITNESS_LDS": [0],  # (shapes witness plans, not provers: walked with its own parity cases in tests/test_gpu_witness.py)
     "ZG_MSM_AFFINE": [0, 1, 2, 3, 4],
     "ZG_LAT_PULL": [0, 1],
     "ZG_LAT_GATE": [1],  # (engages from a prover's second proof in a form on: tests/test_gpu_prover.py walks it there)

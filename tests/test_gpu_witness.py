@@ -17,8 +17,17 @@ def _d2h(ptr: int, nbytes: int) -> np.ndarray:
     return out
 
 
+@pytest.fixture(params=[-1, 0, 3], ids=["lds", "hbm-only", "lds-3KB"])
+def lds_form(request, zg):
+    """ZG_WITNESS_LDS: the default (live values register-allocated into LDS cells), 0 (every operand in HBM: round 2's form)
+    and a 3-KB cell budget that forces all but a few hundred values to stay in HBM (the spill path the large models take)."""
+    zg.tuning_set("ZG_WITNESS_LDS", request.param)
+    yield request.param
+    zg.tuning_set("ZG_WITNESS_LDS", -1)
+
+
 @pytest.mark.parametrize("model", ["tiny", "medium"])
-def test_device_witness_equals_host_synthesis(ctx, zg, orc, model):
+def test_device_witness_equals_host_synthesis(ctx, zg, orc, model, lds_form):
     import witness_tape
     import wnn_circuit
     import wnn_model
@@ -27,6 +36,15 @@ def test_device_witness_equals_host_synthesis(ctx, zg, orc, model):
     wnn = wnn_model.load_checked_in(name)
     prog = witness_tape.trace(wnn, k)
     plan = zg.WitnessPlan(ctx, prog.arrays())
+    info = plan.info()
+    if lds_form == 0:
+        assert info["lds_bytes"] == 0 and info["values_in_lds"] == 0 and info["hbm_levels"] == info["levels"]
+    elif lds_form == -1 and model == "tiny":  # the whole live set fits: no operand in HBM, no barrier waits for a store
+        assert info["values_in_hbm"] == 0 and info["hbm_levels"] == 0 and 0 < info["lds_bytes"] <= 160 * 1024
+        assert info["values_in_lds"] > 18000 and info["narrow_cells"] < 6000 and info["wide_values"] < info["values_in_lds"] // 2
+    else:  # medium at the full budget, or the 3-KB budget: both kinds of operands, some levels with the global barrier
+        assert info["values_in_lds"] > 0 and info["values_in_hbm"] > 0 and 0 < info["hbm_levels"] <= info["levels"]
+        assert info["lds_bytes"] <= 160 * 1024
     real = wnn_model.load_test_image()
     rng = np.random.default_rng(11)
     images = [real, np.zeros_like(real), np.full_like(real, 255)] + [rng.integers(0, 256, size=real.shape, dtype=real.dtype)
@@ -117,7 +135,7 @@ def test_proofs_from_device_witness(ctx, zg, orc):
     prover.close()
 
 
-def test_every_operation_on_wide_operands(ctx, zg):
+def test_every_operation_on_wide_operands(ctx, zg, lds_form):
     """The circuit's own programs mostly move small integers; this one drives every opcode with random 256-bit
     operands, carries across all four words, shifts by 0..255 (and beyond, for the variable shift), divisors from 1
     to 2^64 - 1 and table reads on both sides of the bound -- against the reference interpreter."""
@@ -168,6 +186,91 @@ def test_every_operation_on_wide_operands(ctx, zg):
         assert zg.fr_to_int(got[i]) == v[o.slot] % R, f"result {i}: op {symint.OPS[t.ops[o.slot][0]]}"
     assert not got[len(out):].any()
     assert [zg.fr_to_int(x) for x in inst[0]] == [v[out[i].slot] % R for i in range(4)]
+    plan.close()
+
+
+def _run_wrapping(t, image_bytes):
+    """symint.Tape.run without the tape contract's no-underflow assertions: the device computes modulo 2^256 throughout"""
+    import symint
+
+    M = symint.M256
+    v = [0] * len(t.ops)
+    for i, (op, a, b, imm) in enumerate(t.ops):
+        name = symint.OPS[op]
+        r = {"CONST": lambda: t.consts[imm], "PIXEL": lambda: int(image_bytes[imm]), "ADD": lambda: v[a] + v[b], "SUB": lambda: v[a] - v[b],
+             "MUL": lambda: v[a] * v[b], "ADDI": lambda: v[a] + imm, "RSUBI": lambda: imm - v[a], "MULI": lambda: v[a] * imm,
+             "SHRI": lambda: v[a] >> imm, "SHLI": lambda: v[a] << imm, "ANDI": lambda: v[a] & imm,
+             "SHRV": lambda: v[a] >> v[b] if v[b] < 256 else 0, "GTI": lambda: int(v[a] > imm), "GEI": lambda: int(v[a] >= imm),
+             "EQI": lambda: int(v[a] == imm), "DIVI": lambda: v[a] // imm,
+             "TABLE": lambda: t.table[imm + v[a]] if imm + v[a] < len(t.table) else 0}[name]()
+        v[i] = r & M
+    return v
+
+
+def test_chained_operations_through_recycled_lds_cells(ctx, zg, lds_form):
+    """The LDS form's own risks: a value read from the cell another value lived in a level earlier, an 8-byte cell for a
+    value whose bound was wrong, a wide value in the narrow class.  A random DAG of 60 levels x 96 operations, every operand
+    from an EARLIER level (mostly the previous one, some far back: cells recycle constantly), narrow and wide values mixed,
+    subtractions that wrap, shifts back into 64 bits, comparisons and masks that make wide values narrow again -- four images,
+    against the reference interpreter, with every slot shown in an advice cell."""
+    import random
+
+    import symint
+    import witness_tape
+    from circuit import R
+
+    rnd = random.Random(555)
+    t = symint.Tape()
+
+    def raw_const(v):
+        t.consts.append(v)
+        return t.emit("CONST", imm=len(t.consts) - 1)
+
+    px = [t.pixel(i) for i in range(16)]
+    base = t.add_table([rnd.getrandbits(64) for _ in range(64)])
+    levels = [px + [raw_const(rnd.getrandbits(b)) for b in (1, 7, 20, 33, 63, 64, 65, 128, 200, 256)] + [raw_const(v) for v in (0, 1, R - 1, (1 << 64) - 1)]]
+    for lv in range(60):
+        cur = []
+        for _ in range(96):
+            src = levels[-1] if rnd.random() < 0.7 else levels[rnd.randrange(len(levels))]
+            a, b = rnd.choice(src), rnd.choice(levels[rnd.randrange(len(levels))])
+            kind = rnd.randrange(14)
+            if kind == 0: r = a + b
+            elif kind == 1: r = a - b  # (wraps modulo 2^256 when b > a: the bound must call it wide)
+            elif kind == 2: r = a * b
+            elif kind == 3: r = a + rnd.getrandbits(rnd.choice((3, 30, 64)))
+            elif kind == 4: r = a * rnd.getrandbits(rnd.choice((2, 16, 40)))
+            elif kind == 5: r = a >> rnd.choice((0, 1, 13, 64, 100, 192, 200, 255))
+            elif kind == 6: r = (a & symint.M64) << rnd.choice((0, 1, 5, 40, 70))
+            elif kind == 7: r = a & rnd.getrandbits(rnd.choice((1, 8, 32, 64)))
+            elif kind == 8: r = a >> (b & 255)
+            elif kind == 9: r = symint.gt(a, rnd.getrandbits(20))
+            elif kind == 10: r = a // (rnd.getrandbits(rnd.choice((3, 20, 53))) | 1)
+            elif kind == 11: r = (rnd.getrandbits(64)) - (a & rnd.getrandbits(30))  # RSUBI, may or may not wrap
+            elif kind == 12:
+                idx = a & 63
+                r = t.emit("TABLE", idx.slot, imm=base, deps=(idx.slot,))
+            else: r = symint.eq(a & 3, 1)
+            cur.append(r)
+        levels.append(cur)
+    out = [v for lv in levels for v in lv]
+    k = (len(out) - 1).bit_length()
+    prog = witness_tape.WitnessProgram(t, {(0, i): o.slot for i, o in enumerate(out)}, {i: out[-1 - i].slot for i in range(4)}, 1, k, 16)
+    plan = zg.WitnessPlan(ctx, prog.arrays())
+    info = plan.info()
+    if lds_form != 0:
+        assert info["values_in_lds"] > 1000 and info["wide_cells"] > 0 and info["narrow_cells"] > 0
+        # cells are recycled: far fewer cells than values that lived in one
+        assert info["narrow_cells"] + info["wide_cells"] < info["values_in_lds"] // 3
+    images = np.array([[0] * 16, [255] * 16, list(range(0, 256, 16)), [rnd.randrange(256) for _ in range(16)]], dtype=np.uint8)
+    bufs = [torch.full(((1 << k) * 4,), -1, dtype=torch.int64, device="cuda") for _ in images]
+    inst = plan.run(images, [b.data_ptr() for b in bufs])
+    for im, buf, got_inst in zip(images, bufs, inst):
+        v = _run_wrapping(t, im.reshape(-1))
+        got = _d2h(buf.data_ptr(), (1 << k) * 32).reshape(1 << k, 4)
+        for i, o in enumerate(out):
+            assert zg.fr_to_int(got[i]) == v[o.slot] % R, f"slot {o.slot} (level {i // 96}): op {symint.OPS[t.ops[o.slot][0]]}"
+        assert [zg.fr_to_int(x) for x in got_inst] == [v[out[-1 - i].slot] % R for i in range(4)]
     plan.close()
 
 
