@@ -1284,7 +1284,9 @@ def msm_only_main(args, rk) -> int:
     ctx = zg.Ctx(rk.dev_index)
     s = np.array(limbs(0x5EED5EED5EED5EED * MONT % R), dtype=np.uint64)
     g, gl = ctx.params_new(k, s)
-    lo, hi = rk.rank * n // rk.world, (rk.rank + 1) * n // rk.world
+    stub = args.stub_world if (args.stub_world > 1 and rk.world == 1) else 0
+    world = stub or rk.world
+    lo, hi = rk.rank * n // world, (rk.rank + 1) * n // world
     g_bases, gl_bases = ctx.register_bases(g[lo:hi]), ctx.register_bases(gl[lo:hi])
     # the form the prover multiplies random vectors in: free-position odd digits against one table row per bit position
     # (csrc/prover.hip, zg_prover_create: width 16 from 2^16 points, 15 from 2^14, else log2 + 1 -- by the SLICE's size)
@@ -1298,7 +1300,7 @@ def msm_only_main(args, rk) -> int:
     n_gl = int(on_gl.sum())
     d_scal = torch.from_numpy(np.ascontiguousarray(scal[order][:, lo:hi, :]).view(np.int64)).to(rk.dev)
     d_part = torch.zeros(vectors * 16, dtype=torch.int64, device=rk.dev)  # XYZZ, 128 B each
-    d_all = torch.zeros(rk.world * vectors * 16, dtype=torch.int64, device=rk.dev)
+    d_all = torch.zeros(world * vectors * 16, dtype=torch.int64, device=rk.dev)
     d_sum = torch.zeros(vectors * 16, dtype=torch.int64, device=rk.dev)
     stride, m = hi - lo, hi - lo
     torch.cuda.synchronize(rk.dev)  # (torch's stream made the buffers; the library works on its own)
@@ -1313,8 +1315,11 @@ def msm_only_main(args, rk) -> int:
             for v0 in range(first, first + count, CHUNK):
                 nv = min(CHUNK, first + count - v0)
                 ctx.msm_batch_dev(bases, d_scal.data_ptr() + v0 * stride * 32, stride, nv, m, d_part.data_ptr() + v0 * 128)
-        if rk.dist is not None:
-            if rk.backend == "nccl":
+        if rk.dist is not None or stub:
+            if stub:  # (what the gather would deliver, made locally: G copies of this rank's partial sums, on the MSM's stream)
+                with torch.cuda.stream(stream):
+                    d_all.view(world, -1).copy_(d_part.unsqueeze(0).expand(world, -1))
+            elif rk.backend == "nccl":
                 with torch.cuda.stream(stream):  # (the collective on the MSM's own stream: no host round trip in between)
                     rk.dist.all_gather_into_tensor(d_all, d_part)
             else:
@@ -1323,7 +1328,7 @@ def msm_only_main(args, rk) -> int:
                 rk.dist.all_gather(parts, d_part.cpu())
                 d_all.copy_(torch.cat(parts))
                 torch.cuda.synchronize(rk.dev)
-            st = lib.zg_xyzz_sum_ranks_dev(ctx.h, ctypes.c_void_p(d_all.data_ptr()), ctypes.c_size_t(rk.world), ctypes.c_size_t(vectors),
+            st = lib.zg_xyzz_sum_ranks_dev(ctx.h, ctypes.c_void_p(d_all.data_ptr()), ctypes.c_size_t(world), ctypes.c_size_t(vectors),
                                            ctypes.c_void_p(d_sum.data_ptr()))
             assert st == 0, zg.ZgError(st, "zg_xyzz_sum_ranks_dev")
             return ctx.msm_finish(d_sum.data_ptr(), vectors)
@@ -1363,7 +1368,7 @@ def msm_only_main(args, rk) -> int:
                                       f"24 uniform scalars) of n = 2^{k} points, sharded by point range: {hi - lo} points per rank, ONE all-gather "
                                       f"of {vectors} x 128 B partial sums per step, local EC additions + normalisation",
                           "proofs_per_step": batch, "parallelism": f"{rk.world} rank(s) x point range n/{rk.world}; one stream per rank"},
-               "mode": "msm-only", "msms_per_step": vectors, "digit_width": width, "points_per_rank": hi - lo, "us_per_msm": dt / (args.steps * vectors) * 1e6,
+               "mode": "msm-only", "msms_per_step": vectors, "digit_width": width, "points_per_rank": hi - lo, "stub_world": stub or None, "us_per_msm": dt / (args.steps * vectors) * 1e6,
                "collective": collective_object(rk), "ranks_share_a_device": bool(rk.world > 1 and "ZG_BENCH_DEVICE" in os.environ),
                "runtime_env": RUNTIME_ENV, "detail_file": os.path.relpath(DETAIL, ROOT)}
         if stats:
@@ -1380,7 +1385,11 @@ def msm_only_main(args, rk) -> int:
             out["device_ms_per_step"] = device_ms / args.steps
         em.early(out)
 
-        if not args.no_verify:
+        if stub:
+            out["n_gpus"] = 1
+            out["config"]["workload"] = (f"COMPUTE LEG of rank 0 of a world of {stub}, no collective, NOT a scaling figure (sums not checked: the "
+                                         f"other ranks' partial sums are copies of this rank's); ") + out["config"]["workload"]
+        if not args.no_verify and not stub:
             em.leg("verify", lambda: msm_only_check(sums, scal, order, on_gl, g, gl, vectors))
         if not args.no_cpu_baseline and rk.world == 1:
             em.leg("cpu_baseline", lambda: msm_only_cpu_baseline(scal, on_gl, g, gl, k))
@@ -1465,6 +1474,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-latency-probe", action="store_true", help="skip the lone-proof latency measurements (counter passes)")
     ap.add_argument("--no-lone-default", action="store_true", help="skip the child process behind lone.default")
     ap.add_argument("--tail-only-headline", action="store_true", help="no tail legs at all: the timed region and the line")
+    ap.add_argument("--stub-world", type=int, default=0,
+                    help="msm-only on ONE GPU: this process is rank 0 of a world of G -- points [0, n / G) of both base sets, the other "
+                         "ranks' partial sums replaced by copies of its own (no collective, sums not checked): one rank's COMPUTE LEG, "
+                         "never a scaling figure")
     ap.add_argument("--lone-child", choices=sorted(MODELS), default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args(argv)
