@@ -1294,6 +1294,7 @@ def msm_only_main(args, rk) -> int:
     width = 16 if lg >= 16 else 15 if lg >= 14 else max(3, lg + 1)
     ctx.enable_bit_table(g_bases, width)
     ctx.enable_bit_table(gl_bases, width)
+    ctx.set_msm_latency(False)  # the THROUGHPUT form of the stand-alone entry, as a prover in that form multiplies (a context starts in the latency form)
     scal = fill_scalars(k, vectors, 77)
     on_gl = np.array([v % 30 < 20 for v in range(vectors)])
     order = np.concatenate([np.nonzero(on_gl)[0], np.nonzero(~on_gl)[0]])  # (g_lagrange vectors first: two launch sequences)

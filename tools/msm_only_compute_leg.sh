@@ -12,7 +12,7 @@ for m in tiny medium large; do
     echo "$m G=$g done"
   done
 done
-python3 - <<EOF
+python3 - <<EOF  # (on the GPU box this writes into the scratch copy: run the same lines here to file it under profiles/)
 import json
 rows = []
 for m in ("tiny", "medium", "large"):
