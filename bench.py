@@ -1310,12 +1310,28 @@ def msm_only_main(args, rk) -> int:
     import ctypes
 
     CHUNK = 240  # vectors per launch sequence: what one commitment phase of a batch of proofs carries (192-288)
+    # the launch sequences of a step are spread over `streams` contexts (own HIP stream + workspace each, one host thread
+    # each; the base tables are shared), as the provers of a GPU overlap the latency-bound reductions of one sequence with the
+    # accumulation of another
+    nstreams = max(1, args.provers if args.provers else 4)
+    xs = [ctx] + [zg.Ctx(rk.dev_index) for _ in range(nstreams - 1)]
+    for x in xs:
+        x.set_msm_latency(False)
+    work = [(bases, v0, min(CHUNK, first + count - v0)) for bases, first, count in ((gl_bases, 0, n_gl), (g_bases, n_gl, vectors - n_gl))
+            for v0 in range(first, first + count, CHUNK)]
+
+    def run_share(j):
+        for bases, v0, nv in work[j::nstreams]:
+            xs[j].msm_batch_dev(bases, d_scal.data_ptr() + v0 * stride * 32, stride, nv, m, d_part.data_ptr() + v0 * 128)
+        xs[j].sync()
 
     def step():
-        for bases, first, count in ((gl_bases, 0, n_gl), (g_bases, n_gl, vectors - n_gl)):
-            for v0 in range(first, first + count, CHUNK):
-                nv = min(CHUNK, first + count - v0)
-                ctx.msm_batch_dev(bases, d_scal.data_ptr() + v0 * stride * 32, stride, nv, m, d_part.data_ptr() + v0 * 128)
+        th = [threading.Thread(target=run_share, args=(j,)) for j in range(1, nstreams)]
+        for t in th:
+            t.start()
+        run_share(0)
+        for t in th:
+            t.join()
         if rk.dist is not None or stub:
             if stub:  # (what the gather would deliver, made locally: G copies of this rank's partial sums, on the MSM's stream)
                 with torch.cuda.stream(stream):
@@ -1345,7 +1361,8 @@ def msm_only_main(args, rk) -> int:
         WATCHDOG.arm(True)
     for _ in range(max(1, args.warmup)):
         step()
-    ctx.profile(not args.no_kernel_events)
+    for x in xs:
+        x.profile(not args.no_kernel_events)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -1356,8 +1373,13 @@ def msm_only_main(args, rk) -> int:
     dt = max_over_ranks(rk, time.perf_counter() - t0)
     if WATCHDOG:
         WATCHDOG.arm(False)
-    stats = {name: v for name, v in ctx.profile_collect().items()} if not args.no_kernel_events else {}
-    ctx.profile(False)
+    stats = {}
+    for x in xs:
+        if not args.no_kernel_events:
+            for name, (l, ms, by, ub) in x.profile_collect().items():
+                a = stats.get(name, (0, 0.0, 0.0, 0.0))
+                stats[name] = (a[0] + l, a[1] + ms, a[2] + by, a[3] + ub)
+        x.profile(False)
     if rk.rank == 0:
         em = Emitter()
         unit = n * 96 + 96
@@ -1368,7 +1390,7 @@ def msm_only_main(args, rk) -> int:
                "config": {"workload": f"{vectors} MSMs per step = {batch} proofs x 30 commitments (20 over g_lagrange, 10 over g; 6 advice-like, "
                                       f"24 uniform scalars) of n = 2^{k} points, sharded by point range: {hi - lo} points per rank, ONE all-gather "
                                       f"of {vectors} x 128 B partial sums per step, local EC additions + normalisation",
-                          "proofs_per_step": batch, "parallelism": f"{rk.world} rank(s) x point range n/{rk.world}; one stream per rank"},
+                          "proofs_per_step": batch, "parallelism": f"{world} rank(s) x point range n/{world}; {nstreams} streams per rank"},
                "mode": "msm-only", "msms_per_step": vectors, "digit_width": width, "points_per_rank": hi - lo, "stub_world": stub or None, "us_per_msm": dt / (args.steps * vectors) * 1e6,
                "collective": collective_object(rk), "ranks_share_a_device": bool(rk.world > 1 and "ZG_BENCH_DEVICE" in os.environ),
                "runtime_env": RUNTIME_ENV, "detail_file": os.path.relpath(DETAIL, ROOT)}
@@ -1398,6 +1420,8 @@ def msm_only_main(args, rk) -> int:
     if rk.dist is not None:
         rk.dist.barrier()
         rk.dist.destroy_process_group()
+    for x in xs[1:]:
+        x.close()
     g_bases.free()
     gl_bases.free()
     ctx.close()
