@@ -54,7 +54,7 @@ def launch_name(kernel: str) -> str:
              "horner_combine_sets": "horner_combine", "msm_digits_naf": "msm_digits", "sort_global_fused": "sort_global",
              "gate_factor9": "gate_factor", "combine9": "horner_combine", "dot9": "eval_dot", "msm_accumulate_full": "msm_accumulate_full",
              "aff_prefix": "msm_aff_prefix", "aff_apply": "msm_aff_apply", "aff_inv_up": "msm_aff_invert", "aff_inv_top": "msm_aff_invert",
-             "aff_inv_down": "msm_aff_invert", "msm_heavy_groups": "msm_heavy"}
+             "aff_inv_down": "msm_aff_invert", "msm_heavy_groups": "msm_heavy", "witness_run_lds": "witness_run"}
     return alias.get(k, k)
 
 
