@@ -157,9 +157,9 @@ if ms:
 wf = load("witness_run_forms.json") if on("witness") else None
 if wf:
     print(f"### witness_run alone on the chip, µs ({rnd}/witness_run_forms.json)\n")
-    print("| model | operations | levels | round 4's kernel: 1 image / 16 | operands in HBM, no scratch: 1 / 16 | live values in LDS: 1 / 16 | LDS bytes | 8-byte / 32-byte cells | "
+    print("| model | levels | round 4's kernel: 1 image / 16 | operands in HBM, no scratch: 1 / 16 | live values in LDS: 1 / 16 | LDS bytes | 8-byte / 32-byte cells | "
           "values in LDS / left in HBM | levels with a global barrier | 64-bit operations | lanes |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     by = {}
     for r in wf["rows"]:
         by.setdefault(r["model"], {})[r["ZG_WITNESS_LDS"]] = r
@@ -167,7 +167,7 @@ if wf:
         h, l = d[0], d[-1]
         old = wf["round4_kernel_us"][m]
         nops = l["values_in_lds"] + l["values_in_hbm"]
-        print(f"| {m} | {l.get('narrow_ops', 0)} narrow of all | {l['levels']} | {old['1']:.0f} / {old['16']:.0f} | {h['witness_run_us_1']:.0f} / {h['witness_run_us_16']:.0f} | "
+        print(f"| {m} | {l['levels']} | {old['1']:.0f} / {old['16']:.0f} | {h['witness_run_us_1']:.0f} / {h['witness_run_us_16']:.0f} | "
               f"{l['witness_run_us_1']:.0f} / {l['witness_run_us_16']:.0f} | {l['lds_bytes']} | {l['narrow_cells']} / {l['wide_cells']} | "
               f"{l['values_in_lds']} / {l['values_in_hbm']} | {l['hbm_levels']} | {l['narrow_ops']} | {l['lanes']} |")
     print()
