@@ -1006,7 +1006,7 @@ def build_job(args, rk) -> SimpleNamespace:
     # device-side spinning and keeps 4.
     nprov = max(1, args.provers if args.provers else (12 if not sharded else 1 if exchange_kind == "rccl" else 4))
     batch = max(1, args.batch if args.batch else DEFAULT_BATCH[args.model])
-    if args.model == "large":
+    if args.model == "large" and not args.batch:
         batch = min(batch, 8)  # (a k = 17 proof slot is 1.4 GiB; 12 provers x 8 slots + workspaces stay well inside 288 GB)
     exchanges = None
     # rccl_ranks: the ranks RCCL itself counted -- the all-reduce above when the default group is RCCL (replicas and the

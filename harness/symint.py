@@ -198,6 +198,14 @@ def exact_shr(x, bits: int):
     """x * (2^bits)^-1 mod r for an x whose low `bits` bits are zero: the running-sum step z' = (z - word) / 2^K of
     the decomposition gadgets (the reference multiplies by the field inverse; on such an x that IS the shift)."""
     if is_sym(x):
+        # peephole: (z - (z & m)) >> bits with m inside the low `bits` bits is z >> bits -- one level of the replay instead of
+        # three on the decomposition chains' critical path (the subtraction stays on the tape where a cell shows it)
+        t = x.tape
+        op, a, b, _ = t.ops[x.slot]
+        if OPS[op] == "SUB":
+            opb, ab, _, immb = t.ops[b]
+            if OPS[opb] == "ANDI" and ab == a and immb < (1 << bits):
+                return Sym(t, a) >> bits
         return x >> bits
     return x * _inv(1 << bits) % R
 

@@ -102,7 +102,22 @@ class WitnessProgram:
                     instance_slots=inst, image_bytes=self.image_bytes)
 
 
-def trace(wnn: Wnn, k: int, compress_selectors: bool = True) -> WitnessProgram:
+def optimise(prog: "WitnessProgram") -> "WitnessProgram":
+    """The same program with its serial chains as parallel prefixes (tape_opt.py): every cell and instance row shows the same
+    value for every image, in a third of the levels.  `prog.opt` says what was done."""
+    import tape_opt
+
+    ops, level, stats = tape_opt.parallelise_chains(prog.tape)
+    roots = set(prog.cells.values()) | set(prog.instances.values())
+    tape, new = tape_opt.rebuild(prog.tape, ops, level, roots)
+    out = WitnessProgram(tape, {c: new[s] for c, s in prog.cells.items()}, {i: new[s] for i, s in prog.instances.items()},
+                         prog.n_advice, prog.k, prog.image_bytes)
+    stats.update(levels_after=max(tape.level) + 1, operations_before=len(prog.tape.ops), operations_after=len(tape.ops))
+    out.opt = stats
+    return out
+
+
+def trace(wnn: Wnn, k: int, compress_selectors: bool = True, optimised: bool = True) -> WitnessProgram:
     circuit = WnnCircuit(wnn, k, compress_selectors)
     tape = Tape()
     layouter = TapeLayouter(circuit.cs, circuit.constants, tape)
@@ -112,4 +127,5 @@ def trace(wnn: Wnn, k: int, compress_selectors: bool = True) -> WitnessProgram:
     result = chip.predict(layouter, SymImage(tape, height, width))
     for i, score in enumerate(result):
         layouter.constrain_instance(score, circuit.instance_column, i, score.value)
-    return WitnessProgram(tape, layouter.cells, layouter.instances, len(circuit.advice_columns), k, height * width)
+    prog = WitnessProgram(tape, layouter.cells, layouter.instances, len(circuit.advice_columns), k, height * width)
+    return optimise(prog) if optimised else prog

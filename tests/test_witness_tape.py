@@ -99,3 +99,80 @@ def test_helpers_on_integers_are_the_reference_formulas():
         assert [v[r.slot] for r in rec] == [x >> k, symint.byte_be(w, idx, nb), symint.byte_be(w, idx, nb), (byte >> (7 - bit)) & 1,
                                              (byte >> (7 - bit)) & 1, int(byte > y), int(byte >= y), int(byte == y),
                                              256 * int(byte > y) + y - byte + 255]
+
+
+@pytest.mark.parametrize("which", [wnn_model.MNIST_TINY, wnn_model.MNIST_MEDIUM])
+def test_parallel_prefix_form_shows_the_same_values_in_a_third_of_the_levels(which):
+    """harness/tape_opt.py (round 5): the Horner and running-sum chains of the gadgets as Kogge-Stone prefixes.  Every cell and
+    every class score of the optimised program equals the recorded program's for every image; the level count -- what the
+    device's replay time is proportional to -- falls to a third."""
+    k, name = which
+    wnn = wnn_model.load_checked_in(name)
+    plain = witness_tape.trace(wnn, k, optimised=False)
+    fast = witness_tape.optimise(plain)
+    assert fast.opt["levels_before"] == max(plain.tape.level) + 1 and fast.opt["levels_after"] == max(fast.tape.level) + 1
+    assert fast.opt["levels_after"] * 5 <= fast.opt["levels_before"] * 2 and fast.opt["chains"] >= 30
+    assert fast.opt["operations_after"] < 1.1 * fast.opt["operations_before"]
+    assert set(fast.cells) == set(plain.cells) and set(fast.instances) == set(plain.instances)
+    for im in _images(2 if k == 14 else 0):
+        assert fast.run(im) == plain.run(im)
+    assert witness_tape.trace(wnn, k).opt == fast.opt  # (trace() optimises by default)
+
+
+def test_parallel_prefix_on_synthetic_chains():
+    """mixed links (ADD, ADDI, through MULI or not), a chain whose multipliers outgrow 64 bits (left alone), a link whose
+    predecessor has two successors (the chain forks: one branch continues it, the other starts anew), wrap-around modulo 2^256"""
+    import random
+
+    import tape_opt
+
+    rnd = random.Random(9)
+    t = symint.Tape()
+    px = [t.pixel(i) for i in range(8)]
+    outs = []
+    x = px[0]
+    for j in range(40):  # x = 3 x + p (ADD) / 3 x + 7 (ADDI) / x + p
+        kind = j % 3
+        x = x * 3 + px[j % 8] if kind == 0 else (x * 3 + 7 if kind == 1 else x + px[(j * 5) % 8])
+        outs.append(x)
+    y = px[1]
+    for j in range(12):  # multipliers 2^40 each: 2^80 after one round -- must be left as recorded
+        y = y * (1 << 40) + px[j % 8]
+        outs.append(y)
+    z = px[2]
+    fork = None
+    for j in range(10):
+        z = z + px[j % 8]
+        outs.append(z)
+        if j == 4:
+            fork = z
+    w = fork
+    for j in range(8):
+        w = w * 2 + px[j]
+        outs.append(w)
+    big = t.emit("CONST", imm=0)
+    t.consts.append((1 << 256) - 5)
+    v = symint.Sym(t, big.slot)
+    for j in range(6):  # sums that wrap modulo 2^256
+        v = v + px[j]
+        outs.append(v)
+    prog = witness_tape.WitnessProgram(t, {(0, i): o.slot for i, o in enumerate(outs)}, {0: outs[-1].slot}, 1, 7, 8)
+    fast = witness_tape.optimise(prog)
+    assert fast.opt["chains"] >= 3 and fast.opt["levels_after"] < fast.opt["levels_before"]
+    for _ in range(5):
+        im = np.array([rnd.randrange(256) for _ in range(8)], dtype=np.uint8)
+        a = tape_opt_run(prog, im)
+        b = tape_opt_run(fast, im)
+        assert a == b
+
+
+def tape_opt_run(prog, image):
+    """values of every shown slot, computed modulo 2^256 without the tape contract's no-underflow assertions"""
+    v = [0] * len(prog.tape.ops)
+    t = prog.tape
+    for i, (op, a, b, imm) in enumerate(t.ops):
+        n = symint.OPS[op]
+        r = {"CONST": lambda: t.consts[imm], "PIXEL": lambda: int(image[imm]), "ADD": lambda: v[a] + v[b], "MULI": lambda: v[a] * imm,
+             "ADDI": lambda: v[a] + imm}[n]()
+        v[i] = r & symint.M256
+    return {c: v[s] for c, s in prog.cells.items()}

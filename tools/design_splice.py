@@ -13,7 +13,7 @@ path = os.path.join(ROOT, "DESIGN.md")
 doc = open(path).read().split("\n")
 gen = out.split("\n")
 HEADERS = ("| kernel | µs per proof | share |", "| family | share of device time |", "| model | k | provers × batch |", "| | digit tables | gate |",
-           "| model | k | world | points per rank |", "| model | world | points per rank | digit width |", "| model | levels | round 4's kernel")
+           "| model | k | world | points per rank |", "| model | world | points per rank | digit width |", "| model | levels: recorded → parallel prefix |")
 
 
 def tables(lines, header_start):

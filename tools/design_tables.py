@@ -156,18 +156,21 @@ if ms:
 
 wf = load("witness_run_forms.json") if on("witness") else None
 if wf:
-    print(f"### witness_run alone on the chip, µs ({rnd}/witness_run_forms.json)\n")
-    print("| model | levels | round 4's kernel: 1 image / 16 | operands in HBM, no scratch: 1 / 16 | live values in LDS: 1 / 16 | LDS bytes | 8-byte / 32-byte cells | "
-          "values in LDS / left in HBM | levels with a global barrier | 64-bit operations | lanes |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|")
-    by = {}
+    print(f"### witness_run alone on the chip, µs, 1 image / batch of 16 ({rnd}/witness_run_forms.json)\n")
+    print("| model | levels: recorded → parallel prefix | round 4's kernel, recorded program | + no scratch memory (operands in HBM) | + live values in LDS | "
+          "parallel-prefix program, operands in HBM | parallel-prefix program, live values in LDS | LDS bytes | 8-byte / 32-byte cells | values in LDS / left in HBM | "
+          "levels with a global barrier | 64-bit operations |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
+    by, rec = {}, {}
     for r in wf["rows"]:
         by.setdefault(r["model"], {})[r["ZG_WITNESS_LDS"]] = r
+    for r in wf["rows_recorded_program"]:
+        rec.setdefault(r["model"], {})[r["ZG_WITNESS_LDS"]] = r
     for m, d in by.items():
-        h, l = d[0], d[-1]
+        h, l, rh, rl = d[0], d[-1], rec[m][0], rec[m][-1]
         old = wf["round4_kernel_us"][m]
-        nops = l["values_in_lds"] + l["values_in_hbm"]
-        print(f"| {m} | {l['levels']} | {old['1']:.0f} / {old['16']:.0f} | {h['witness_run_us_1']:.0f} / {h['witness_run_us_16']:.0f} | "
-              f"{l['witness_run_us_1']:.0f} / {l['witness_run_us_16']:.0f} | {l['lds_bytes']} | {l['narrow_cells']} / {l['wide_cells']} | "
-              f"{l['values_in_lds']} / {l['values_in_hbm']} | {l['hbm_levels']} | {l['narrow_ops']} | {l['lanes']} |")
+        print(f"| {m} | {rl['levels']} → {l['levels']} | {old['1']:.0f} / {old['16']:.0f} | {rh['witness_run_us_1']:.0f} / {rh['witness_run_us_16']:.0f} | "
+              f"{rl['witness_run_us_1']:.0f} / {rl['witness_run_us_16']:.0f} | {h['witness_run_us_1']:.0f} / {h['witness_run_us_16']:.0f} | "
+              f"**{l['witness_run_us_1']:.0f} / {l['witness_run_us_16']:.0f}** | {l['lds_bytes']} | {l['narrow_cells']} / {l['wide_cells']} | "
+              f"{l['values_in_lds']} / {l['values_in_hbm']} | {l['hbm_levels']} | {l['narrow_ops']} |")
     print()
