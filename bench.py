@@ -1189,7 +1189,7 @@ def other_config(job, m: str, into: dict):
             pmc2 = load_pmc(m)
             scale2 = b2 / float(pmc2.get("proofs_per_launch", b2)) if pmc2 else 1.0
             serial2 = serialised_pass(st2, cx, barrier, b2, pmc2, scale2, steps=2)
-            rf, _, dev2, _ = roofline_object(stats2, serial2, pmc2, scale2, n2, b2)
+            rf, _, _, _ = roofline_object(stats2, serial2, pmc2, scale2, n2, b2)
             rec["roofline"] = {**_pick(rf, ("kernel", "achieved", "frac", "avg_launch_ms", "algo_bytes_per_launch", "msm_counter_over_algorithmic",
                                             "counter_file")), "traffic": rf.get("traffic"),
                                "serialised": _pick(rf["serialised"], ("frac", "avg_launch_ms", "ms_per_proof", "device_ms_per_proof")),

@@ -15,7 +15,7 @@ keep their identity (cells and instance rows refer to them), only their defining
 """
 from __future__ import annotations
 
-from symint import M64, OPCODE, OPS, Tape
+from symint import M64, OPCODE, Tape
 
 _USES_B = {OPCODE[n] for n in ("ADD", "SUB", "MUL", "SHRV")}
 _ADD, _MULI, _FIRST_WITH_A = OPCODE["ADD"], OPCODE["MULI"], OPCODE["ADD"]  # (opcodes >= ADD read operand a: csrc/witness.hip)
@@ -116,7 +116,6 @@ def parallelise_chains(tape: Tape):
             d *= 2
         if not ok:
             continue
-        mark = len(ops)
         d = 1
         while d < L:
             nm, nv = list(m), list(v)

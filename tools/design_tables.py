@@ -39,7 +39,6 @@ def on(section):
 
 
 line = load("final_bench_detail.json") or load("final_bench.json")
-BATCH = {"tiny": 32, "small": 16, "medium": 16, "large": 8}
 
 if on("kernels"):
     for model in ("tiny", "medium", "large"):
