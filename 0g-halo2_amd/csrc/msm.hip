@@ -206,9 +206,16 @@ __global__ __launch_bounds__(256) void msm_digits_kernel(const Fe* __restrict__ 
 // is what sizes the 255-row bit table and the 254 / w + 1 digit slots.  A modulus of 2^254 or more would read table row
 // 255 and drop digits.
 static_assert((FrParams::P_TOP >> 30) == 0, "msm_digits_naf_kernel: the scalar field's modulus must be below 2^254");
+// `balanced` (ZG_MSM_TOPSPLIT, round 5): the LAST digit of such a recoding covers whatever bits remain above the previous one
+// -- between 1 and w of them, about uniformly -- so it is tiny with probability ~1/5 (P(top = 1) = 0.21 at w = 15), whatever range
+// the scalar comes from (tools/top_digit_skew_sim.py): bucket k collects ~n / (8 k) extra entries, the hot buckets msm_heavy
+// exists for.  With the whole remainder in the register the last TWO digits are cut evenly instead: once fewer than 2 (w - 1)
+// bits are left the next digit takes half of them, and a remainder below 2^(w-1) is the last digit as it stands (positive).
+// Same number of digits (tools/top_digit_skew_sim.py checks the slot bound on adversarial scalars for w = 3 .. 16), same sum,
+// P(top = 1) = 0.003: the small buckets carry ~5 x the mean load instead of ~100 x.
 __global__ __launch_bounds__(256) void msm_digits_naf_kernel(const Fe* __restrict__ scalars, size_t stride, uint32_t per,
                                                              size_t outer, uint32_t n, uint32_t w, uint32_t slots,
-                                                             uint32_t* __restrict__ dig, uint64_t run_mask) {
+                                                             uint32_t* __restrict__ dig, uint64_t run_mask, uint32_t balanced) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
     if (i >= n) return;
     const uint32_t vj = b % per;
@@ -260,17 +267,31 @@ __global__ __launch_bounds__(256) void msm_digits_naf_kernel(const Fe* __restric
             pos += z;
             continue;
         }
-        const uint32_t v = (uint32_t)bits & mask;  // odd
-        const bool neg = v > half;
-        const uint32_t d = neg ? (mask + 1u) - v : v;
+        uint32_t wd = w, m = mask, hf = half;
+        if (balanced && next >= 8) {  // every limb is in: `bits` is all that is left of the scalar
+            const uint32_t rem = 64u - (uint32_t)__clzll((long long)bits);
+            if (rem <= w - 1u) {  // the last digit, positive, as it stands
+                if (slot < slots && pos <= 254u) db[(size_t)slot * n] = (((uint32_t)bits + 1u) >> 1) | (pos << 16) | flip;
+                slot++;
+                break;
+            }
+            if (rem <= 2u * (w - 1u)) {  // two digits left: cut them evenly
+                wd = (rem + 1u) >> 1;
+                m = (1u << wd) - 1u;
+                hf = 1u << (wd - 1u);
+            }
+        }
+        const uint32_t v = (uint32_t)bits & m;  // odd
+        const bool neg = v > hf;
+        const uint32_t d = neg ? (m + 1u) - v : v;
         // (slot < slots and pos <= 254 always: Fr::to_raw returns a value below r for ANY 256-bit input -- the Montgomery
         //  reduction of x < 2^256 is below r + 1 before its final subtraction -- and r < 2^254 by the static_assert
         //  above; the guard only keeps a violated assumption from writing outside the digit array)
         if (slot < slots && pos <= 254u) db[(size_t)slot * n] = ((d + 1u) >> 1) | (pos << 16) | ((neg ? 0x80000000u : 0u) ^ flip);
         slot++;
-        bits = (bits >> w) + (neg ? 1ull : 0ull);
-        have = have >= w ? have - w : 0;
-        pos += w;
+        bits = (bits >> wd) + (neg ? 1ull : 0ull);
+        have = have >= wd ? have - wd : 0;
+        pos += wd;
     }
     for (; slot < slots; slot++) db[(size_t)slot * n] = 0u;
 }
@@ -1892,7 +1913,7 @@ int msm_batch4_dev(zg_ctx* ctx, const zg_bases* bases, const zg_bases* bases_b, 
     }
     if (naf)
         ZG_LAUNCH(ctx, "msm_digits", dig_bytes, msm_digits_naf_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
-                  (uint32_t)per, outer, N, naf, W, dig, run_mask);
+                  (uint32_t)per, outer, N, naf, W, dig, run_mask, knob(K_MSM_TOPSPLIT) != 0 ? 1u : 0u);
     else
         ZG_LAUNCH(ctx, "msm_digits", dig_bytes, msm_digits_kernel, dim3((N + 255) / 256, B), dim3(256), 0, d_scalars, stride,
                   (uint32_t)per, outer, N, c, W, tbits, dig, run_mask);

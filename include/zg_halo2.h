@@ -109,7 +109,9 @@ const char *zg_version(void);
  *   ZG_WITNESS_LDS    0 = a witness plan (zg_witness_plan_create) keeps every operand of its program in HBM; 1 (default) =
  *                     the plan is register-allocated into LDS cells when it is made (live values in LDS, a level costs an LDS
  *                     round trip instead of three HBM round trips); n >= 2 = at most n KB of cells (what does not fit stays
- *                     in HBM: the medium and large models' case at the full 150 KB); read when the plan is created */
+ *                     in HBM: the medium and large models' case at the full 150 KB); read when the plan is created
+ *   ZG_MSM_TOPSPLIT   0 = the free-position recoding (ZG_MSM_NAF) leaves its last digit whatever bits remain above the previous one
+ *                     (tiny with probability 1/5: the hot small buckets); 1 (default) = the last two digits are cut evenly */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */
