@@ -16,9 +16,12 @@ CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config")
 
 
-def _run(argv, env_extra=None, timeout=900):
-    env = dict(os.environ, ZG_BENCH_STALL_S="240", **(env_extra or {}))
+def _run(argv, env_extra=None, timeout=900, keep_world=False):
+    env = dict(os.environ, ZG_BENCH_STALL_S="240")
     env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
+    if not keep_world:
+        env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -60,6 +63,20 @@ def test_msm_only_over_two_ranks_gathers_the_oracles_sums():
     assert d["verified"] is True and d["mode"] == "msm-only" and detail["msms_per_step"] == 60 and detail["points_per_rank"] == 8192
     assert abs(d["value"] - 2 * 60 / (2 * d["ms_per_step"] / 1e3)) < 1e-4 * d["value"]
     assert d["roofline"]["kernel"] == "msm_accumulate"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["msm-only", "replicas"])
+def test_the_rccl_code_paths_run_with_a_one_rank_group(mode):
+    """This pool has one GPU per box, so no world > 1 RCCL collective can run; what CAN run is every RCCL call of the bench with
+    a real one-rank group (ZG_BENCH_FORCE_DIST=1): init_process_group("nccl"), the barrier, the rank count by all-reduce, the
+    MAX over ranks, and msm-only's all_gather_into_tensor queued on the library's own stream between the MSM and the additions."""
+    d, detail, _ = _run(["--mode", mode, "--steps", "2", "--warmup", "1", "--provers", "2", "--batch", "4", "--no-other-configs",
+                         "--no-cpu-baseline", "--no-latency-probe"],
+                        {"ZG_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29561", "RANK": "0", "LOCAL_RANK": "0",
+                         "WORLD_SIZE": "1"}, keep_world=True)
+    assert d["collective"] == {"backend": "rccl", "ranks_seen": 1} and d["verified"] is True and d["n_gpus"] == 1
+    assert detail["rccl_ranks"] == 1 if mode == "replicas" else True
 
 
 @pytest.mark.gpu
