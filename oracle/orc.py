@@ -216,7 +216,7 @@ def extended_to_coeff(d: Domain, evals: np.ndarray) -> np.ndarray:
 # ---------------------------------------------------------------- create_proof / verify_proof
 class _Pk(ctypes.Structure):
     _fields_ = [("cs", c_void_p), ("fixed_values", c_void_p), ("sigma_values", c_void_p),
-                ("params", c_void_p), ("vk_repr", c_uint64 * 4)]
+                ("params", c_void_p), ("vk_repr", c_uint64 * 4), ("derived", c_void_p)]
 
 
 class Trace(ctypes.Structure):
@@ -234,10 +234,13 @@ class Trace(ctypes.Structure):
 
 
 class ProvingKey:
-    """orc_pk: circuit image (harness/circuit.py CircuitImage), fixed/sigma values, SRS."""
+    """orc_pk: circuit image (harness/circuit.py CircuitImage), fixed/sigma values, SRS.  The rest of what keygen_pk
+    stores (polys, cosets, l0 / l_last / l_active_row) is derived at the first create_proof and kept with the key;
+    derive=False computes it inside every proof instead (same bytes: tests/test_oracle_prover.py)."""
 
     def __init__(self, image, fixed_values: np.ndarray, sigma_values: np.ndarray, params: Params,
-                 vk_repr: np.ndarray):
+                 vk_repr: np.ndarray, derive: bool = True):
+        self.keep_derived = derive
         self.image = image
         self.fixed = np.ascontiguousarray(fixed_values, dtype=np.uint64)
         self.sigma = np.ascontiguousarray(sigma_values, dtype=np.uint64)
@@ -250,6 +253,18 @@ class ProvingKey:
         self.c.params = ctypes.cast(ctypes.byref(params), c_void_p)
         for i in range(4):
             self.c.vk_repr[i] = int(self.vk_repr[i])
+        self.c.derived = None
+
+    def derive(self):
+        if self.keep_derived and not self.c.derived:
+            load().orc_pk_derive(ctypes.byref(self.c))
+
+    def __del__(self):
+        try:
+            if self.c.derived:
+                load().orc_pk_release(ctypes.byref(self.c))
+        except Exception:  # interpreter shutdown: the process's memory goes with it
+            pass
 
 
 def proof_size(image) -> int:
@@ -267,6 +282,7 @@ def create_proof(pk: ProvingKey, advice: np.ndarray, instance: np.ndarray, seed,
     buf = (ctypes.c_uint8 * cap)()
     plen = c_size_t(0)
     tr = Trace() if want_trace else None
+    pk.derive()
     st = load().orc_create_proof(ctypes.byref(pk.c), _p(advice), _p(instance), c_size_t(inst_len),
                                  rng_key(seed), buf, c_size_t(cap), ctypes.byref(plen),
                                  ctypes.byref(tr) if tr is not None else None)

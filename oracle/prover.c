@@ -335,6 +335,80 @@ void orc_last_phase_ms(double *out, size_t cap) {
         t_prev_ = now_;                          \
     } while (0)
 
+/* What keygen_pk stores in the ProvingKey beside the Lagrange values (halo2_proofs src/plonk/keygen.rs keygen_pk:
+ * fixed_polys, fixed_cosets, permutation::ProvingKey {polys, cosets}, l0, l_last, l_active_row): a function of the key
+ * alone.  orc_pk_derive fills pk->derived once; a key without it (derived == NULL) has the same material computed inside
+ * every create_proof -- the bytes of the proof are the same either way (tests/test_oracle_prover.py). */
+typedef struct {
+    orc_fr *fix_poly, *sig_poly;          /* [F][n], [P][n] coefficient forms          */
+    orc_fr *fix_cos, *sig_cos;            /* [F][en], [P][en] on the extended coset    */
+    orc_fr *l0, *llast, *lactive;         /* [en]                                      */
+} pk_derived;
+
+static void transform_columns(const orc_domain *dom, orc_fr *cos, orc_fr *poly, size_t count, int lagrange_input);
+
+static pk_derived *derive_key_material(const orc_pk *pk) {
+    const zg_circuit *cs = pk->cs;
+    const size_t n = (size_t)1 << cs->k, F = cs->n_fixed, P = cs->n_perm_columns, bf = cs->blinding_factors;
+    orc_domain dom;
+    orc_domain_new(&dom, cs->cs_degree, cs->k);
+    const size_t en = (size_t)dom.extended_n;
+    pk_derived *d = (pk_derived *)calloc(1, sizeof(pk_derived));
+    d->fix_poly = (orc_fr *)malloc((F ? F : 1) * n * sizeof(orc_fr));
+    d->sig_poly = (orc_fr *)malloc((P ? P : 1) * n * sizeof(orc_fr));
+    d->fix_cos = (orc_fr *)malloc((F ? F : 1) * en * sizeof(orc_fr));
+    d->sig_cos = (orc_fr *)malloc((P ? P : 1) * en * sizeof(orc_fr));
+    memcpy(d->fix_poly, pk->fixed_values, F * n * sizeof(orc_fr));
+    memcpy(d->sig_poly, pk->sigma_values, P * n * sizeof(orc_fr));
+    transform_columns(&dom, d->fix_cos, d->fix_poly, F, 1);
+    transform_columns(&dom, d->sig_cos, d->sig_poly, P, 1);
+    /* l_0, l_last, l_active_row on the coset */
+    orc_fr *l = (orc_fr *)calloc(3 * n, sizeof(orc_fr)), *lc = (orc_fr *)malloc(3 * en * sizeof(orc_fr));
+    l[0] = ORC_FR_ONE;
+    l[n + n - bf - 1] = ORC_FR_ONE;
+    for (size_t j = 0; j < bf; j++) l[2 * n + n - 1 - j] = ORC_FR_ONE; /* l_blind */
+    transform_columns(&dom, lc, l, 3, 1);
+    d->l0 = (orc_fr *)malloc(en * sizeof(orc_fr));
+    d->llast = (orc_fr *)malloc(en * sizeof(orc_fr));
+    d->lactive = (orc_fr *)malloc(en * sizeof(orc_fr));
+    memcpy(d->l0, lc, en * sizeof(orc_fr));
+    memcpy(d->llast, lc + en, en * sizeof(orc_fr));
+    for (size_t i = 0; i < en; i++) {
+        orc_fr t;
+        orc_fr_add(&t, &lc[en + i], &lc[2 * en + i]);
+        orc_fr_sub(&d->lactive[i], &ORC_FR_ONE, &t);
+    }
+    free(l);
+    free(lc);
+    orc_domain_free(&dom);
+    return d;
+}
+static void free_key_material(pk_derived *d) {
+    if (!d) return;
+    free(d->fix_poly); free(d->sig_poly); free(d->fix_cos); free(d->sig_cos);
+    free(d->l0); free(d->llast); free(d->lactive);
+    free(d);
+}
+void orc_pk_derive(orc_pk *pk) {
+    if (!pk->derived) pk->derived = derive_key_material(pk);
+}
+void orc_pk_release(orc_pk *pk) {
+    free_key_material((pk_derived *)pk->derived);
+    pk->derived = NULL;
+}
+
+/* `count` columns of n values each to coefficient form in place (when lagrange_input) and on to the extended coset
+ * (when cos != NULL): one column per thread -- the transforms of different columns share nothing (halo2 runs each
+ * transform's butterflies over its rayon pool instead; the values are the same). */
+static void transform_columns(const orc_domain *dom, orc_fr *cos, orc_fr *poly, size_t count, int lagrange_input) {
+    const size_t n = (size_t)dom->n, en = (size_t)dom->extended_n;
+#pragma omp parallel for schedule(dynamic, 1) if (count > 1)
+    for (long c = 0; c < (long)count; c++) {
+        if (lagrange_input) orc_lagrange_to_coeff(dom, poly + (size_t)c * n);
+        if (cos) orc_coeff_to_extended(dom, cos + (size_t)c * en, poly + (size_t)c * n);
+    }
+}
+
 int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *instance_in, size_t instance_len,
                      const uint8_t seed[32], uint8_t *proof, size_t cap, size_t *proof_len, orc_trace *trace) {
     const zg_circuit *cs = pk->cs;
@@ -504,75 +578,28 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     PHASE_LAP(2);
 
     /* ---- coefficient forms */
-    orc_fr *adv_poly = (orc_fr *)malloc((A ? A : 1) * n * sizeof(orc_fr));
+    pk_derived *own = pk->derived ? NULL : derive_key_material(pk);
+    const pk_derived *km = pk->derived ? (const pk_derived *)pk->derived : own;
+    const orc_fr *fix_poly = km->fix_poly, *sig_poly = km->sig_poly;
+    /* every column this proof made, side by side: advice | permutation z | lookup z | permuted inputs | permuted tables */
+    const size_t n_own = A + sets + 3 * NL;
+    orc_fr *own_poly = (orc_fr *)malloc((n_own ? n_own : 1) * n * sizeof(orc_fr));
+    orc_fr *adv_poly = own_poly, *pz_poly = adv_poly + A * n, *lz_poly = pz_poly + sets * n;
+    orc_fr *pin_poly = lz_poly + NL * n, *ptab_poly = pin_poly + NL * n;
     memcpy(adv_poly, adv_val, A * n * sizeof(orc_fr));
-    for (size_t c = 0; c < A; c++) orc_lagrange_to_coeff(&dom, adv_poly + c * n);
-    orc_fr *fix_poly = (orc_fr *)malloc((F ? F : 1) * n * sizeof(orc_fr));
-    memcpy(fix_poly, pk->fixed_values, F * n * sizeof(orc_fr));
-    for (size_t c = 0; c < F; c++) orc_lagrange_to_coeff(&dom, fix_poly + c * n);
-    orc_fr *sig_poly = (orc_fr *)malloc((P ? P : 1) * n * sizeof(orc_fr));
-    memcpy(sig_poly, pk->sigma_values, P * n * sizeof(orc_fr));
-    for (size_t c = 0; c < P; c++) orc_lagrange_to_coeff(&dom, sig_poly + c * n);
-    orc_fr *pz_poly = (orc_fr *)malloc((sets ? sets : 1) * n * sizeof(orc_fr));
     memcpy(pz_poly, pz, sets * n * sizeof(orc_fr));
-    for (size_t s = 0; s < sets; s++) orc_lagrange_to_coeff(&dom, pz_poly + s * n);
-    orc_fr *lz_poly = (orc_fr *)malloc((NL ? NL : 1) * n * sizeof(orc_fr));
-    orc_fr *pin_poly = (orc_fr *)malloc((NL ? NL : 1) * n * sizeof(orc_fr));
-    orc_fr *ptab_poly = (orc_fr *)malloc((NL ? NL : 1) * n * sizeof(orc_fr));
     memcpy(lz_poly, lz, NL * n * sizeof(orc_fr));
     memcpy(pin_poly, pin, NL * n * sizeof(orc_fr));
     memcpy(ptab_poly, ptab, NL * n * sizeof(orc_fr));
-    for (size_t l = 0; l < NL; l++) {
-        orc_lagrange_to_coeff(&dom, lz_poly + l * n);
-        orc_lagrange_to_coeff(&dom, pin_poly + l * n);
-        orc_lagrange_to_coeff(&dom, ptab_poly + l * n);
-    }
-
     /* ---- evaluate_h on the extended coset */
-    orc_fr *adv_cos = (orc_fr *)malloc((A ? A : 1) * en * sizeof(orc_fr));
+    orc_fr *own_cos = (orc_fr *)malloc((n_own ? n_own : 1) * en * sizeof(orc_fr));
+    orc_fr *adv_cos = own_cos, *pz_cos = adv_cos + A * en, *lz_cos = pz_cos + sets * en;
+    orc_fr *pin_cos = lz_cos + NL * en, *ptab_cos = pin_cos + NL * en;
+    transform_columns(&dom, own_cos, own_poly, n_own, 1);
     orc_fr *inst_cos = (orc_fr *)malloc((I ? I : 1) * en * sizeof(orc_fr));
-    orc_fr *fix_cos = (orc_fr *)malloc((F ? F : 1) * en * sizeof(orc_fr));
-    orc_fr *sig_cos = (orc_fr *)malloc((P ? P : 1) * en * sizeof(orc_fr));
-    orc_fr *pz_cos = (orc_fr *)malloc((sets ? sets : 1) * en * sizeof(orc_fr));
-    orc_fr *lz_cos = (orc_fr *)malloc((NL ? NL : 1) * en * sizeof(orc_fr));
-    orc_fr *pin_cos = (orc_fr *)malloc((NL ? NL : 1) * en * sizeof(orc_fr));
-    orc_fr *ptab_cos = (orc_fr *)malloc((NL ? NL : 1) * en * sizeof(orc_fr));
-    for (size_t c = 0; c < A; c++) orc_coeff_to_extended(&dom, adv_cos + c * en, adv_poly + c * n);
-    for (size_t c = 0; c < I; c++) orc_coeff_to_extended(&dom, inst_cos + c * en, inst_poly + c * n);
-    for (size_t c = 0; c < F; c++) orc_coeff_to_extended(&dom, fix_cos + c * en, fix_poly + c * n);
-    for (size_t c = 0; c < P; c++) orc_coeff_to_extended(&dom, sig_cos + c * en, sig_poly + c * n);
-    for (size_t s = 0; s < sets; s++) orc_coeff_to_extended(&dom, pz_cos + s * en, pz_poly + s * n);
-    for (size_t l = 0; l < NL; l++) {
-        orc_coeff_to_extended(&dom, lz_cos + l * en, lz_poly + l * n);
-        orc_coeff_to_extended(&dom, pin_cos + l * en, pin_poly + l * n);
-        orc_coeff_to_extended(&dom, ptab_cos + l * en, ptab_poly + l * n);
-    }
-    /* l_0, l_last, l_active_row on the coset (keygen_pk) */
-    orc_fr *l0 = (orc_fr *)calloc(en, sizeof(orc_fr));
-    orc_fr *llast = (orc_fr *)calloc(en, sizeof(orc_fr));
-    orc_fr *lactive = (orc_fr *)calloc(en, sizeof(orc_fr));
-    {
-        orc_fr *tmp = (orc_fr *)calloc(n, sizeof(orc_fr));
-        tmp[0] = ORC_FR_ONE;
-        orc_lagrange_to_coeff(&dom, tmp);
-        orc_coeff_to_extended(&dom, l0, tmp);
-        memset(tmp, 0, n * sizeof(orc_fr));
-        tmp[n - bf - 1] = ORC_FR_ONE;
-        orc_lagrange_to_coeff(&dom, tmp);
-        orc_coeff_to_extended(&dom, llast, tmp);
-        memset(tmp, 0, n * sizeof(orc_fr));
-        for (size_t j = 0; j < bf; j++) tmp[n - 1 - j] = ORC_FR_ONE;
-        orc_lagrange_to_coeff(&dom, tmp);
-        orc_fr *lblind = (orc_fr *)malloc(en * sizeof(orc_fr));
-        orc_coeff_to_extended(&dom, lblind, tmp);
-        for (size_t i = 0; i < en; i++) {
-            orc_fr t;
-            orc_fr_add(&t, &llast[i], &lblind[i]);
-            orc_fr_sub(&lactive[i], &ORC_FR_ONE, &t);
-        }
-        free(lblind);
-        free(tmp);
-    }
+    transform_columns(&dom, inst_cos, inst_poly, I, 0);
+    const orc_fr *fix_cos = km->fix_cos, *sig_cos = km->sig_cos;
+    const orc_fr *l0 = km->l0, *llast = km->llast, *lactive = km->lactive;
     orc_fr *h = (orc_fr *)malloc(en * sizeof(orc_fr));
     {
         /* beta_term = extended_omega^idx, delta_start = beta * ZETA */
@@ -849,10 +876,8 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     PHASE_LAP(5);
     g_phase_ms[6] = t_prev_ - t_start_;
     free(qs); free(fq); free(sq); free(pz_eval); free(lk_eval); free(h_poly); free(h_coeff); free(h);
-    free(l0); free(llast); free(lactive);
-    free(adv_cos); free(inst_cos); free(fix_cos); free(sig_cos); free(pz_cos); free(lz_cos); free(pin_cos);
-    free(ptab_cos);
-    free(adv_poly); free(fix_poly); free(sig_poly); free(pz_poly); free(lz_poly); free(pin_poly); free(ptab_poly);
+    free(inst_cos); free(own_cos); free(own_poly);
+    free_key_material(own);
     free(random_poly); free(lz); free(pz);
 fail_early:
     free(cin); free(ctab); free(pin); free(ptab);

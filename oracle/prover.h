@@ -51,7 +51,12 @@ typedef struct {
     const orc_fr *sigma_values;   /* [n_perm_columns][n] */
     const orc_params *params;
     orc_fr vk_repr;
+    void *derived;                /* orc_pk_derive's; NULL = computed inside every create_proof */
 } orc_pk;
+/* The rest of what keygen_pk leaves in the ProvingKey (fixed / permutation polys and cosets, l0, l_last, l_active_row):
+ * computed once per key.  create_proof gives the same bytes with or without it. */
+void orc_pk_derive(orc_pk *pk);
+void orc_pk_release(orc_pk *pk);
 
 /* Intermediates kept for piecewise parity checks against the GPU path. */
 typedef struct {

@@ -7,10 +7,10 @@ import pytest
 from circuits import toy_circuit
 
 
-def make_pk(orc, cs, asg, params):
+def make_pk(orc, cs, asg, params, derive=True):
     img = cs.to_c()
     vk_repr = orc.fr_from_int(0x1234567)
-    return orc.ProvingKey(img, asg.fixed_values(), asg.sigma_values(), params, vk_repr)
+    return orc.ProvingKey(img, asg.fixed_values(), asg.sigma_values(), params, vk_repr, derive=derive)
 
 
 @pytest.fixture(scope="module")
@@ -41,6 +41,10 @@ def test_toy_proof_verifies(orc, params5, force_degree):
     assert proof2 == proof
     st3, proof3, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=8)
     assert proof3 != proof and orc.verify_proof(pk, inst, proof3) == 1
+    # the key's polys / cosets / l0, l_last, l_active_row kept with the key (keygen_pk) or computed inside the proof: same bytes
+    assert pk.c.derived
+    bare = make_pk(orc, cs, asg, params5, derive=False)
+    assert orc.create_proof(bare, asg.advice_values(), inst, seed=7)[1] == proof and not bare.c.derived
 
 
 def test_tampered_proofs_and_wrong_instance_fail(orc, params5):
@@ -95,6 +99,7 @@ def test_wnn_shaped_circuit_proof_verifies(orc):
     inst = asg.instance_values(ilen)
     st, proof, _ = orc.create_proof(pk, asg.advice_values(), inst, seed=5)
     assert st == 0
+    assert orc.create_proof(make_pk(orc, cs, asg, params, derive=False), asg.advice_values(), inst, seed=5)[1] == proof
     # 6 advice + 8 permuted + 2 perm z + 4 lookup z + 1 random + 5 h + 4 W = 30 points
     n_scalars = 10 + len(cs.fixed_queries) + 1 + 8 + 5 + 20
     assert len(proof) == 64 * 30 + 32 * n_scalars
