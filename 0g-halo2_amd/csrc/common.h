@@ -245,6 +245,7 @@ enum Knob : int {
     K_LAT_GATE,       // 1 = a lone proof queues each phase before the previous one's challenge exists, behind a gate word the host opens
     K_WITNESS_LDS,    // 0 = the witness program keeps every operand in HBM (witness.hip; read when a plan is made)
     K_MSM_TOPSPLIT,   // 0 = the free-position recoding leaves its last digit whatever bits remain (msm_digits_naf_kernel)
+    K_NTT9,           // the transforms' butterflies: 0 = on 8 x 32-bit limbs (ntt_pass_kernel), 1 = on nine 29-bit ones; default: nine in the latency form
     K_COUNT
 };
 int knob(Knob k);

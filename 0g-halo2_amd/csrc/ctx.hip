@@ -20,7 +20,7 @@ void set_error(const char* fmt, ...) {
 static const char* const kKnobNames[K_COUNT] = {"ZG_MSM_C", "ZG_MSM_K", "ZG_MSM_K_LAT", "ZG_MSM_RB", "ZG_MSM_LANES", "ZG_MSM_STRIP",
                                                 "ZG_MSM_NAF", "ZG_MSM_NAF_GL", "ZG_MSM_RUNS", "ZG_EVALH_GROUPED", "ZG_EVALH9",
                                                 "ZG_SPLIT_DOMAIN", "ZG_LAT_SPLIT_K", "ZG_LAT_FULL_C", "ZG_LAT_FULL_K", "ZG_LAZY_DOT",
-                                                "ZG_MSM_AFFINE", "ZG_MSM_HEAVY", "ZG_LAT_PULL", "ZG_LAT_GATE", "ZG_WITNESS_LDS", "ZG_MSM_TOPSPLIT"};
+                                                "ZG_MSM_AFFINE", "ZG_MSM_HEAVY", "ZG_LAT_PULL", "ZG_LAT_GATE", "ZG_WITNESS_LDS", "ZG_MSM_TOPSPLIT", "ZG_NTT9"};
 // (read beside the knobs, not knobs: settings of the HIP RUNTIME under which every launch completes before the next one is
 //  submitted -- a stream that waits for the host, ZG_LAT_GATE, must not be started then)
 static const char* const kRuntimeSerialising[2] = {"AMD_SERIALIZE_KERNEL", "HIP_LAUNCH_BLOCKING"};

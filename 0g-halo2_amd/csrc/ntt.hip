@@ -29,6 +29,9 @@ struct NttArgs {
     const Fe* in;
     Fe* out;
     const Fe* tw;       // omega^i, i < N; entries [N, 2N) hold omega^i * 2^5 (the 2^261 Montgomery form)
+    const Fe* tw_m;     // (nine-limb pass) the same table for the pass's sub-transform: omega_M^t, t < M, then omega_M^t * 2^5
+    uint32_t tw_shift;  // (nine-limb pass) LDS holds the sub-transform twiddles whose index is a multiple of 2^tw_shift; the
+                        // stages before that read theirs from tw_m (contiguous, L1-resident)
     size_t in_stride;   // elements between consecutive batch arrays
     size_t out_stride;
     // groups (poly.h Grouping): array v of the batch sits at (v / per) * outer + (v % per) * stride; a flat side has
@@ -285,6 +288,213 @@ __global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt_pass_kernel(NttArgs a) {
     }
 }
 
+// ---- the same pass on nine 29-bit limbs (field9.h; ZG_NTT9: the default of the latency form).  Tiling, indices, the XOR-folded LDS slots and
+// the fused first-load / last-store work are ntt_pass_kernel's; what differs is the arithmetic:
+//   * an element is 36 bytes in LDS (limbs 0..3 and 4..7 as two 16-byte words, limb 8 in a third array);
+//   * the data stay in the library's x * 2^256 form and every twiddle comes from the table's second half
+//     (omega^i * 2^5, i.e. the 2^261 form as an integer): Fr9::mul(x * 2^256, w * 2^261) = x w * 2^256 -- no conversion;
+//   * sums and differences are limb-wise, a sum is carried back to 29-bit limbs (f9_norm) before it is stored or subtracted,
+//     the difference of two normalised values enters its product as it is, and EVERY twiddle is multiplied (omega^0 too:
+//     the branch of ntt_pass_kernel saved nothing -- a wave takes it for the one lane that has i = 0);
+//   * bounds.  A product by a canonical twiddle of an operand below 2^261 lies in (-p, 2p).  An element that is only ever
+//     SUMMED quadruples per radix-2^2 group: from 2p to 8p, 32p, 128p -- under the 2^261 = 169 p that Fr9::mul's top limb
+//     allows for the differences taken from it only while it is <= 84 p.  So the sum of every THIRD group is multiplied
+//     by one (2^261 mod r: a Montgomery reduction back into (-p, 2p)) -- one product in twelve on top.  Where every lane's
+//     twiddle is omega^0 (the last group of an even stage count: three of its four; the last stage of an odd count) nothing
+//     is multiplied, as in ntt_pass_kernel, and the results leave at most 4 x (2 x) their inputs' size: with the reduction
+//     in the third group that is 64 p after ten stages and 128 p after eleven, under what the pass's closing product or
+//     f9_reduce_pack (2^263) take;
+//   * what leaves a pass is canonical (f9_reduce_pack: magnitude < 2^263), so the bytes are ntt_pass_kernel's.
+// 4 x 232 + 3 x 24 + 8 x 9 instructions per group of four against 4 x 340 + 8 x 28.
+template <int LOG_T, bool COLS, bool FIRST>
+__global__ __launch_bounds__(1 << (LOG_T - 2)) void ntt9_pass_kernel(NttArgs a) {
+    constexpr uint32_t T = 1u << LOG_T;
+    constexpr uint32_t NT = T / 4;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const uint32_t log_m = COLS ? a.log_n1 : a.log_n2;
+    const uint32_t M = 1u << log_m;
+    const uint32_t S = a.tw_shift;
+    const uint32_t TWN = (M / 2) >> S ? (M / 2) >> S : 1;
+    uint4* XL = reinterpret_cast<uint4*>(smem);
+    uint4* XH = XL + T;
+    uint4* TL = XH + T;
+    uint4* TH = TL + TWN;
+    int32_t* X8 = reinterpret_cast<int32_t*>(TH + TWN);
+    int32_t* T8 = X8 + T;
+    auto slot = [](uint32_t i) { return i ^ ((i >> 3) & 7u) ^ ((i >> 6) & 7u) ^ ((i >> 9) & 7u); };
+    auto ld3 = [&](const uint4* L, const uint4* H, const int32_t* E, uint32_t i) {
+        const uint32_t s = slot(i);
+        const uint4 lo = L[s], hi = H[s];
+        F9 r;
+        r.l[0] = (int32_t)lo.x; r.l[1] = (int32_t)lo.y; r.l[2] = (int32_t)lo.z; r.l[3] = (int32_t)lo.w;
+        r.l[4] = (int32_t)hi.x; r.l[5] = (int32_t)hi.y; r.l[6] = (int32_t)hi.z; r.l[7] = (int32_t)hi.w;
+        r.l[8] = E[s];
+        return r;
+    };
+    auto st3 = [&](uint4* L, uint4* H, int32_t* E, uint32_t i, const F9& v) {
+        const uint32_t s = slot(i);
+        L[s] = make_uint4((uint32_t)v.l[0], (uint32_t)v.l[1], (uint32_t)v.l[2], (uint32_t)v.l[3]);
+        H[s] = make_uint4((uint32_t)v.l[4], (uint32_t)v.l[5], (uint32_t)v.l[6], (uint32_t)v.l[7]);
+        E[s] = v.l[8];
+    };
+    auto ldx = [&](uint32_t i) { return ld3(XL, XH, X8, i); };
+    auto stx = [&](uint32_t i, const F9& v) { st3(XL, XH, X8, i, v); };
+    const Fe* twm9 = a.tw_m + M;
+    // twiddle omega_M^i of stage st (i is a multiple of 2^st; st is uniform)
+    auto ldt = [&](uint32_t i, uint32_t st) { return st >= S ? ld3(TL, TH, T8, i >> S) : f9_unpack(ld_fe(twm9 + i)); };
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N1 = 1u << a.log_n1, N2 = 1u << a.log_n2;
+    uint32_t log_cnt = LOG_T - log_m;
+    if (!COLS && log_cnt > a.log_n1) log_cnt = a.log_n1;
+    const uint32_t cnt = 1u << log_cnt;
+    const uint32_t tile = M << log_cnt;
+
+    uint32_t nblk = gridDim.x, bid = blockIdx.x;
+    if ((nblk & 7u) == 0) bid = (bid & 7u) * (nblk >> 3) + (bid >> 3);
+    const uint32_t base = bid << log_cnt;
+
+    const Fe* in = a.in + (size_t)(blockIdx.y / a.in_per) * a.in_outer + (size_t)(blockIdx.y % a.in_per) * a.in_stride;
+    Fe* out = a.out + (size_t)(blockIdx.y / a.out_per) * a.out_outer + (size_t)(blockIdx.y % a.out_per) * a.out_stride;
+    const Fe* tw9 = a.tw + ((size_t)1 << a.log_n);  // omega^i * 2^5
+
+    for (uint32_t t = tid; t < (M / 2) >> S; t += NT) st3(TL, TH, T8, t, f9_unpack(ld_fe(twm9 + (t << S))));
+    for (uint32_t e = tid; e < tile; e += NT) {
+        uint32_t g;
+        if (COLS) {
+            uint32_t c = e & (cnt - 1), j1 = e >> log_cnt;
+            g = j1 * N2 + base + c;
+        } else {
+            uint32_t j2 = e & (M - 1), r = e >> log_m;
+            g = (base + r) * N2 + j2;
+        }
+        F9 v;
+        if (FIRST) {
+            if (g < a.in_len) {
+                v = f9_unpack(ld_fe(in + g));
+                if (a.coset_in) {  // (zin*, zout*, scale arrive in the 2^261 form on this path: launch_passes)
+                    uint32_t m3 = g % 3u;
+                    if (m3 == 1) v = Fr9::mul(v, f9_unpack(a.zin1));
+                    else if (m3 == 2) v = Fr9::mul(v, f9_unpack(a.zin2));
+                    else if (a.coset_in == 2) v = Fr9::mul(v, f9_unpack(a.zin0));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; i++) v.l[i] = 0;
+            }
+        } else {
+            v = f9_unpack(ld_fe(in + g));
+        }
+        stx(e, v);
+    }
+    __syncthreads();
+
+    auto at = [&](uint32_t sub, uint32_t e) { return COLS ? (e << log_cnt) + sub : (sub << log_m) + e; };
+    uint32_t st = 0, grp = 0;  // grp: radix-2^2 groups an only-summed element has been through since its last reduction
+    if (FIRST && COLS && log_m >= 2) {  // (zero padding: ntt_pass_kernel)
+        const uint32_t nz_rows = (a.in_len + N2 - 1) >> a.log_n2;
+        const uint32_t quarter = M >> 2, half = M >> 1;
+        if (nz_rows <= quarter) {
+            for (uint32_t g = tid; g < tile / 4; g += NT) {
+                const uint32_t sub = g & (cnt - 1), i = g >> log_cnt;
+                if (i >= nz_rows) continue;
+                const uint32_t i0 = at(sub, i), i1 = at(sub, i + quarter), i2 = at(sub, i + half), i3 = at(sub, i + half + quarter);
+                const F9 x0 = ldx(i0);
+                const F9 a2 = Fr9::mul(x0, ldt(i, 0));
+                const F9 w = ldt(i << 1, 1);
+                stx(i2, a2);
+                stx(i1, Fr9::mul(x0, w));
+                stx(i3, Fr9::mul(a2, w));
+            }
+            __syncthreads();
+            st = 2;  // (x0 itself stays where it is: nothing was summed)
+        }
+    }
+    for (; st + 1 < log_m; st += 2) {
+        const uint32_t log_half = log_m - st - 1, log_q = log_half - 1;
+        const uint32_t half = 1u << log_half, quarter = 1u << log_q;
+        const bool reduce = ++grp == 3;  // (uniform)
+        if (reduce) grp = 0;
+        const bool last = quarter == 1;  // (uniform) i = 0 for every lane: three of the four twiddles are omega^0
+        for (uint32_t g = tid; g < tile / 4; g += NT) {
+            uint32_t sub, b;
+            if (COLS) {
+                sub = g & (cnt - 1);
+                b = g >> log_cnt;
+            } else {
+                b = g & (M / 4 - 1);
+                sub = g >> (log_m - 2);
+            }
+            const uint32_t blk = b >> log_q, i = b & (quarter - 1);
+            const uint32_t e0 = (blk << (log_half + 1)) + i;
+            const uint32_t i0 = at(sub, e0), i1 = at(sub, e0 + quarter), i2 = at(sub, e0 + half), i3 = at(sub, e0 + half + quarter);
+            const F9 x0 = ldx(i0), x1 = ldx(i1), x2 = ldx(i2), x3 = ldx(i3);
+            const F9 a0 = f9_add(x0, x2), a1 = f9_add(x1, x3);
+            const F9 a3 = Fr9::mul(f9_sub(x1, x3), ldt((i + quarter) << st, st));
+            if (last) {  // the sub-transform's last two stages: its results leave at most four times their inputs' size
+                const F9 d0 = f9_sub(x0, x2);
+                stx(i0, f9_norm(f9_add(a0, a1)));
+                stx(i1, f9_norm(f9_sub(a0, a1)));
+                stx(i2, f9_norm(f9_add(d0, a3)));
+                stx(i3, f9_norm(f9_sub(d0, a3)));
+                continue;
+            }
+            const F9 a2 = Fr9::mul(f9_sub(x0, x2), ldt(i << st, st));
+            F9 s0 = f9_norm(f9_add(a0, a1));
+            if (reduce) s0 = Fr9::mul(s0, Fr9Params::one());
+            stx(i0, s0);
+            stx(i2, f9_norm(f9_add(a2, a3)));
+            const F9 w = ldt(i << (st + 1), st + 1);
+            stx(i1, Fr9::mul(f9_norm(f9_sub(a0, a1)), w));
+            stx(i3, Fr9::mul(f9_sub(a2, a3), w));
+        }
+        __syncthreads();
+    }
+    const uint32_t nbf = tile / 2;
+    for (; st < log_m; st++) {  // (the last stage of an odd count: half = 1, every twiddle is omega^0)
+        for (uint32_t bf = tid; bf < nbf; bf += NT) {
+            uint32_t s, b;
+            if (COLS) {
+                s = bf & (cnt - 1);
+                b = bf >> log_cnt;
+            } else {
+                b = bf & (M / 2 - 1);
+                s = bf >> (log_m - 1);
+            }
+            const uint32_t ilo = at(s, b << 1), ihi = at(s, (b << 1) + 1);
+            const F9 u = ldx(ilo), v = ldx(ihi);
+            stx(ilo, f9_norm(f9_add(u, v)));
+            stx(ihi, f9_norm(f9_sub(u, v)));
+        }
+        __syncthreads();
+    }
+
+    if (COLS) {
+        for (uint32_t e = tid; e < tile; e += NT) {
+            uint32_t c = e & (cnt - 1), pos = e >> log_cnt;
+            uint32_t k1 = bitrev(pos, log_m);
+            uint32_t j2 = base + c;
+            const F9 v = Fr9::mul(ldx(e), f9_unpack(ld_fe(tw9 + j2 * k1)));  // (j2 * k1 < N)
+            st_fe(out + (size_t)k1 * N2 + j2, f9_reduce_pack<Fr9Params>(v));
+        }
+    } else {
+        for (uint32_t e = tid; e < tile; e += NT) {
+            uint32_t r = e & (cnt - 1), k2 = e >> log_cnt;
+            uint32_t pos = bitrev(k2, log_m);
+            uint32_t k = (base + r) + N1 * k2;
+            if (k >= a.out_len) continue;
+            F9 v = ldx((r << log_m) + pos);
+            if (a.scale_out) v = Fr9::mul(v, f9_unpack(a.scale));
+            if (a.coset_out) {
+                uint32_t m3 = k % 3u;
+                if (m3 == 1) v = Fr9::mul(v, f9_unpack(a.zout1));
+                else if (m3 == 2) v = Fr9::mul(v, f9_unpack(a.zout2));
+            }
+            st_fe(out + k, f9_reduce_pack<Fr9Params>(v));
+        }
+    }
+}
+
 // tw[i] = omega^i, tw[n + i] = omega^i in the 2^261 Montgomery form (nine-limb butterflies), i < n
 __global__ void twiddle_kernel(Fe* tw, Fe omega, uint32_t n) {
     constexpr uint32_t CH = 16;
@@ -346,10 +556,30 @@ struct NttPlan {
     Fe zin0, zin1, zin2, zout1, zout2, scale;
 };
 
-template <int LOG_T>
+// (nine-limb pass) the sub-transform's own twiddle table -- omega_M = omega^(N / M), contiguous -- and how much of it the pass
+// keeps in LDS: a tile of T nine-limb elements is 36 T bytes, and what is left of the CU's 160 KB at four workgroups of
+// 2^10 elements (two of 2^11) holds 113 (227) twiddles; the stages whose twiddles do not fit read them from the table.
+static int sub_twiddles(zg_ctx* ctx, const NttPlan& p, uint32_t log_m, uint32_t log_t, const Fe** table, uint32_t* shift) {
+    Fe om = p.omega;
+    for (uint32_t i = log_m; i < p.log_n; i++) om = Fr::sqr(om);
+    Fe* t = nullptr;
+    ZG_TRY(get_twiddles(ctx, log_m, om, &t));
+    *table = t;
+    const uint32_t room = log_t == 10 ? 113u : 227u;
+    uint32_t s = 0;
+    while ((((1u << log_m) / 2) >> s) > room) s++;
+    *shift = s;
+    return ZG_OK;
+}
+static size_t nine_lds_bytes(uint32_t T, uint32_t log_m, uint32_t shift) {
+    const uint32_t twn = ((1u << log_m) / 2) >> shift;
+    return (size_t)(T + (twn ? twn : 1)) * 36;
+}
+
+template <int LOG_T, bool NINE>
 static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, size_t tmp_stride) {
     constexpr uint32_t T = 1u << LOG_T;
-    constexpr size_t ELEM = sizeof(Fe);
+    constexpr size_t ELEM = NINE ? 36 : sizeof(Fe);
     NttArgs a;
     memset(&a, 0, sizeof(a));
     a.tw = tw;
@@ -360,6 +590,10 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
     a.coset_out = p.coset_out;
     a.scale_out = p.scale_out;
     a.zin0 = p.zin0; a.zin1 = p.zin1; a.zin2 = p.zin2; a.zout1 = p.zout1; a.zout2 = p.zout2; a.scale = p.scale;
+    if (NINE) {  // the nine-limb pass multiplies x * 2^256 by constants in the 2^261 form (c * 2^5 here)
+        const Fe c261 = Fr9Params::c261_fe();
+        for (Fe* c : {&a.zin0, &a.zin1, &a.zin2, &a.zout1, &a.zout2, &a.scale}) *c = Fr::mul(*c, c261);
+    }
     const uint32_t N = 1u << p.log_n;
     const uint32_t gper = p.grp.per ? p.grp.per : 0xffffffffu;
     // algorithmic bytes.  The UNIT is one transform: input entries read + output entries written -- or what
@@ -379,9 +613,15 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.in = p.in; a.in_stride = p.in_stride;
         a.out = p.out; a.out_stride = p.out_stride;
         a.in_per = a.out_per = gper; a.in_outer = p.grp.in_outer; a.out_outer = p.grp.out_outer;
-        size_t lds = (size_t)(T + N / 2) * ELEM;
-        ZG_LAUNCH_U(ctx, "ntt_single", pass_bytes, unit_bytes, (ntt_pass_kernel<LOG_T, false, true>),
-                  dim3(1, (uint32_t)p.batch), block, lds, a);
+        size_t lds = (size_t)(T + (N > 1 ? N / 2 : 1)) * ELEM;
+        if (NINE) {
+            ZG_TRY(sub_twiddles(ctx, p, a.log_n2, LOG_T, &a.tw_m, &a.tw_shift));
+            lds = nine_lds_bytes(T, a.log_n2, a.tw_shift);
+        }
+        if (NINE)
+            ZG_LAUNCH_U(ctx, "ntt_single", pass_bytes, unit_bytes, (ntt9_pass_kernel<LOG_T, false, true>), dim3(1, (uint32_t)p.batch), block, lds, a);
+        else
+            ZG_LAUNCH_U(ctx, "ntt_single", pass_bytes, unit_bytes, (ntt_pass_kernel<LOG_T, false, true>), dim3(1, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
         return ZG_OK;
     }
@@ -394,9 +634,17 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.in_per = gper; a.in_outer = p.grp.in_outer;
         a.out_per = 0xffffffffu; a.out_outer = 0;
         uint32_t cnt = T / N1;
-        size_t lds = (size_t)(T + N1 / 2) * ELEM;
-        ZG_LAUNCH(ctx, "ntt_cols", (double)p.batch * (double)p.in_len * 32.0 + pts, (ntt_pass_kernel<LOG_T, true, true>),
-                  dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
+        size_t lds = (size_t)(T + (N1 > 1 ? N1 / 2 : 1)) * ELEM;
+        if (NINE) {
+            ZG_TRY(sub_twiddles(ctx, p, a.log_n1, LOG_T, &a.tw_m, &a.tw_shift));
+            lds = nine_lds_bytes(T, a.log_n1, a.tw_shift);
+        }
+        if (NINE)
+            ZG_LAUNCH(ctx, "ntt_cols", (double)p.batch * (double)p.in_len * 32.0 + pts, (ntt9_pass_kernel<LOG_T, true, true>),
+                      dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
+        else
+            ZG_LAUNCH(ctx, "ntt_cols", (double)p.batch * (double)p.in_len * 32.0 + pts, (ntt_pass_kernel<LOG_T, true, true>),
+                      dim3(N2 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }
     {   // pass 2: tmp -> out
@@ -406,9 +654,17 @@ static int launch_passes(zg_ctx* ctx, const NttPlan& p, const Fe* tw, Fe* tmp, s
         a.out_per = gper; a.out_outer = p.grp.out_outer;
         uint32_t cnt = T / N2;
         if (cnt > N1) cnt = N1;
-        size_t lds = (size_t)(T + N2 / 2) * ELEM;
-        ZG_LAUNCH_U(ctx, "ntt_rows", pts + (double)p.batch * (double)p.out_len * 32.0, unit_bytes, (ntt_pass_kernel<LOG_T, false, false>),
-                  dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
+        size_t lds = (size_t)(T + (N2 > 1 ? N2 / 2 : 1)) * ELEM;
+        if (NINE) {
+            ZG_TRY(sub_twiddles(ctx, p, a.log_n2, LOG_T, &a.tw_m, &a.tw_shift));
+            lds = nine_lds_bytes(T, a.log_n2, a.tw_shift);
+        }
+        if (NINE)
+            ZG_LAUNCH_U(ctx, "ntt_rows", pts + (double)p.batch * (double)p.out_len * 32.0, unit_bytes, (ntt9_pass_kernel<LOG_T, false, false>),
+                        dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
+        else
+            ZG_LAUNCH_U(ctx, "ntt_rows", pts + (double)p.batch * (double)p.out_len * 32.0, unit_bytes, (ntt_pass_kernel<LOG_T, false, false>),
+                        dim3(N1 / cnt, (uint32_t)p.batch), block, lds, a);
         ZG_HIP(hipGetLastError());
     }
     return ZG_OK;
@@ -424,8 +680,13 @@ int ntt_run(zg_ctx* ctx, const NttPlan& p, Fe* tmp, size_t tmp_stride) {
     if (p.batch == 0) return ZG_OK;
     Fe* tw = nullptr;
     ZG_TRY(get_twiddles(ctx, p.log_n, p.omega, &tw));
-    if (ntt_log_t(p.log_n) == 10) return launch_passes<10>(ctx, p, tw, tmp, tmp_stride);
-    return launch_passes<11>(ctx, p, tw, tmp, tmp_stride);
+    // nine-limb butterflies in the latency form (a lone proof: its transforms finish 7-15 % sooner), 8 x 32-bit ones in the
+    // throughput form (twelve provers hold the chip at its power limit, where the nine-limb pass's 27 % more multiply-adds
+    // cost the clock what its shorter instruction stream gains: measured +0.6 ... +0.9 % ms/proof); ZG_NTT9 = 0 / 1 forces one
+    const int k9 = knob(K_NTT9);
+    const bool nine = k9 < 0 ? ctx->msm_pair : k9 != 0;
+    if (ntt_log_t(p.log_n) == 10) return nine ? launch_passes<10, true>(ctx, p, tw, tmp, tmp_stride) : launch_passes<10, false>(ctx, p, tw, tmp, tmp_stride);
+    return nine ? launch_passes<11, true>(ctx, p, tw, tmp, tmp_stride) : launch_passes<11, false>(ctx, p, tw, tmp, tmp_stride);
 }
 
 static int ensure_lds_attr(zg_ctx* ctx) {
@@ -446,6 +707,12 @@ static int ensure_lds_attr(zg_ctx* ctx) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
     ZG_HIP(hipFuncSetAttribute((const void*)ntt_pass_kernel<10, false, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<11, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<11, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<11, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<10, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<10, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
+    ZG_HIP(hipFuncSetAttribute((const void*)ntt9_pass_kernel<10, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, big));
     ds.ntt_attrs = true;
     return ZG_OK;
 }

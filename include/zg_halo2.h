@@ -111,7 +111,12 @@ const char *zg_version(void);
  *                     round trip instead of three HBM round trips); n >= 2 = at most n KB of cells (what does not fit stays
  *                     in HBM: the medium and large models' case at the full 150 KB); read when the plan is created
  *   ZG_MSM_TOPSPLIT   0 = the free-position recoding (ZG_MSM_NAF) leaves its last digit whatever bits remain above the previous one
- *                     (tiny with probability 1/5: the hot small buckets); 1 (default) = the last two digits are cut evenly */
+ *                     (tiny with probability 1/5: the hot small buckets); 1 (default) = the last two digits are cut evenly
+ *   ZG_NTT9           the transforms' butterflies: 0 = on 8 x 32-bit limbs (a canonical value after every operation), 1 = on nine
+ *                     29-bit limbs (limb-wise sums, no carry word in the products: a quarter fewer instructions per pass, 27 %
+ *                     more multiply-adds; 36-byte elements in LDS).  Default: nine in the latency form (a lone proof: -0.3 / -1.7 /
+ *                     -1.2 % at k = 14 / 15 / 17), eight in the throughput form (the chip is at its power limit there and the
+ *                     nine-limb pass measured +0.6 % ms/proof).  Same bytes either way: what leaves a pass is canonical. */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */

@@ -40,6 +40,7 @@ SETTINGS = {
     "ZG_LAT_GATE": [1],  # (engages from a prover's second proof in a form on: tests/test_gpu_prover.py walks it there)
     "ZG_MSM_HEAVY": [1, 5, 64],
     "ZG_MSM_TOPSPLIT": [0],
+    "ZG_NTT9": [0, 1],  # (the default is one or the other by scheduling form)
 }
 # knobs that act together: walked as pairs as well
 PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2, 4)] + [
@@ -51,6 +52,7 @@ PAIRS = [({"ZG_MSM_RB": rb, "ZG_MSM_LANES": l}) for rb in (64, 128) for l in (2,
     {"ZG_MSM_AFFINE": 2, "ZG_MSM_NAF": 0, "ZG_MSM_NAF_GL": 0},   # affine rounds over the window tables
     {"ZG_MSM_AFFINE": 3, "ZG_MSM_K": 4},
     {"ZG_MSM_AFFINE": 1, "ZG_MSM_RUNS": 0},
+    {"ZG_NTT9": 1, "ZG_SPLIT_DOMAIN": 0}, {"ZG_NTT9": 0, "ZG_EVALH9": 0}, {"ZG_NTT9": 1, "ZG_LAT_SPLIT_K": 0},
     {"ZG_MSM_TOPSPLIT": 0, "ZG_MSM_NAF": 9}, {"ZG_MSM_TOPSPLIT": 1, "ZG_MSM_NAF": 3}, {"ZG_MSM_TOPSPLIT": 1, "ZG_MSM_NAF": 16, "ZG_MSM_NAF_GL": 5},
 ]
 CASES = [{k: v} for k, vs in SETTINGS.items() for v in vs] + PAIRS

@@ -6,6 +6,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["nine_limb", "eight_limb"])
+def limb_form(request, zg):
+    """every case on both butterfly back ends (ZG_NTT9: nine 29-bit limbs, the default, and 8 x 32-bit)"""
+    before = zg.tuning_get("ZG_NTT9")
+    zg.tuning_set("ZG_NTT9", request.param)
+    yield request.param
+    zg.tuning_set("ZG_NTT9", before)
+
+
 @pytest.mark.parametrize("log_n", [0, 1, 2, 5, 10, 11, 12, 14, 15, 17])
 def test_ntt_matches_oracle(ctx, zg, orc, log_n):
     n = 1 << log_n
@@ -30,6 +39,30 @@ def test_ntt_extended_domain_sizes_match_oracle(ctx, zg, orc, log_n):
     assert np.array_equal(got, orc.fft(a, om))
     div = orc.fr_inv(orc.fr_from_int(n))
     assert np.array_equal(ctx.ntt(got, omi, div), a)
+
+
+@pytest.mark.parametrize("log_n", [3, 10, 11, 13, 16, 19, 22])
+def test_ntt_of_extreme_values(ctx, zg, orc, log_n):
+    """The nine-limb butterflies keep sums unreduced between their reductions (csrc/ntt.hip: an only-summed element grows
+    fourfold per radix-2^2 group): inputs that drive those sums and differences to their largest magnitudes -- every stored
+    value p - 1, p - 1 against 0 in every pairing the stages make, and p - 1 at the even rows of a zero-padded transform."""
+    n = 1 << log_n
+    top = np.array([(zg.FR_MODULUS - 1 >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+    om, omi = zg.domain_omega(log_n)
+    div = orc.fr_inv(orc.fr_from_int(n))
+    idx = np.arange(n)
+    patterns = [np.ones(n, bool)] + [((idx >> b) & 1) == 0 for b in sorted({0, 1, log_n // 2, max(log_n - 2, 0), log_n - 1})]
+    for keep in patterns:
+        a = np.zeros((n, 4), np.uint64)
+        a[keep] = top
+        got = ctx.ntt(a, om)
+        assert np.array_equal(got, orc.fft(a, om))
+        assert np.array_equal(ctx.ntt(got, omi, div), a)
+    if 4 <= log_n <= 17:  # coeff_to_extended's zero padding with the largest coefficients
+        d = orc.domain(6, log_n - 3) if log_n - 3 >= 1 else None
+        if d is not None and d.extended_k == log_n:
+            a = np.tile(top, (1 << (log_n - 3), 1))
+            assert np.array_equal(ctx.coeff_to_extended(a, log_n - 3, log_n), orc.coeff_to_extended(d, a))
 
 
 def test_ntt_linearity_and_delta(ctx, zg, orc):
