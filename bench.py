@@ -268,6 +268,60 @@ def run_steps(streams, steps):
         raise errors[0]
 
 
+class PowerSampler:
+    """Package power and shader clock of this box's GPU(s) while the timed steps run, read from the driver's hwmon files
+    (/sys/class/drm/card*/device/hwmon/hwmon*/{power1_input, freq1_input, power1_cap}: no process, no HIP call) every 50 ms
+    by one thread: says whether the figure was made at the part's power limit and at which clock.  Best effort: an empty
+    object where the files are not readable."""
+
+    def __init__(self, period: float = 0.05):
+        import glob
+        self.cards = [os.path.dirname(f) for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))]
+        self.period, self.rows, self.stop_flag, self.thread = period, [], threading.Event(), None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        if not self.cards:
+            return self
+
+        def work():
+            while not self.stop_flag.is_set():
+                self.rows.append([(self._read(c + "/power1_input"), self._read(c + "/freq1_input")) for c in self.cards])
+                self.stop_flag.wait(self.period)
+
+        self.thread = threading.Thread(target=work, daemon=True)
+        self.thread.start()
+        return self
+
+    def stop(self) -> dict:
+        if not self.thread:
+            return {}
+        self.stop_flag.set()
+        self.thread.join()
+        out = []
+        for i, c in enumerate(self.cards):
+            pw = [r[i][0] / 1e6 for r in self.rows if r[i][0] is not None]
+            fq = [r[i][1] / 1e6 for r in self.rows if r[i][1] is not None]
+            if not pw or max(pw) < 400.0:  # (an idle card of the node: 245 W)
+                continue
+            cap = self._read(c + "/power1_cap")
+            out.append({"card": c.split("/")[4], "samples": len(pw), "power_w_avg": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1),
+                        "power_cap_w": round(cap / 1e6, 1) if cap else None,
+                        "sclk_mhz_avg": round(sum(fq) / len(fq), 1) if fq else None, "sclk_mhz_min": round(min(fq), 1) if fq else None,
+                        "sclk_mhz_max": round(max(fq), 1) if fq else None})
+        return {"source": "hwmon power1_input / freq1_input every %d ms over the timed steps" % int(self.period * 1e3), "cards": out}
+
+
+LAST_POWER = {}
+
+
 def measure(streams, ctxs, steps, warmup, barrier, profile=False):
     """`warmup` untimed steps, then EXACTLY `steps` timed ones between two barriers; with `profile` every launch carries
     its own start / stop event on the stream it is launched on (hipExtLaunchKernelGGL), collected per kernel afterwards."""
@@ -277,10 +331,13 @@ def measure(streams, ctxs, steps, warmup, barrier, profile=False):
     for x in ctxs:
         x.profile(profile)
     barrier()
+    sampler = PowerSampler().start()
     t0 = time.perf_counter()
     run_steps(streams, steps)
     barrier()
     dt = time.perf_counter() - t0
+    LAST_POWER.clear()
+    LAST_POWER.update(sampler.stop())
     if WATCHDOG:
         WATCHDOG.arm(False)
     stats = {}
@@ -759,6 +816,9 @@ def format_line(out: dict, limit: int = LINE_LIMIT) -> str:
                                           "bytes_equal_plain_order"))
     add("lone", lc)
     add("valu", _pick(out.get("valu"), ("frac_of_four_cycle_issue_rate",)))
+    pw = (out.get("power") or {}).get("cards") or []
+    if pw:  # (the busiest card: is the figure made at the part's power limit, and at which clock)
+        add("power", _pick(max(pw, key=lambda x: x.get("power_w_avg") or 0), ("power_w_avg", "power_w_max", "power_cap_w", "sclk_mhz_avg")))
     oc = out.get("other_configs") or {}
     add("other_configs", {m: _pick(v, ("ms_per_proof", "image_to_proof_wall_s", "verified")) for m, v in oc.items() if isinstance(v, dict)})
     add("algorithmic_bytes_per_proof", out.get("algorithmic_bytes_per_proof"))
@@ -1097,6 +1157,8 @@ def measure_headline(job) -> dict:
         "algorithmic_GBps": algorithmic_bytes_per_proof(cs) / (dt / n_local) / 1e9,
         "detail_file": os.path.relpath(DETAIL, ROOT),
     }
+    if LAST_POWER.get("cards"):
+        out["power"] = dict(LAST_POWER)  # (this rank's view of the node's busy cards during the timed steps)
     if job.images:
         out["witness_program"] = c.witness_program()[1]
     if stats:
@@ -1184,6 +1246,8 @@ def other_config(job, m: str, into: dict):
         n2 = steps * np2 * b2
         rec.update({"ms_per_proof": dt2 / n2 * 1e3, "proofs_per_hour": n2 / dt2 * 3600.0,
                     "timed_region": "image_to_proof" if job.images else "from_resident_columns"})
+        if LAST_POWER.get("cards"):
+            rec["power"] = LAST_POWER["cards"]
         if not args.no_verify:
             rec.update(verify_last_step(c2, st2, host_cores(), byte_checks=1))
         if stats2 and not args.no_serialised:
