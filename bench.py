@@ -276,8 +276,20 @@ class PowerSampler:
 
     def __init__(self, period: float = 0.05):
         import glob
-        self.cards = [os.path.dirname(f) for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))]
+        cards = [os.path.dirname(f) for f in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input"))]
+        # only THIS process's device (a shared host shows its neighbours' cards as well): matched by PCI address
+        mine = self._pci_of_current_device()
+        own = [c for c in cards if mine and os.path.basename(os.path.realpath(os.path.join(c, "..", ".."))).lower() == mine]
+        self.cards, self.matched = (own, True) if own else (cards, False)
         self.period, self.rows, self.stop_flag, self.thread = period, [], threading.Event(), None
+
+    @staticmethod
+    def _pci_of_current_device():
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+            return "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:  # noqa: BLE001  (no such attributes on this build: every busy card is reported, flagged unmatched)
+            return None
 
     @staticmethod
     def _read(path):
@@ -316,7 +328,10 @@ class PowerSampler:
                         "power_cap_w": round(cap / 1e6, 1) if cap else None,
                         "sclk_mhz_avg": round(sum(fq) / len(fq), 1) if fq else None, "sclk_mhz_min": round(min(fq), 1) if fq else None,
                         "sclk_mhz_max": round(max(fq), 1) if fq else None})
-        return {"source": "hwmon power1_input / freq1_input every %d ms over the timed steps" % int(self.period * 1e3), "cards": out}
+        if not self.matched and len(out) > 1:  # (could not tell which card is ours: keep the busiest one only)
+            out = [max(out, key=lambda x: x["power_w_avg"])]
+        return {"source": "hwmon power1_input / freq1_input every %d ms over the timed steps" % int(self.period * 1e3),
+                "matched_by_pci_address": self.matched, "cards": out}
 
 
 LAST_POWER = {}
