@@ -833,7 +833,8 @@ def format_line(out: dict, limit: int = LINE_LIMIT) -> str:
     add("valu", _pick(out.get("valu"), ("frac_of_four_cycle_issue_rate",)))
     pw = (out.get("power") or {}).get("cards") or []
     if pw:  # (the busiest card: is the figure made at the part's power limit, and at which clock)
-        add("power", _pick(max(pw, key=lambda x: x.get("power_w_avg") or 0), ("power_w_avg", "power_w_max", "power_cap_w", "sclk_mhz_avg")))
+        add("power", {**_pick(max(pw, key=lambda x: x.get("power_w_avg") or 0), ("power_w_avg", "power_w_max", "power_cap_w", "sclk_mhz_avg")),
+                      **_pick(out.get("power"), ("joules_per_proof",))})
     oc = out.get("other_configs") or {}
     add("other_configs", {m: _pick(v, ("ms_per_proof", "image_to_proof_wall_s", "verified")) for m, v in oc.items() if isinstance(v, dict)})
     add("algorithmic_bytes_per_proof", out.get("algorithmic_bytes_per_proof"))
@@ -1173,7 +1174,9 @@ def measure_headline(job) -> dict:
         "detail_file": os.path.relpath(DETAIL, ROOT),
     }
     if LAST_POWER.get("cards"):
-        out["power"] = dict(LAST_POWER)  # (this rank's view of the node's busy cards during the timed steps)
+        out["power"] = dict(LAST_POWER)  # (this rank's card during the timed steps)
+        # energy of one proof on this rank's card: what a power-limited chip is really short of
+        out["power"]["joules_per_proof"] = LAST_POWER["cards"][0]["power_w_avg"] * dt / n_local
     if job.images:
         out["witness_program"] = c.witness_program()[1]
     if stats:
