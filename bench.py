@@ -324,7 +324,7 @@ class PowerSampler:
             if not pw or max(pw) < 400.0:  # (an idle card of the node: 245 W)
                 continue
             cap = self._read(c + "/power1_cap")
-            out.append({"card": c.split("/")[4], "samples": len(pw), "power_w_avg": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1),
+            out.append({"card": next((x for x in c.split("/") if x.startswith("card")), "?"), "samples": len(pw), "power_w_avg": round(sum(pw) / len(pw), 1), "power_w_max": round(max(pw), 1),
                         "power_cap_w": round(cap / 1e6, 1) if cap else None,
                         "sclk_mhz_avg": round(sum(fq) / len(fq), 1) if fq else None, "sclk_mhz_min": round(min(fq), 1) if fq else None,
                         "sclk_mhz_max": round(max(fq), 1) if fq else None})

@@ -311,3 +311,29 @@ def test_eight_ranks_of_plumbing_without_a_gpu(mode):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["collective"] == {"backend": "gloo", "ranks_seen": 8}
     assert d["value"] == 0.0 and "DRY RUN" in d["metric"] and d["mode"] == mode
+
+
+def test_the_power_sampler_reads_hwmon_files_and_is_silent_without_them(tmp_path, monkeypatch):
+    """bench.PowerSampler against a made-up hwmon tree (two cards, one idle), and on a box without any"""
+    import glob as glob_mod
+    import time
+
+    bench = _bench()
+    for card, watts, hz in (("card3", 1300e6, 2250e6), ("card4", 240e6, 150e6)):
+        d = tmp_path / "drm" / card / "device" / "hwmon" / "hwmon7"
+        d.mkdir(parents=True)
+        (d / "power1_input").write_text(f"{int(watts)}\n")
+        (d / "freq1_input").write_text(f"{int(hz)}\n")
+        (d / "power1_cap").write_text("1400000000\n")
+    real_glob = glob_mod.glob
+    monkeypatch.setattr(glob_mod, "glob", lambda pat: real_glob(pat.replace("/sys/class/drm", str(tmp_path / "drm"))))
+    s = bench.PowerSampler(period=0.005).start()
+    time.sleep(0.05)
+    got = s.stop()
+    assert [c["card"] for c in got["cards"]] == ["card3"] and all(c["power_w_avg"] == 1300.0 and c["sclk_mhz_avg"] == 2250.0 and c["power_cap_w"] == 1400.0
+                                                       for c in got["cards"]), got  # (the idle card is not reported)
+    assert len(got["cards"]) == 1 and got["cards"][0]["samples"] >= 2 and got["matched_by_pci_address"] is False
+    monkeypatch.setattr(glob_mod, "glob", lambda pat: [])
+    assert bench.PowerSampler().start().stop() == {}
+    line = json.loads(bench.format_line({**_oversized_record(), "power": {**got, "joules_per_proof": 0.8571234}}))
+    assert line["power"]["power_w_avg"] == 1300.0 and line["power"]["joules_per_proof"] == 0.857123
