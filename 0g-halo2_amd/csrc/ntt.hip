@@ -681,8 +681,8 @@ int ntt_run(zg_ctx* ctx, const NttPlan& p, Fe* tmp, size_t tmp_stride) {
     Fe* tw = nullptr;
     ZG_TRY(get_twiddles(ctx, p.log_n, p.omega, &tw));
     // nine-limb butterflies in the latency form (a lone proof: its transforms finish 7-15 % sooner), 8 x 32-bit ones in the
-    // throughput form (twelve provers hold the chip at its power limit, where the nine-limb pass's 27 % more multiply-adds
-    // cost the clock what its shorter instruction stream gains: measured +0.6 ... +0.9 % ms/proof); ZG_NTT9 = 0 / 1 forces one
+    // throughput form (under twelve provers the nine-limb pass measured +0.4 ... +0.6 % ms/proof: 127 VGPRs instead of 76, the CU's
+    // LDS full at four workgroups, 27 % more multiply-adds and a 0.7 % lower clock -- DESIGN.md section 5); ZG_NTT9 = 0 / 1 forces one
     const int k9 = knob(K_NTT9);
     const bool nine = k9 < 0 ? ctx->msm_pair : k9 != 0;
     if (ntt_log_t(p.log_n) == 10) return nine ? launch_passes<10, true>(ctx, p, tw, tmp, tmp_stride) : launch_passes<10, false>(ctx, p, tw, tmp, tmp_stride);

@@ -115,8 +115,8 @@ const char *zg_version(void);
  *   ZG_NTT9           the transforms' butterflies: 0 = on 8 x 32-bit limbs (a canonical value after every operation), 1 = on nine
  *                     29-bit limbs (limb-wise sums, no carry word in the products: a quarter fewer instructions per pass, 27 %
  *                     more multiply-adds; 36-byte elements in LDS).  Default: nine in the latency form (a lone proof: -0.3 / -1.7 /
- *                     -1.2 % at k = 14 / 15 / 17), eight in the throughput form (the chip is at its power limit there and the
- *                     nine-limb pass measured +0.6 % ms/proof).  Same bytes either way: what leaves a pass is canonical. */
+ *                     -1.2 % at k = 14 / 15 / 17), eight in the throughput form (the nine-limb pass measured +0.4 ... +0.6 % ms/proof
+ *                     under twelve provers: DESIGN.md section 5).  Same bytes either way: what leaves a pass is canonical. */
 int zg_tuning_set(const char *name, int value);
 int zg_tuning_get(const char *name, int *value);
 /* out[i] = name of knob i for i < min(cap, count); returns the count. */
