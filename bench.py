@@ -1176,7 +1176,8 @@ def measure_headline(job) -> dict:
     if LAST_POWER.get("cards"):
         out["power"] = dict(LAST_POWER)  # (this rank's card during the timed steps)
         # energy of one proof on this rank's card: what a power-limited chip is really short of
-        out["power"]["joules_per_proof"] = LAST_POWER["cards"][0]["power_w_avg"] * dt / n_local
+        if not (rk.world > 1 and "ZG_BENCH_DEVICE" in os.environ):  # (a rehearsal's ranks share one card: its power is not this rank's)
+            out["power"]["joules_per_proof"] = LAST_POWER["cards"][0]["power_w_avg"] * dt / n_local
     if job.images:
         out["witness_program"] = c.witness_program()[1]
     if stats:
