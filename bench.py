@@ -636,8 +636,8 @@ def cpu_baseline(c: Circuit, proof_len: int, threads: int, repeats: int = 7):
         "sample": f"median of {repeats} oracle create_proofs, k={c.k}, OpenMP x{threads}, no witness synthesis; expected SLOWER than real halo2",
         "sample_long": f"median of {repeats} full create_proofs of the same k={c.k} circuit (after 1 warm-up): {dt:.3f} s each; "
                        f"oracle/prover.c (plain-C restatement of halo2 create_proof, OpenMP {threads} threads); its evaluate_h "
-                       f"INTERPRETS the expanded gate monomials row by row (414 products per row at k=14) where halo2's GraphEvaluator runs "
-                       f"the shared expression graph (the `h` phase is {phases[mid][3] / max(phases[mid][6], 1e-9):.0%} of this proof; the key's "
+                       f"walks the expanded gate monomials row by row as prefix tries (135 products per row at k=14 for the gates) where halo2's "
+                       f"GraphEvaluator runs the shared expression graph (the `h` phase is {phases[mid][3] / max(phases[mid][6], 1e-9):.0%} of this proof; the key's "
                        f"polys and cosets are kept with the key as keygen_pk does), on {threads} of the machine's {os.cpu_count()} cores: expected SLOWER than real halo2 on the "
                        f"same cores -- a baseline to be read with that, never a speed-up claim",
         "wall_s": dt, "samples_s": [round(x, 4) for x in samples], "min_s": min(samples), "max_s": max(samples),

@@ -179,23 +179,83 @@ static int tr_read_scalar(transcript *t, orc_fr *s) {
 }
 
 /* ------------------------------------------------------------------ expression evaluation */
-/* value of polynomial `p` at `row` of arrays of length `size`, rotations scaled by rot_scale */
-static void eval_poly_row(orc_fr *out, const zg_circuit *cs, const zg_poly *p, const orc_fr *fixed,
-                          const orc_fr *advice, const orc_fr *instance, size_t size, size_t row,
-                          int64_t rot_scale) {
-    orc_fr acc = ORC_FR_ZERO;
-    for (uint32_t m = p->first; m < p->first + p->count; m++) {
-        const zg_monomial *mo = &cs->monomials[m];
-        orc_fr prod;
-        memcpy(&prod, &mo->coeff, 32);
-        for (uint32_t f = 0; f < mo->n_factors; f++) {
-            const zg_query *q = &cs->queries[mo->factors[f]];
-            int64_t idx = ((int64_t)row + (int64_t)q->rotation * rot_scale) % (int64_t)size;
-            if (idx < 0) idx += (int64_t)size;
-            const orc_fr *col = q->kind == ZG_FIXED ? fixed : q->kind == ZG_ADVICE ? advice : instance;
-            orc_fr_mul(&prod, &prod, &col[(size_t)q->column * size + (size_t)idx]);
+/* value of polynomial `p` at `row` of arrays of length `size`, rotations scaled by rot_scale: sum over its monomials of
+ * coeff * product of the queried cells.  The monomials of a polynomial, their factors sorted by query index, form a trie
+ * whose node is the product of the cells on its path -- a cell product that several monomials begin with is taken once (the
+ * twelve gates of WnnCircuit: 414 products per row as a flat list, 135 as tries).  halo2's GraphEvaluator shares the nodes of
+ * the expression graph in the same spirit (plonk/evaluation.rs); the field element is the same either way. */
+#define PLAN_NONE 0xffffffffu
+typedef struct {
+    uint32_t n_nodes, n_terms;
+    uint32_t *parent, *query;   /* [n_nodes]: node = parent's product (or 1) times cell(query) */
+    uint32_t *term_node;        /* [n_terms]: the node a monomial ends at (PLAN_NONE: a constant) */
+    uint8_t *term_kind;         /* 0: +1, 1: -1, 2: coeff */
+    const zg_monomial **term_mono;
+} poly_plan;
+
+static void poly_plan_build(poly_plan *pl, const zg_circuit *cs, const zg_poly *p) {
+    uint32_t cap = 1;
+    for (uint32_t m = p->first; m < p->first + p->count; m++) cap += cs->monomials[m].n_factors;
+    pl->parent = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    pl->query = (uint32_t *)malloc(cap * sizeof(uint32_t));
+    pl->term_node = (uint32_t *)malloc((p->count ? p->count : 1) * sizeof(uint32_t));
+    pl->term_kind = (uint8_t *)malloc(p->count ? p->count : 1);
+    pl->term_mono = (const zg_monomial **)malloc((p->count ? p->count : 1) * sizeof(void *));
+    pl->n_nodes = 0;
+    pl->n_terms = p->count;
+    orc_fr minus_one;
+    orc_fr_neg(&minus_one, &ORC_FR_ONE);
+    for (uint32_t t = 0; t < p->count; t++) {
+        const zg_monomial *mo = &cs->monomials[p->first + t];
+        uint32_t f[64], nf = mo->n_factors;
+        for (uint32_t i = 0; i < nf; i++) { /* insertion sort by query index */
+            uint32_t v = mo->factors[i], j = i;
+            while (j > 0 && f[j - 1] > v) { f[j] = f[j - 1]; j--; }
+            f[j] = v;
         }
-        orc_fr_add(&acc, &acc, &prod);
+        uint32_t node = PLAN_NONE;
+        for (uint32_t i = 0; i < nf; i++) {
+            uint32_t found = PLAN_NONE;
+            for (uint32_t c = 0; c < pl->n_nodes; c++)
+                if (pl->parent[c] == node && pl->query[c] == f[i]) { found = c; break; }
+            if (found == PLAN_NONE) {
+                found = pl->n_nodes++;
+                pl->parent[found] = node;
+                pl->query[found] = f[i];
+            }
+            node = found;
+        }
+        pl->term_node[t] = node;
+        pl->term_mono[t] = mo;
+        pl->term_kind[t] = memcmp(&mo->coeff, &ORC_FR_ONE, 32) == 0 ? 0 : memcmp(&mo->coeff, &minus_one, 32) == 0 ? 1 : 2;
+    }
+}
+static void poly_plan_free(poly_plan *pl) {
+    free(pl->parent); free(pl->query); free(pl->term_node); free(pl->term_kind); free((void *)pl->term_mono);
+}
+
+static void eval_plan_row(orc_fr *out, const zg_circuit *cs, const poly_plan *pl, const orc_fr *fixed, const orc_fr *advice,
+                          const orc_fr *instance, size_t size, size_t row, int64_t rot_scale) {
+    orc_fr val[pl->n_nodes ? pl->n_nodes : 1];
+    for (uint32_t i = 0; i < pl->n_nodes; i++) {
+        const zg_query *q = &cs->queries[pl->query[i]];
+        int64_t idx = ((int64_t)row + (int64_t)q->rotation * rot_scale) % (int64_t)size;
+        if (idx < 0) idx += (int64_t)size;
+        const orc_fr *col = q->kind == ZG_FIXED ? fixed : q->kind == ZG_ADVICE ? advice : instance;
+        const orc_fr *v = &col[(size_t)q->column * size + (size_t)idx];
+        if (pl->parent[i] == PLAN_NONE) val[i] = *v;
+        else orc_fr_mul(&val[i], &val[pl->parent[i]], v);
+    }
+    orc_fr acc = ORC_FR_ZERO, prod;
+    for (uint32_t t = 0; t < pl->n_terms; t++) {
+        const orc_fr *x = pl->term_node[t] == PLAN_NONE ? &ORC_FR_ONE : &val[pl->term_node[t]];
+        if (pl->term_kind[t] == 0) orc_fr_add(&acc, &acc, x);
+        else if (pl->term_kind[t] == 1) orc_fr_sub(&acc, &acc, x);
+        else {
+            memcpy(&prod, &pl->term_mono[t]->coeff, 32);
+            if (pl->term_node[t] != PLAN_NONE) orc_fr_mul(&prod, &prod, x);
+            orc_fr_add(&acc, &acc, &prod);
+        }
     }
     *out = acc;
 }
@@ -426,6 +486,22 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     int status = 0;
     const double t_start_ = now_ms();
     double t_prev_ = t_start_;
+    /* the polynomials this proof evaluates row by row (gates; the lookups' input and table expressions), as tries */
+    size_t n_lk_polys = 0;
+    for (size_t l = 0; l < NL; l++) n_lk_polys += 2 * (size_t)cs->lookups[l].width;
+    poly_plan *gate_plan = (poly_plan *)calloc(cs->n_gates ? cs->n_gates : 1, sizeof(poly_plan));
+    poly_plan *lk_plan = (poly_plan *)calloc(n_lk_polys ? n_lk_polys : 1, sizeof(poly_plan));
+    size_t *lk_plan_first = (size_t *)calloc(NL ? NL : 1, sizeof(size_t)); /* lookup l: inputs at [first + e], tables at [first + width + e] */
+    for (uint32_t g = 0; g < cs->n_gates; g++) poly_plan_build(&gate_plan[g], cs, &cs->gates[g]);
+    for (size_t l = 0, at = 0; l < NL; l++) {
+        const zg_lookup *lk = &cs->lookups[l];
+        lk_plan_first[l] = at;
+        for (uint32_t e = 0; e < lk->width; e++) {
+            poly_plan_build(&lk_plan[at + e], cs, &lk->inputs[e]);
+            poly_plan_build(&lk_plan[at + lk->width + e], cs, &lk->tables[e]);
+        }
+        at += 2 * (size_t)lk->width;
+    }
 
     transcript tr;
     tr_init(&tr, proof, cap);
@@ -468,10 +544,10 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
         for (long row = 0; row < (long)n; row++) {
             orc_fr ai = ORC_FR_ZERO, ti = ORC_FR_ZERO, v;
             for (uint32_t e = 0; e < lk->width; e++) {
-                eval_poly_row(&v, cs, &lk->inputs[e], pk->fixed_values, adv_val, inst_val, n, (size_t)row, 1);
+                eval_plan_row(&v, cs, &lk_plan[lk_plan_first[l] + e], pk->fixed_values, adv_val, inst_val, n, (size_t)row, 1);
                 orc_fr_mul(&ai, &ai, &theta);
                 orc_fr_add(&ai, &ai, &v);
-                eval_poly_row(&v, cs, &lk->tables[e], pk->fixed_values, adv_val, inst_val, n, (size_t)row, 1);
+                eval_plan_row(&v, cs, &lk_plan[lk_plan_first[l] + lk->width + e], pk->fixed_values, adv_val, inst_val, n, (size_t)row, 1);
                 orc_fr_mul(&ti, &ti, &theta);
                 orc_fr_add(&ti, &ti, &v);
             }
@@ -618,7 +694,7 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
             orc_fr value = ORC_FR_ZERO, t, u;
             /* custom gates */
             for (uint32_t g = 0; g < cs->n_gates; g++) {
-                eval_poly_row(&t, cs, &cs->gates[g], fix_cos, adv_cos, inst_cos, en, idx, rs);
+                eval_plan_row(&t, cs, &gate_plan[g], fix_cos, adv_cos, inst_cos, en, idx, rs);
                 orc_fr_mul(&value, &value, &y);
                 orc_fr_add(&value, &value, &t);
             }
@@ -669,10 +745,10 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
                 const zg_lookup *lk = &cs->lookups[l];
                 orc_fr ai = ORC_FR_ZERO, ti = ORC_FR_ZERO, v;
                 for (uint32_t e = 0; e < lk->width; e++) {
-                    eval_poly_row(&v, cs, &lk->inputs[e], fix_cos, adv_cos, inst_cos, en, idx, rs);
+                    eval_plan_row(&v, cs, &lk_plan[lk_plan_first[l] + e], fix_cos, adv_cos, inst_cos, en, idx, rs);
                     orc_fr_mul(&ai, &ai, &theta);
                     orc_fr_add(&ai, &ai, &v);
-                    eval_poly_row(&v, cs, &lk->tables[e], fix_cos, adv_cos, inst_cos, en, idx, rs);
+                    eval_plan_row(&v, cs, &lk_plan[lk_plan_first[l] + lk->width + e], fix_cos, adv_cos, inst_cos, en, idx, rs);
                     orc_fr_mul(&ti, &ti, &theta);
                     orc_fr_add(&ti, &ti, &v);
                 }
@@ -880,6 +956,9 @@ int orc_create_proof(const orc_pk *pk, const orc_fr *advice_in, const orc_fr *in
     free_key_material(own);
     free(random_poly); free(lz); free(pz);
 fail_early:
+    for (uint32_t g = 0; g < cs->n_gates; g++) poly_plan_free(&gate_plan[g]);
+    for (size_t i = 0; i < n_lk_polys; i++) poly_plan_free(&lk_plan[i]);
+    free(gate_plan); free(lk_plan); free(lk_plan_first);
     free(cin); free(ctab); free(pin); free(ptab);
     free(adv_val); free(inst_val); free(inst_poly);
     tr_free(&tr);
