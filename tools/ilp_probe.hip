@@ -93,5 +93,9 @@ int main() {
         run<0>(d, e0, e1, 256, threads, "one accumulator  , whole chip");
         run<1>(d, e0, e1, 256, threads, "column accumulators, whole chip");
     }
+    for (int rep = 0; rep < 3; rep++) {  // (one wave per SIMD on every CU, alternating: is the difference above the order of the runs?)
+        run<1>(d, e0, e1, 256, 256, "column accumulators, whole chip");
+        run<0>(d, e0, e1, 256, 256, "one accumulator  , whole chip");
+    }
     return bad;
 }
