@@ -1448,6 +1448,7 @@ def msm_only_main(args, rk) -> int:
     for x in xs:
         x.profile(not args.no_kernel_events)
     barrier()
+    sampler = PowerSampler().start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sums = step()
@@ -1455,6 +1456,7 @@ def msm_only_main(args, rk) -> int:
             WATCHDOG.pat()
     barrier()
     dt = max_over_ranks(rk, time.perf_counter() - t0)
+    power = sampler.stop()
     if WATCHDOG:
         WATCHDOG.arm(False)
     stats = {}
@@ -1478,6 +1480,8 @@ def msm_only_main(args, rk) -> int:
                "mode": "msm-only", "msms_per_step": vectors, "digit_width": width, "points_per_rank": hi - lo, "stub_world": stub or None, "us_per_msm": dt / (args.steps * vectors) * 1e6,
                "collective": collective_object(rk), "ranks_share_a_device": bool(rk.world > 1 and "ZG_BENCH_DEVICE" in os.environ),
                "runtime_env": RUNTIME_ENV, "detail_file": os.path.relpath(DETAIL, ROOT)}
+        if power.get("cards"):
+            out["power"] = power
         if stats:
             kernels, families, device_ms, _ = roofline_tables(stats, None, 1.0)
             acc = kernels.get("msm_accumulate")
